@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the UNMODIFIED reference (run in the build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Imports ``models.rendering`` / ``models.nerf`` straight from ``/root/reference`` (read-only mount,
+never present on the GPU box), executes them on CPU/fp32 with seeded synthetic inputs and stores
+inputs' recipe + outputs as small ``tests/golden/*.npz`` fixtures.  Weights are produced by
+``oracle_np.init_params(seed)`` (numpy RandomState: stable across torch versions) and loaded into the
+reference's ``NeRF`` through ``load_state_dict`` so that a fixture only needs to carry the seed.
+Random draws made by the reference (``torch.rand`` / ``torch.randn``) are recorded in call order and
+stored so the oracle / HIP path can be fed the very same numbers.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("SINNERF_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)          # reference first: its `datasets` pkg name clashes with HF datasets
+sys.path.insert(1, REPO)
+
+from models.nerf import NeRF, Embedding                      # noqa: E402  (reference)
+from models import rendering as ref_rendering                # noqa: E402  (reference)
+from oracle import oracle_np as O                            # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def ref_model(seed, teacher):
+    m = NeRF(use_new_activation=True)
+    p = O.init_params(seed, teacher)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    return m.eval(), p
+
+
+class RngTap:
+    """Record torch.rand/randn draws made inside the reference, in order."""
+
+    def __enter__(self):
+        self.draws = []
+        self._rand, self._randn = torch.rand, torch.randn
+
+        def rand(*a, **k):
+            t = self._rand(*a, **k); self.draws.append(("rand", t.numpy().copy())); return t
+
+        def randn(*a, **k):
+            t = self._randn(*a, **k); self.draws.append(("randn", t.numpy().copy())); return t
+        torch.rand, torch.randn = rand, randn
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randn = self._rand, self._randn
+
+
+def llff_like_rays(n, seed):
+    r = np.random.RandomState(seed)
+    W, H = 504, 378
+    f = W * 0.82
+    idx = r.choice(W * H, n, replace=False)
+    i, j = (idx % W).astype(np.float64), (idx // W).astype(np.float64)
+    d = np.stack([(i - W / 2) / f, -(j - H / 2) / f, -np.ones_like(i)], -1)
+    o = np.broadcast_to(np.array([0.1, -0.05, 0.2]), d.shape)
+    rays = np.concatenate([o, d, np.full((n, 1), 1.2), np.full((n, 1), 8.0)], 1).astype(np.float32)
+    return rays
+
+
+def case_render(name, rays, seeds, teacher, **kw):
+    mc, _ = ref_model(seeds[0], teacher)
+    mf, _ = ref_model(seeds[1], teacher)
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    torch.manual_seed(1234)
+    with torch.no_grad(), RngTap() as tap:
+        res = ref_rendering.render_rays([mc, mf], emb, torch.from_numpy(rays),
+                                        kw["N_samples"], kw.get("use_disp", False), kw["perturb"], kw["noise_std"],
+                                        kw["N_importance"], kw.get("chunk", 32768), kw["white_back"],
+                                        test_time=kw.get("test_time", False))
+    rng = {}
+    kinds = [k for k, _ in tap.draws]
+    draws = [d for _, d in tap.draws]
+    # consumption order: [perturb rand] -> coarse noise randn -> [u rand] -> fine noise randn
+    it = iter(zip(kinds, draws))
+    if kw["perturb"] > 0:
+        k, d = next(it); assert k == "rand"; rng["perturb"] = d
+    k, d = next(it); assert k == "randn"; rng["noise_coarse"] = d
+    if kw["N_importance"] > 0:
+        if kw["perturb"] > 0:
+            k, d = next(it); assert k == "rand"; rng["u"] = d
+        k, d = next(it); assert k == "randn"; rng["noise_fine"] = d
+    assert next(it, None) is None
+    meta = dict(seed_coarse=seeds[0], seed_fine=seeds[1], teacher=int(teacher),
+                use_disp=int(kw.get("use_disp", False)), test_time=int(kw.get("test_time", False)),
+                chunk=kw.get("chunk", 32768),
+                **{k: kw[k] for k in ("N_samples", "perturb", "noise_std", "N_importance", "white_back")})
+    arrays = {"rays": rays}
+    arrays.update({"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    arrays.update({"rng_" + k: v for k, v in rng.items()})
+    arrays.update({"out_" + k: v.numpy() for k, v in res.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print(name, {k: tuple(v.shape) for k, v in res.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    lego = O.lego_rays(400, 400, seed=0)
+    sel = np.random.RandomState(7).choice(lego.shape[0], 192, replace=False)
+    lego_s = np.ascontiguousarray(lego[sel])
+
+    case_render("render_lego_eval_teacher", lego_s, (0, 1), True, N_samples=64, perturb=0, noise_std=0,
+                N_importance=64, white_back=True)
+    case_render("render_lego_eval_rawinit", lego_s[:96], (2, 3), False, N_samples=64, perturb=0, noise_std=0,
+                N_importance=64, white_back=True, chunk=1024)
+    case_render("render_llff_eval_128", llff_like_rays(96, 5), (0, 1), True, N_samples=64, perturb=0, noise_std=0,
+                N_importance=128, white_back=False)
+    case_render("render_lego_train_teacher", lego_s[:128], (0, 1), True, N_samples=64, perturb=1.0, noise_std=1.0,
+                N_importance=64, white_back=True)
+    case_render("render_lego_testtime", lego_s[:64], (0, 1), True, N_samples=64, perturb=0, noise_std=0,
+                N_importance=64, white_back=True, test_time=True)
+    case_render("render_llff_disp_coarse_only", llff_like_rays(64, 9), (4, 5), True, N_samples=64, perturb=0.5,
+                noise_std=0.0, N_importance=0, white_back=False, use_disp=True)
+    case_render("render_ragged_small", lego_s[:37], (0, 1), True, N_samples=24, perturb=1.0, noise_std=0.5,
+                N_importance=40, white_back=False)
+
+    # ---- sample_pdf alone, incl. zero-weight rows and u at the ends (rendering.py:15-61)
+    r = np.random.RandomState(11)
+    n, m, k = 64, 62, 64
+    bins = np.sort(r.uniform(2, 6, (n, m + 1)).astype(np.float32), -1)
+    w = r.uniform(0, 1, (n, m)).astype(np.float32) ** 4
+    w[0] = 0.0                              # all-zero row -> uniform pdf
+    w[1, :30] = 0.0                         # long empty prefix
+    w[2] = 0.0; w[2, 17] = 1.0              # delta
+    u = r.uniform(0, 1, (n, k)).astype(np.float32)
+    u[3, 0] = 0.0; u[3, 1] = 1.0 - 2 ** -24
+    det = ref_rendering.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), k, det=True).numpy()
+    _rand = torch.rand
+    torch.rand = lambda *a, **kk: torch.from_numpy(u.copy())
+    try:
+        rnd = ref_rendering.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), k, det=False).numpy()
+    finally:
+        torch.rand = _rand
+    np.savez_compressed(os.path.join(OUT, "sample_pdf.npz"), bins=bins, weights=w, u=u, out_det=det, out_rand=rnd)
+
+    # ---- NeRF MLP + Embedding alone (nerf.py)
+    m0, _ = ref_model(6, True)
+    x3 = r.uniform(-4, 4, (300, 3)).astype(np.float32)
+    d3 = r.uniform(-1.2, 1.2, (300, 3)).astype(np.float32)
+    with torch.no_grad():
+        e_xyz = Embedding(3, 10)(torch.from_numpy(x3))
+        e_dir = Embedding(3, 4)(torch.from_numpy(d3))
+        full = m0(torch.cat([e_xyz, e_dir], 1))
+        sig = m0(e_xyz, sigma_only=True)
+    np.savez_compressed(os.path.join(OUT, "nerf_mlp.npz"), seed=np.asarray(6), teacher=np.asarray(1), xyz=x3, dir=d3,
+                        emb_xyz=e_xyz.numpy(), emb_dir=e_dir.numpy(), out_full=full.numpy(), out_sigma=sig.numpy())
+    # ---- parameter checksums guard init_params() against silent change
+    cs = {f"seed{s}_{int(t)}": np.float64(sum(float(np.sum(v, dtype=np.float64)) for v in O.init_params(s, t).values()))
+          for s in range(7) for t in (False, True)}
+    np.savez_compressed(os.path.join(OUT, "param_checksums.npz"), **cs)
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()

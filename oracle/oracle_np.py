@@ -1,0 +1,317 @@
+"""CPU oracle for the SinNeRF volume-rendering hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a numpy/fp32 *restatement* of the reference algorithm
+(VITA-Group/SinNeRF: ``models/nerf.py``, ``models/activations.py``,
+``models/rendering.py``).  It is the checker the HIP path is compared against.
+Nothing in the product package (``sinnerf_amd/``) may import it: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do.
+
+Parity pinning: the reference ships no tests / golden vectors, so this
+oracle is pinned against outputs of the *reference itself* executed in the build
+container (``oracle/gen_golden.py`` imports ``/root/reference`` and writes
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` replays them).
+
+Conventions
+-----------
+* everything is ``np.float32`` and every elementwise op is rounded separately, in
+  the order the reference executes it (torch eager = one rounding per op);
+* random draws are *inputs* (``rng`` dict) in the order the reference consumes the
+  generator: ``perturb`` (N,S) -> ``noise_coarse`` (N,S) -> ``u`` (N,N_imp) ->
+  ``noise_fine`` (N,S_f)   [rendering.py:281, :224, :43, :224];
+* ``params`` is a dict keyed exactly like ``NeRF.state_dict()``
+  (``xyz_encoding_1.0.weight`` ... ``rgb.0.bias``), values ``np.float32`` arrays.
+"""
+import numpy as np
+
+F = np.float32
+
+
+# --------------------------------------------------------------------------- nerf.py
+def embedding(x, n_freqs):
+    """Positional embedding, reference ``models/nerf.py:36-41`` (logscale bands, :20).
+
+    out = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], each 3 wide.
+    """
+    x = np.asarray(x, F)
+    out = [x]
+    for k in range(n_freqs):
+        f = F(2.0 ** k)
+        fx = (f * x).astype(F)          # exact: power-of-two scale
+        out.append(np.sin(fx).astype(F))
+        out.append(np.cos(fx).astype(F))
+    return np.concatenate(out, -1)
+
+
+def shifted_softplus(x):
+    """``models/activations.py:33-35``: log1p(exp(-|x-1|)) + (x-1)*[x-1>=0]."""
+    sx = (x - F(1)).astype(F)
+    a = np.abs(sx)
+    return (np.log1p(np.exp(-a).astype(F)).astype(F) + sx * (sx >= 0).astype(F)).astype(F)
+
+
+def widened_sigmoid(x):
+    """``models/activations.py:18-20``: .5*(1 + 1.002*tanh(.5 x))."""
+    scale = F(1.0 + 2.0 * 1e-3)
+    return (F(0.5) * (F(1) + scale * np.tanh((F(0.5) * x).astype(F)).astype(F))).astype(F)
+
+
+def _linear(x, w, b):
+    """nn.Linear: x @ W^T + b (``nerf.py:68-76``)."""
+    return (x @ w.T + b).astype(F)
+
+
+def nerf_forward(params, x, sigma_only=False, D=8, W=256, in_xyz=63, in_dir=27, skips=(4,),
+                 return_hidden=False):
+    """NeRF MLP forward, reference ``models/nerf.py:122-148`` with
+    ``use_new_activation=True`` (both call sites: sinnerf.py:137,140 / eval.py:136-137).
+
+    x: (B, 63[+27]) embedded input.  Returns (B,1) raw sigma if sigma_only else (B,4)=[rgb,sigma].
+    """
+    x = np.asarray(x, F)
+    if not sigma_only:
+        input_xyz, input_dir = x[:, :in_xyz], x[:, in_xyz:in_xyz + in_dir]   # :123-125
+    else:
+        input_xyz = x
+    h = input_xyz
+    hidden = []
+    for i in range(D):                                                       # :131-134
+        if i in skips:
+            h = np.concatenate([input_xyz, h], -1)                           # :133
+        h = _linear(h, params[f"xyz_encoding_{i+1}.0.weight"], params[f"xyz_encoding_{i+1}.0.bias"])
+        h = np.maximum(h, F(0))                                              # ReLU, :73
+        hidden.append(h)
+    sigma = _linear(h, params["sigma.weight"], params["sigma.bias"])        # :136
+    if sigma_only:
+        return sigma
+    final = _linear(h, params["xyz_encoding_final.weight"], params["xyz_encoding_final.bias"])  # :140
+    d_in = np.concatenate([final, input_dir], -1)                            # :142
+    d = shifted_softplus(_linear(d_in, params["dir_encoding.0.weight"], params["dir_encoding.0.bias"]))  # :143
+    rgb = widened_sigmoid(_linear(d, params["rgb.0.weight"], params["rgb.0.bias"]))                      # :144
+    out = np.concatenate([rgb, sigma], -1)                                   # :146
+    if return_hidden:
+        return out, hidden + [final, d]
+    return out
+
+
+# --------------------------------------------------------------------- rendering.py
+def linspace01(n):
+    """torch.linspace(0, 1, n) in fp32 as the CPU kernel evaluates it: step = 1/(n-1) in fp32;
+    lower half i*step, upper half fma(-(n-1-i), step, 1) (probe-verified bit-exact for
+    n in {5,7,33,64,128,192}).  Used at ``rendering.py:264`` and ``:40``."""
+    if n == 1:
+        return np.zeros(1, F)
+    step = F(1) / F(n - 1)
+    i = np.arange(n)
+    lo = (i.astype(F) * step).astype(F)
+    hi = (1.0 - (n - 1 - i).astype(np.float64) * np.float64(step)).astype(F)   # single rounding = fma
+    return np.where(i < n // 2, lo, hi).astype(F)
+
+
+def sample_pdf(bins, weights, n_importance, det=False, u=None, eps=1e-5):
+    """Inverse-CDF importance sampling, reference ``models/rendering.py:15-61``.
+
+    bins (N, M+1), weights (N, M).  ``u`` (N, n_importance) replaces ``torch.rand`` (:43) when det=False.
+    """
+    bins = np.asarray(bins, F)
+    n_rays, m = weights.shape
+    eps32 = F(eps)
+    w = (np.asarray(weights, F) + eps32).astype(F)                            # :30
+    pdf = (w / np.sum(w, -1, keepdims=True, dtype=F)).astype(F)               # :32
+    # torch's CPU cumsum/cumprod accumulate float inputs in double (acc_type) and round once per
+    # element (probe: bit-exact against torch 2.10 CPU); plain fp32 sequential scans are not.
+    cdf = np.cumsum(pdf.astype(np.float64), -1).astype(F)                     # :34
+    cdf = np.concatenate([np.zeros_like(cdf[:, :1]), cdf], -1)                # :36
+    if det:
+        u = np.broadcast_to(linspace01(n_importance), (n_rays, n_importance)) # :40-41
+    else:
+        assert u is not None and u.shape == (n_rays, n_importance)
+    u = np.ascontiguousarray(u, F)
+    # searchsorted(cdf, u, right=True) == number of cdf entries <= u         # :46
+    inds = np.empty((n_rays, n_importance), np.int64)
+    step = max(1, (1 << 22) // max(1, n_importance * (m + 1)))
+    for s in range(0, n_rays, step):
+        inds[s:s + step] = (cdf[s:s + step, None, :] <= u[s:s + step, :, None]).sum(-1)
+    below = np.maximum(inds - 1, 0)                                           # :47
+    above = np.minimum(inds, m)                                               # :48
+    cdf_b = np.take_along_axis(cdf, below, 1)                                 # :50-52
+    cdf_a = np.take_along_axis(cdf, above, 1)
+    bin_b = np.take_along_axis(bins, below, 1)
+    bin_a = np.take_along_axis(bins, above, 1)
+    denom = (cdf_a - cdf_b).astype(F)                                         # :54
+    denom = np.where(denom < eps32, F(1), denom)                              # :56
+    samples = (bin_b + ((u - cdf_b).astype(F) / denom).astype(F) * (bin_a - bin_b).astype(F)).astype(F)  # :59-60
+    return samples
+
+
+def composite(rgbsigma, z_vals, rays_d, noise, noise_std, white_back, weights_only=False):
+    """Alpha compositing, reference closure ``inference`` ``models/rendering.py:215-248``.
+
+    rgbsigma: (N,S,4) [rgb, raw sigma] or (N,S) raw sigma when weights_only.
+    noise: (N,S) standard normal draws (the reference always draws them, :224) or None (=0).
+    """
+    z_vals = np.asarray(z_vals, F)
+    if weights_only:
+        sigmas = np.asarray(rgbsigma, F)
+    else:
+        rgbs = rgbsigma[..., :3]
+        sigmas = rgbsigma[..., 3]
+    deltas = (z_vals[:, 1:] - z_vals[:, :-1]).astype(F)                       # :215
+    deltas = np.concatenate([deltas, np.full_like(deltas[:, :1], 1e10)], -1)  # :217-218
+    dnorm = np.sqrt(np.sum((rays_d * rays_d).astype(F), -1, keepdims=True, dtype=F)).astype(F)
+    deltas = (deltas * dnorm).astype(F)                                       # :222
+    if noise is None:
+        nz = np.zeros_like(sigmas)
+    else:
+        nz = (np.asarray(noise, F) * F(noise_std)).astype(F)                  # :224
+    alphas = (F(1) - np.exp((-deltas * np.maximum((sigmas + nz).astype(F), F(0))).astype(F)).astype(F)).astype(F)  # :228
+    shifted = np.concatenate([np.ones_like(alphas[:, :1]),
+                              ((F(1) - alphas).astype(F) + F(1e-10)).astype(F)], -1)                 # :229-231
+    trans = np.cumprod(shifted.astype(np.float64), -1).astype(F)[:, :-1]      # :233 (double accumulate, see sample_pdf)
+    weights = (alphas * trans).astype(F)                                      # :232-234
+    if weights_only:
+        return weights                                                        # :238-239
+    wsum = np.sum(weights, 1, dtype=F)                                        # :236
+    rgb = np.sum((weights[..., None] * rgbs).astype(F), -2, dtype=F)          # :242
+    depth = np.sum((weights * z_vals).astype(F), -1, dtype=F)                 # :243
+    if white_back:
+        rgb = ((rgb + F(1)).astype(F) - wsum[:, None]).astype(F)              # :246
+    return rgb, depth, weights
+
+
+def coarse_z_vals(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=None):
+    """Stratified depths, reference ``models/rendering.py:264-282``."""
+    rays = np.asarray(rays, F)
+    n_rays = rays.shape[0]
+    near, far = rays[:, 6:7], rays[:, 7:8]                                    # :258
+    t = linspace01(n_samples)[None, :]                                        # :264
+    if not use_disp:
+        z = ((near * (F(1) - t).astype(F)).astype(F) + (far * t).astype(F)).astype(F)        # :268
+    else:
+        z = (F(1) / (((F(1) / near).astype(F) * (F(1) - t).astype(F)).astype(F)
+                     + ((F(1) / far).astype(F) * t).astype(F)).astype(F)).astype(F)            # :270
+    z = np.broadcast_to(z, (n_rays, n_samples)).astype(F)                     # :272
+    if perturb > 0:                                                           # :274-282
+        mid = (F(0.5) * (z[:, :-1] + z[:, 1:]).astype(F)).astype(F)
+        upper = np.concatenate([mid, z[:, -1:]], -1)
+        lower = np.concatenate([z[:, :1], mid], -1)
+        pr = (F(perturb) * np.asarray(perturb_rand, F)).astype(F)
+        z = (lower + ((upper - lower).astype(F) * pr).astype(F)).astype(F)
+    return z
+
+
+def _points(rays, z):
+    """xyz = o + d*z, ``rendering.py:284-285, 317-318``."""
+    o, d = rays[:, None, 0:3], rays[:, None, 3:6]
+    return (o + (d * z[:, :, None]).astype(F)).astype(F)
+
+
+def _run_model(params, rays, z, dir_emb, weights_only, chunk):
+    """Point-chunk loop of closure ``inference`` (``rendering.py:185-212``)."""
+    n_rays, s = z.shape
+    xyz = _points(rays, z).reshape(-1, 3)                                     # :187
+    if not weights_only:
+        de = np.repeat(dir_emb, s, axis=0)                                    # :189-190
+    outs = []
+    for i in range(0, xyz.shape[0], chunk):                                   # :196
+        xe = embedding(xyz[i:i + chunk], 10)                                  # :198
+        if not weights_only:
+            xe = np.concatenate([xe, de[i:i + chunk]], 1)                     # :200-201
+        outs.append(nerf_forward(params, xe, sigma_only=weights_only))       # :204
+    out = np.concatenate(outs, 0)                                             # :206
+    return out.reshape(n_rays, s) if weights_only else out.reshape(n_rays, s, 4)
+
+
+def render_rays(models, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
+                chunk=1024 * 32, white_back=False, test_time=False, rng=None, return_z=False):
+    """Reference ``models/rendering.py:126-335``.  ``models`` = [coarse_params] or [coarse, fine]
+    (state_dict-keyed dicts).  ``rng`` supplies the draws (see module docstring); missing keys = zeros
+    (noise) and are required when perturb>0 (``perturb``, ``u``)."""
+    rng = rng or {}
+    rays = np.asarray(rays, F)
+    rays_d = rays[:, 3:6]
+    dir_emb = embedding(rays_d, 4)                                            # :261
+    z = coarse_z_vals(rays, N_samples, use_disp, perturb, rng.get("perturb"))  # :264-282
+    z_coarse = z
+    result = {}
+    if test_time:                                                             # :287-291
+        sig = _run_model(models[0], rays, z, dir_emb, True, chunk)
+        w_c = composite(sig, z, rays_d, rng.get("noise_coarse"), noise_std, white_back, weights_only=True)
+        result["opacity_coarse"] = w_c
+    else:                                                                     # :293-306
+        raw = _run_model(models[0], rays, z, dir_emb, False, chunk)
+        rgb_c, depth_c, w_c = composite(raw, z, rays_d, rng.get("noise_coarse"), noise_std, white_back)
+        result.update(rgb_coarse=rgb_c, depth_coarse=depth_c, opacity_coarse=w_c)
+    if N_importance > 0:                                                      # :308-328
+        mid = (F(0.5) * (z[:, :-1] + z[:, 1:]).astype(F)).astype(F)           # :310
+        z_f = sample_pdf(mid, w_c[:, 1:-1], N_importance, det=(perturb == 0), u=rng.get("u"))   # :311-312
+        z = np.sort(np.concatenate([z, z_f], -1), -1)                         # :315
+        raw = _run_model(models[1], rays, z, dir_emb, False, chunk)           # :322-324
+        rgb_f, depth_f, w_f = composite(raw, z, rays_d, rng.get("noise_fine"), noise_std, white_back)
+        result.update(rgb_fine=rgb_f, depth_fine=depth_f, opacity_fine=w_f)
+    else:                                                                     # :330-333
+        result.update(rgb_fine=result["rgb_coarse"], depth_fine=result["depth_coarse"],
+                      opacity_fine=result["opacity_coarse"])
+    if return_z:
+        result["_z_coarse"] = z_coarse
+        result["_z_fine"] = z
+    return result
+
+
+def psnr(a, b):
+    """``metrics.py:5-15``: -10 log10(mean((a-b)^2))."""
+    mse = np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)
+    return float(-10.0 * np.log10(mse))
+
+
+# ------------------------------------------------------------------ synthetic inputs
+_KEYS = ([f"xyz_encoding_{i+1}.0" for i in range(8)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"])
+_SHAPES = {"xyz_encoding_1.0": (256, 63), "xyz_encoding_5.0": (256, 319), "xyz_encoding_final": (256, 256),
+           "dir_encoding.0": (128, 283), "sigma": (1, 256), "rgb.0": (3, 128)}
+
+
+def param_shapes():
+    """state_dict key -> shape of ``NeRF(D=8, W=256, 63, 27, skips=[4])`` (``nerf.py:66-103``)."""
+    out = {}
+    for k in _KEYS:
+        shp = _SHAPES.get(k, (256, 256))
+        out[k + ".weight"] = shp
+        out[k + ".bias"] = (shp[0],)
+    return out
+
+
+def init_params(seed, teacher=False):
+    """Seeded stand-in for nn.Linear's default init (U(-1/sqrt(fan_in), 1/sqrt(fan_in))), numpy RNG.
+    ``teacher=True`` applies SURVEY §8d's non-degenerate-density variant (sigma.weight*8, sigma.bias=.3)."""
+    r = np.random.RandomState(seed)
+    p = {}
+    for k, shp in param_shapes().items():
+        fan_in = shp[1] if len(shp) == 2 else param_shapes()[k.replace(".bias", ".weight")][1]
+        b = 1.0 / np.sqrt(fan_in)
+        p[k] = r.uniform(-b, b, size=shp).astype(F)
+    if teacher:
+        p["sigma.weight"] = (p["sigma.weight"] * F(8)).astype(F)
+        p["sigma.bias"] = np.full((1,), 0.3, F)
+    return p
+
+
+def lego_rays(H, W, seed=0, camera_angle_x=0.6911112, radius=4.0, near=2.0, far=6.0, sel=None):
+    """Pin-hole rays as ``datasets/ray_utils.py:86-133`` builds them (un-normalised directions),
+    blender/lego intrinsics (``blender_ray_patch_1image_rot3d.py:201-211``), pose on a radius-4 sphere
+    looking at the origin (seed-indexed).  Returns (H*W, 8) = [o, d, near, far]."""
+    r = np.random.RandomState(1000 + seed)
+    focal = 0.5 * 800 / np.tan(0.5 * camera_angle_x) * (W / 800.0)
+    th, ph = r.uniform(0, 2 * np.pi), r.uniform(0.15, 0.45) * np.pi
+    c = radius * np.array([np.cos(th) * np.sin(ph), np.sin(th) * np.sin(ph), np.cos(ph)])
+    fwd = -c / np.linalg.norm(c)
+    up = np.array([0, 0, 1.0])
+    right = np.cross(fwd, up); right /= np.linalg.norm(right)
+    upv = np.cross(right, fwd)
+    c2w = np.stack([right, upv, -fwd, c], 1)                                  # (3,4)
+    j, i = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    dirs = np.stack([(i - W / 2) / focal, -(j - H / 2) / focal, -np.ones_like(i)], -1)
+    rays_d = dirs.reshape(-1, 3) @ c2w[:, :3].T
+    rays_o = np.broadcast_to(c2w[:, 3], rays_d.shape)
+    rays = np.concatenate([rays_o, rays_d, np.full((H * W, 1), near), np.full((H * W, 1), far)], 1).astype(F)
+    if sel is not None:
+        rays = rays[sel]
+    return np.ascontiguousarray(rays)
