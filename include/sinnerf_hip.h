@@ -1,0 +1,98 @@
+/* sinnerf_hip.h -- C ABI of libsinnerf_hip.so: the MI355X (gfx950) volume-rendering hot path of SinNeRF.
+ *
+ * The reference (VITA-Group/SinNeRF) has no FFI: its hot path is Python calling ATen ops
+ * (models/rendering.py::render_rays, models/nerf.py::{Embedding,NeRF}).  Each entry point below replaces the
+ * group of reference lines cited next to it; sinnerf_amd/rendering.py (the drop-in render_rays) binds them
+ * with ctypes -- see INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless the name ends in _host; tensors are dense row-major
+ * fp32; `stream` is a hipStream_t passed as void* (NULL = default stream).  Functions only enqueue work: no
+ * allocation, no synchronisation, no global state.  Return 0 on success, a negative SN_E_* code for argument
+ * errors, a positive value = hipError_t of a failed launch.
+ */
+#ifndef SINNERF_HIP_H
+#define SINNERF_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_ABI_VERSION 1
+
+#define SN_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32                                          */
+#define SN_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate                    */
+
+#define SN_E_BADARG (-1)
+#define SN_E_TOOLARGE (-2)
+#define SN_E_MISSING_RNG (-3)
+#define SN_E_UNSUPPORTED (-4)
+#define SN_E_BADSHAPE (-5)
+
+/* sn_mlp_forward flags */
+#define SN_FLAG_NO_LDS_DMA 1 /* stage weight slabs through VGPRs instead of global_load_lds (ablation/debug) */
+
+int sn_abi_version(void);
+const char* sn_error_string(int code);
+
+/* layout introspection (host only; mirrors csrc/sn_layout.h -- used by the CPU layout tests) */
+int sn_layout_xyz_slot_col(int lane_half, int slot); /* reference Embedding(3,10) column, -1 = zero pad */
+int sn_layout_dir_slot_col(int lane_half, int slot); /* reference Embedding(3,4) column, -1 = zero pad  */
+int sn_layout_slab_k(int slab);
+int sn_layout_n_slabs(void);
+
+/* ---- weights -------------------------------------------------------------------------------------------
+ * One NeRF MLP (models/nerf.py:66-103, NeRF(D=8,W=256,63,27,skips=[4],use_new_activation=True)) is consumed by
+ * the kernels as a "packed blob": weights reordered into MFMA A-fragment order (csrc/sn_layout.h).
+ * raw[24] = device pointers of the state_dict tensors in this order (names = nerf.py:75-103):
+ *   xyz_encoding_{1..8}.0.weight/.bias (16), xyz_encoding_final.weight/.bias, dir_encoding.0.weight/.bias,
+ *   sigma.weight/.bias, rgb.0.weight/.bias                                                              */
+#define SN_N_RAW_TENSORS 24
+long sn_packed_weights_bytes(int dtype);
+long sn_pack_table_entries(void);
+/* fills table_host[2*entries] int32 (dst byte offset, src tensor<<20|offset or -1); upload it once */
+int sn_build_pack_table(int dtype, int32_t* table_host);
+int sn_pack_weights(const float* const* raw_host_array_of_device_ptrs, const int32_t* table, void* blob, int dtype,
+                    void* stream);
+
+/* ---- models/rendering.py:264-282  z_vals = near*(1-t)+far*t (or disparity), stratified perturb -----------
+ * rays (n_rays,8) = [o(3), d(3), near, far] (rendering.py:257-258); perturb_rand (n_rays,n_samples) = the
+ * torch.rand draw of :281 (required iff perturb > 0); z_vals out (n_rays,n_samples).                      */
+int sn_sample_coarse(const float* rays, long n_rays, int n_samples, int use_disp, float perturb,
+                     const float* perturb_rand, float* z_vals, void* stream);
+
+/* ---- models/rendering.py:187-212 (closure `inference`, MLP part) + models/nerf.py:36-41,122-148 -----------
+ * For every sample point p = (ray, i): xyz = o + d*z (rendering.py:284-285), Embedding(xyz) (63), Embedding(d)
+ * (27), NeRF.forward.  out: (n_rays*n_samples, 4) = [rgb, raw sigma] (nerf.py:146), or (n_rays*n_samples)
+ * raw sigma when sigma_only (nerf.py:136-138).  Replaces the chunk loop of rendering.py:196-206.           */
+int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
+                   int sigma_only, int flags, float* out, void* stream);
+
+/* ---- models/nerf.py:105-148  NeRF.forward(x, sigma_only) on an already embedded matrix --------------------
+ * x (n_rows, ld) with columns [0,63) = embedded xyz and [63,90) = embedded dir (ignored when sigma_only).   */
+int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_rows, int ld, int sigma_only,
+                            int flags, float* out, void* stream);
+
+/* ---- models/rendering.py:215-246  deltas, noise, alpha, cumprod transmittance, weights, rgb/depth/white_back
+ * raw: (n_rays,n_samples,4) if has_rgb else (n_rays,n_samples) raw sigma (weights_only, rendering.py:238-239)
+ * noise: (n_rays,n_samples) torch.randn draw of :224 or NULL (= zeros).  rgb (n_rays,3), depth (n_rays) are
+ * written only when has_rgb; weights (n_rays,n_samples) always.                                           */
+int sn_composite_forward(const float* raw, int has_rgb, const float* z_vals, const float* rays, const float* noise,
+                         float noise_std, long n_rays, int n_samples, int white_back, float* rgb, float* depth,
+                         float* weights, void* stream);
+
+/* ---- models/rendering.py:15-61 (sample_pdf) + :310-315 (mid points, detach, cat + sort) -------------------
+ * z_vals/weights (n_rays,n_samples) coarse depths / compositing weights; u (n_rays,n_importance) = torch.rand
+ * draw of :43 or NULL for det=True (linspace, :40).  z_fine (n_rays,n_importance) optional (may be NULL),
+ * z_merged (n_rays, n_samples+n_importance) ascending.                                                     */
+int sn_sample_pdf(const float* z_vals, const float* weights, const float* u, long n_rays, int n_samples,
+                  int n_importance, float* z_fine, float* z_merged, void* stream);
+
+/* ---- models/rendering.py:15-61  sample_pdf(bins, weights, N_importance, det) exactly as the reference exposes
+ * it: bins (n_rays, n_bins+1), weights (n_rays, n_bins) -> samples (n_rays, n_importance); u as above.       */
+int sn_sample_pdf_bins(const float* bins, const float* weights, const float* u, long n_rays, int n_bins,
+                       int n_importance, float* samples, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

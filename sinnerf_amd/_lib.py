@@ -1,0 +1,79 @@
+"""ctypes binding of ``csrc/libsinnerf_hip.so`` (C ABI: ``include/sinnerf_hip.h``).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol cannot be resolved the
+import of this module raises, and every operator raises on non-CUDA tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsinnerf_hip.so")
+
+SN_DTYPE_F32 = 0
+SN_DTYPE_BF16 = 1
+SN_FLAG_NO_LDS_DMA = 1
+N_RAW_TENSORS = 24
+
+c_fp = ctypes.c_void_p      # device float*
+c_vp = ctypes.c_void_p
+_long, _int, _float = ctypes.c_long, ctypes.c_int, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/sinnerf_hip.h line by line
+SIGNATURES = {
+    "sn_abi_version": (_int, []),
+    "sn_error_string": (ctypes.c_char_p, [_int]),
+    "sn_layout_xyz_slot_col": (_int, [_int, _int]),
+    "sn_layout_dir_slot_col": (_int, [_int, _int]),
+    "sn_layout_slab_k": (_int, [_int]),
+    "sn_layout_n_slabs": (_int, []),
+    "sn_packed_weights_bytes": (_long, [_int]),
+    "sn_pack_table_entries": (_long, []),
+    "sn_build_pack_table": (_int, [_int, c_vp]),
+    "sn_pack_weights": (_int, [ctypes.POINTER(c_vp), c_vp, c_vp, _int, c_vp]),
+    "sn_sample_coarse": (_int, [c_fp, _long, _int, _int, _float, c_fp, c_fp, c_vp]),
+    "sn_mlp_forward": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
+    "sn_mlp_forward_embedded": (_int, [c_vp, _int, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
+    "sn_composite_forward": (_int, [c_fp, _int, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_vp]),
+    "sn_sample_pdf": (_int, [c_fp, c_fp, c_fp, _long, _int, _int, c_fp, c_fp, c_vp]),
+    "sn_sample_pdf_bins": (_int, [c_fp, c_fp, c_fp, _long, _int, _int, c_fp, c_vp]),
+}
+
+
+class SinnerfHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C sinnerf_amd/csrc`). There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError -> loud failure on a stale .so
+        fn.restype, fn.argtypes = res, args
+    if lib.sn_abi_version() != 1:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.sn_abi_version()} != 1; rebuild the extension")
+    return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib.sn_error_string(int(code))
+        raise SinnerfHipError(f"{what} failed: [{code}] {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """device pointer of a contiguous torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "sinnerf_amd kernels need contiguous tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,142 @@
+// sn_api.hip -- the extern "C" boundary declared in include/sinnerf_hip.h + the weight packer.
+#include "../../include/sinnerf_hip.h"
+#include "sn_device.h"
+#include "sn_layout.h"
+
+extern "C" {
+int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                              int sigma_only, int input_mode, int use_dma, float* out, hipStream_t stream);
+int sn_sample_coarse_launch(const float* rays, long n_rays, int n_samples, int use_disp, float perturb,
+                            const float* perturb_rand, float* z_out, hipStream_t stream);
+int sn_composite_forward_launch(const float* raw, int has_rgb, const float* z_vals, const float* rays,
+                                const float* noise, float noise_std, long n_rays, int n_samples, int white_back,
+                                float* rgb, float* depth, float* weights, hipStream_t stream);
+int sn_sample_pdf_launch(const float* z_vals, const float* weights, const float* u, long n_rays, int n_samples,
+                         int n_importance, float* z_fine, float* z_merged, hipStream_t stream);
+int sn_sample_pdf_bins_launch(const float* bins, const float* weights, const float* u, long n_rays, int n_bins,
+                              int n_importance, float* samples, hipStream_t stream);
+}
+
+namespace {
+struct RawPtrs { const float* p[snl::N_RAW]; };
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+__global__ void __launch_bounds__(256)
+pack_kernel(RawPtrs raw, const snl::PackEntry* __restrict__ table, long n, char* __restrict__ blob, long bias_off, int dtype) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const snl::PackEntry e = table[i];
+    float v = 0.0f;
+    if (e.src >= 0) {
+      const int t = e.src >> 20, off = e.src & 0xfffff;
+      const float* src = raw.p[0];
+#pragma unroll
+      for (int k = 1; k < snl::N_RAW; ++k) src = (t == k) ? raw.p[k] : src;
+      v = src[off];
+    }
+    if (dtype == snl::DT_F32 || e.dst >= bias_off) *reinterpret_cast<float*>(blob + e.dst) = v;
+    else *reinterpret_cast<unsigned short*>(blob + e.dst) = f32_to_bf16_rne(v);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int sn_abi_version(void) { return SN_ABI_VERSION; }
+
+// layout introspection (used by the CPU layout tests; csrc/sn_layout.h is the single source of truth)
+int sn_layout_xyz_slot_col(int h, int e) { return (h < 0 || h > 1 || e < 0 || e > 31) ? -2 : snl::xyz_slot_col(h, e); }
+int sn_layout_dir_slot_col(int h, int e) { return (h < 0 || h > 1 || e < 0 || e > 15) ? -2 : snl::dir_slot_col(h, e); }
+int sn_layout_slab_k(int slab) { return (slab < 0 || slab >= snl::N_SLABS) ? -2 : snl::slab_k(slab); }
+int sn_layout_n_slabs(void) { return snl::N_SLABS; }
+
+const char* sn_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case SN_E_BADARG: return "bad argument";
+    case SN_E_TOOLARGE: return "problem too large for one launch";
+    case SN_E_MISSING_RNG: return "perturb > 0 requires the perturb_rand tensor";
+    case SN_E_UNSUPPORTED: return "unsupported configuration (dtype / samples per ray)";
+    case SN_E_BADSHAPE: return "bad shape";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+long sn_packed_weights_bytes(int dtype) {
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
+  return snl::blob_bytes(dtype);
+}
+long sn_pack_table_entries(void) { return snl::table_entries(); }
+
+int sn_build_pack_table(int dtype, int32_t* table_host) {
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
+  if (!table_host) return SN_E_BADARG;
+  snl::build_pack_table(dtype, reinterpret_cast<snl::PackEntry*>(table_host));
+  return 0;
+}
+
+int sn_pack_weights(const float* const* raw, const int32_t* table, void* blob, int dtype, void* stream) {
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
+  if (!raw || !table || !blob) return SN_E_BADARG;
+  RawPtrs rp;
+  for (int i = 0; i < snl::N_RAW; ++i) {
+    if (!raw[i]) return SN_E_BADARG;
+    rp.p[i] = raw[i];
+  }
+  const long n = snl::table_entries();
+  hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, rp,
+                     reinterpret_cast<const snl::PackEntry*>(table), n, reinterpret_cast<char*>(blob),
+                     snl::bias_byte_offset(dtype), dtype);
+  return (int)hipGetLastError();
+}
+
+int sn_sample_coarse(const float* rays, long n_rays, int n_samples, int use_disp, float perturb,
+                     const float* perturb_rand, float* z_vals, void* stream) {
+  if (!rays || !z_vals || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  return sn_sample_coarse_launch(rays, n_rays, n_samples, use_disp, perturb, perturb_rand, z_vals, (hipStream_t)stream);
+}
+
+int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
+                   int sigma_only, int flags, float* out, void* stream) {
+  if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
+  return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
+                                   (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1, out, (hipStream_t)stream);
+}
+
+int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_rows, int ld, int sigma_only,
+                            int flags, float* out, void* stream) {
+  if (!blob || !x || !out || n_rows < 0) return SN_E_BADARG;
+  if (ld < (sigma_only ? 63 : 90)) return SN_E_BADSHAPE;
+  if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
+  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1,
+                                   out, (hipStream_t)stream);
+}
+
+int sn_composite_forward(const float* raw, int has_rgb, const float* z_vals, const float* rays, const float* noise,
+                         float noise_std, long n_rays, int n_samples, int white_back, float* rgb, float* depth,
+                         float* weights, void* stream) {
+  if (!raw || !z_vals || !rays || !weights || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  if (has_rgb && (!rgb || !depth)) return SN_E_BADARG;
+  return sn_composite_forward_launch(raw, has_rgb, z_vals, rays, noise, noise_std, n_rays, n_samples, white_back, rgb,
+                                     depth, weights, (hipStream_t)stream);
+}
+
+int sn_sample_pdf(const float* z_vals, const float* weights, const float* u, long n_rays, int n_samples,
+                  int n_importance, float* z_fine, float* z_merged, void* stream) {
+  if (!z_vals || !weights || !z_merged || n_rays < 0) return SN_E_BADARG;
+  return sn_sample_pdf_launch(z_vals, weights, u, n_rays, n_samples, n_importance, z_fine, z_merged, (hipStream_t)stream);
+}
+
+int sn_sample_pdf_bins(const float* bins, const float* weights, const float* u, long n_rays, int n_bins,
+                       int n_importance, float* samples, void* stream) {
+  if (!bins || !weights || !samples || n_rays < 0) return SN_E_BADARG;
+  return sn_sample_pdf_bins_launch(bins, weights, u, n_rays, n_bins, n_importance, samples, (hipStream_t)stream);
+}
+
+}  // extern "C"

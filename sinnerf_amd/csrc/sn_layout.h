@@ -1,0 +1,178 @@
+// sn_layout.h -- packed-weight ("MFMA fragment order") layout of one NeRF MLP, shared by the host
+// packer (table builder below, plain C++) and the device kernels (compile-time constants).
+//
+// Reference network: models/nerf.py:66-103 (NeRF(D=8,W=256,63,27,skips=[4],use_new_activation=True)).
+//
+// The fused MLP kernel computes every layer "transposed":  D[out_feature, point] = W * X^T, with the
+// weight matrix as the MFMA A operand (streamed through LDS) and the activations as the B operand
+// held in registers.  A 32x32 MFMA leaves D in the accumulator layout
+//      col (point)   = lane & 31
+//      row (feature) = (r & 3) + 8*(r >> 2) + 4*(lane >> 5),   r = accumulator register 0..15
+// and consumes B as  B[k][col = lane & 31]  with the k index split over (lane >> 5, register slot).
+// Because the order of the k index inside a contraction is free, the accumulators of layer n are fed
+// *unchanged* as the B operand of layer n+1; the host permutes the K order of layer n+1's weights to
+// match ("K-slot order").  No activation ever leaves the register file.
+//
+// K-slot order of a 32-feature hidden tile t (features 32t..32t+31), lane-half h = lane>>5:
+//      slot r (0..15)  <->  feature 32t + (r&3) + 8*(r>>2) + 4*h
+// fp32 path  (v_mfma_f32_32x32x2_f32):  one k-step = one slot      (k = h)
+// bf16 path  (v_mfma_f32_32x32x16_bf16): one k-step = 8 slots r = 8*(s&1)+i (k = 8h+i)
+//
+// Blob = sequence of "slabs" (one 32-row output tile x full K each, in execution order) followed by a
+// bias area.  A slab holds the A fragments in the exact order the wave reads them:
+//   fp32: [K/8 groups][64 lanes][4 k-steps]  float   (one ds_read_b128 feeds 4 MFMAs)
+//   bf16: [K/16 k-steps][64 lanes][8]        bf16    (one ds_read_b128 feeds 1 MFMA per point tile)
+// lane = 32*h + i  holds output row i of the tile.  Bias area: per slab 32 floats [h][r] (accumulator order).
+#pragma once
+#include <stdint.h>
+
+namespace snl {
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+// ---- network constants (padded K per layer kind)
+constexpr int W_HID = 256;
+constexpr int K_XYZ = 64;    // 63 embedded xyz features + 1 zero pad          (nerf.py:68)
+constexpr int K_DIRE = 32;   // 27 embedded dir features + 5 zero pads        (nerf.py:82)
+constexpr int K_L0 = K_XYZ;
+constexpr int K_HID = W_HID;
+constexpr int K_SKIP = K_XYZ + W_HID;    // cat([input_xyz, h])  nerf.py:133 (xyz FIRST)
+constexpr int K_DIR = W_HID + K_DIRE;    // cat([final, input_dir]) nerf.py:142 (dir LAST)
+constexpr int K_RGB = W_HID / 2;
+
+// ---- slab sequence (execution order)
+//  0.. 7  L0   (xyz_encoding_1)            K_L0
+//  8..31  L1-3 (xyz_encoding_2..4)         K_HID
+// 32..39  L4   (xyz_encoding_5, skip)      K_SKIP
+// 40..63  L5-7 (xyz_encoding_6..8)         K_HID
+// 64      SIG  (sigma, row 0 of the tile)  K_HID
+// 65..72  FIN  (xyz_encoding_final)        K_HID
+// 73..76  DIR  (dir_encoding)              K_DIR
+// 77      RGB  (rgb, rows 0..2)            K_RGB
+constexpr int N_SLABS = 78;
+constexpr int SLAB_SIG = 64, SLAB_FIN = 65, SLAB_DIR = 73, SLAB_RGB = 77;
+
+constexpr int slab_k(int s) {
+  return s < 8 ? K_L0 : s < 32 ? K_HID : s < 40 ? K_SKIP : s < 73 ? K_HID : s < 77 ? K_DIR : K_RGB;
+}
+// elements (of the weight dtype) per slab = 32 rows x K
+constexpr int slab_elems(int s) { return 32 * slab_k(s); }
+constexpr long slab_elem_offset(int s) {
+  long o = 0;
+  for (int i = 0; i < s; ++i) o += slab_elems(i);
+  return o;
+}
+constexpr long TOTAL_W_ELEMS = slab_elem_offset(N_SLABS);           // 606208
+constexpr int esize(int dt) { return dt == DT_F32 ? 4 : 2; }
+constexpr long bias_byte_offset(int dt) { return TOTAL_W_ELEMS * esize(dt); }
+constexpr int BIAS_FLOATS = N_SLABS * 32;
+constexpr long blob_bytes(int dt) { return bias_byte_offset(dt) + (long)BIAS_FLOATS * 4; }
+constexpr int MAX_SLAB_K = K_SKIP;
+
+// ---- raw tensor ids (order of NeRF.state_dict(): nerf.py:66-103)
+//  2*l, 2*l+1 : xyz_encoding_{l+1}.0.{weight,bias}  l=0..7
+//  16,17 xyz_encoding_final ; 18,19 dir_encoding.0 ; 20,21 sigma ; 22,23 rgb.0
+constexpr int N_RAW = 24;
+constexpr int RAW_FIN = 16, RAW_DIR = 18, RAW_SIG = 20, RAW_RGB = 22;
+
+// accumulator register r, lane half h -> row inside the 32-row tile
+constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- embedded-input slot maps (what each lane half computes itself, see sn_mlp_fwd.hip)
+// xyz: 32 slots per half.  e<30: pair p=e>>1 -> (band = 5h + p/3, coord = p%3), e&1: 0 sin, 1 cos
+//      e=30: h0 -> x, h1 -> z ; e=31: h0 -> y, h1 -> pad.  Reference column: nerf.py:36-41
+//      [x y z | sin(f0 xyz) cos(f0 xyz) | sin(f1 xyz) ...] -> 3 + 6*band + 3*fn + coord
+constexpr int xyz_slot_col(int h, int e) {
+  if (e < 30) { int p = e >> 1; return 3 + 6 * (5 * h + p / 3) + 3 * (e & 1) + p % 3; }
+  if (e == 30) return h == 0 ? 0 : 2;
+  return h == 0 ? 1 : -1;
+}
+// dir: 16 slots per half. e<12: pair p=e>>1 -> (band = 2h + p/3, coord = p%3); e=12,13: h0 -> dx,dy ; h1 -> dz,pad
+constexpr int dir_slot_col(int h, int e) {
+  if (e < 12) { int p = e >> 1; return 3 + 6 * (2 * h + p / 3) + 3 * (e & 1) + p % 3; }
+  if (e == 12) return h == 0 ? 0 : 2;
+  if (e == 13) return h == 0 ? 1 : -1;
+  return -1;
+}
+
+// K-slot (global slot index q within the layer's padded K, lane half h) -> raw weight column, or -1 (zero).
+// A layer's K is the concatenation of segments in the order the kernel walks them.
+constexpr int hid_slot_feature(int q, int h) { return 32 * (q >> 4) + acc_row(q & 15, h); }   // q in [0,128)
+
+constexpr int slab_raw_col(int slab, int q, int h) {
+  // q = slot index in [0, K/2)
+  if (slab < 8) return xyz_slot_col(h, q);                                  // L0: K = xyz
+  if (slab >= 32 && slab < 40) {                                            // skip: [xyz | hid]
+    if (q < 32) return xyz_slot_col(h, q);
+    return 63 + hid_slot_feature(q - 32, h);
+  }
+  if (slab >= SLAB_DIR && slab < SLAB_RGB) {                                // dir: [hid(final) | dir]
+    if (q < 128) return hid_slot_feature(q, h);
+    int c = dir_slot_col(h, q - 128);
+    return c < 0 ? -1 : 256 + c;
+  }
+  return hid_slot_feature(q, h);                                            // hidden / sig / fin / rgb (K=128: q<64)
+}
+// slab -> raw weight tensor id, first raw row of the tile, number of valid rows
+constexpr int slab_raw_w(int s) {
+  return s < 64 ? 2 * (s / 8) : s == SLAB_SIG ? RAW_SIG : s < SLAB_DIR ? RAW_FIN : s < SLAB_RGB ? RAW_DIR : RAW_RGB;
+}
+constexpr int slab_row0(int s) {
+  return s < 64 ? 32 * (s % 8) : s == SLAB_SIG ? 0 : s < SLAB_DIR ? 32 * (s - SLAB_FIN) : s < SLAB_RGB ? 32 * (s - SLAB_DIR) : 0;
+}
+constexpr int slab_rows(int s) { return s == SLAB_SIG ? 1 : s == SLAB_RGB ? 3 : 32; }
+constexpr int raw_cols(int raw_w) {
+  return raw_w == 0 ? 63 : raw_w == 8 ? 319 : raw_w == RAW_DIR ? 283 : raw_w == RAW_RGB ? 128 : 256;
+}
+
+// ---- host-side table: one entry per blob element.
+//  dst : byte offset into the blob
+//  src : -1 -> zero ; else (raw_tensor_id << 20) | flat element offset in that raw fp32 tensor
+//  The element is written as the weight dtype for dst < bias_byte_offset(dt), as fp32 otherwise.
+struct PackEntry { int32_t dst; int32_t src; };
+constexpr long table_entries() { return TOTAL_W_ELEMS + BIAS_FLOATS; }
+
+inline void build_pack_table(int dt, PackEntry* out) {
+  long n = 0;
+  const int es = esize(dt);
+  for (int s = 0; s < N_SLABS; ++s) {
+    const int K = slab_k(s), rw = slab_raw_w(s), row0 = slab_row0(s), rows = slab_rows(s), ncol = raw_cols(rw);
+    const long base = slab_elem_offset(s);
+    if (dt == DT_F32) {
+      for (int g = 0; g < K / 8; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j) {
+            const int i = lane & 31, h = lane >> 5, q = 4 * g + j;
+            const int col = slab_raw_col(s, q, h);
+            PackEntry e;
+            e.dst = (int32_t)((base + ((long)g * 64 + lane) * 4 + j) * es);
+            e.src = (i < rows && col >= 0) ? ((rw << 20) | ((row0 + i) * ncol + col)) : -1;
+            out[n++] = e;
+          }
+    } else {
+      for (int ks = 0; ks < K / 16; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int i = lane & 31, h = lane >> 5, q = 8 * ks + j;
+            const int col = slab_raw_col(s, q, h);
+            PackEntry e;
+            e.dst = (int32_t)((base + ((long)ks * 64 + lane) * 8 + j) * es);
+            e.src = (i < rows && col >= 0) ? ((rw << 20) | ((row0 + i) * ncol + col)) : -1;
+            out[n++] = e;
+          }
+    }
+  }
+  for (int s = 0; s < N_SLABS; ++s) {
+    const int rb = slab_raw_w(s) + 1, row0 = slab_row0(s), rows = slab_rows(s);
+    for (int h = 0; h < 2; ++h)
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, h);
+        PackEntry e;
+        e.dst = (int32_t)(bias_byte_offset(dt) + ((long)s * 32 + h * 16 + r) * 4);
+        e.src = row < rows ? ((rb << 20) | (row0 + row)) : -1;
+        out[n++] = e;
+      }
+  }
+}
+
+}  // namespace snl

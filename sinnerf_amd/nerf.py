@@ -1,0 +1,167 @@
+"""Drop-in ``Embedding`` / ``NeRF`` modules (reference: ``models/nerf.py:7-41, 46-148``).
+
+Same constructor arguments, attribute names and ``state_dict`` keys as the reference
+(``xyz_encoding_{1..8}.0.{weight,bias}``, ``xyz_encoding_final.*``, ``dir_encoding.0.*``, ``sigma.*``,
+``rgb.0.*`` -- the checkpoint contract of ``train.py:25-32`` / ``utils/__init__.py:60-83``), so reference
+checkpoints load unchanged and ``.parameters()`` feed the reference optimisers / DDP.  The arithmetic runs in
+``libsinnerf_hip.so``: ``NeRF.forward`` calls the fused MFMA kernel on a pre-embedded matrix, and
+``render_rays`` reads ``NeRF.packed()`` (weights re-ordered into MFMA fragment order) directly.
+
+There is no CPU fallback: calling these modules on CPU tensors raises.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_DTYPES = {"fp32": _lib.SN_DTYPE_F32, "float32": _lib.SN_DTYPE_F32, torch.float32: _lib.SN_DTYPE_F32,
+           "bf16": _lib.SN_DTYPE_BF16, "bfloat16": _lib.SN_DTYPE_BF16, torch.bfloat16: _lib.SN_DTYPE_BF16}
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32' or 'bf16')")
+
+
+class Embedding(nn.Module):
+    """``Embedding(in_channels, N_freqs, logscale=True)`` -- reference ``models/nerf.py:7-41``.
+
+    x -> (x, sin(2^k x), cos(2^k x), ...).  Inside ``render_rays`` the embedding is fused into the MLP kernel
+    (never materialised); this module exists for API compatibility and stand-alone use.  Its forward is plain
+    torch elementwise code on whatever device ``x`` lives on (it is not part of the accelerated hot path).
+    """
+
+    def __init__(self, in_channels, N_freqs, logscale=True):
+        super().__init__()
+        self.N_freqs = N_freqs
+        self.in_channels = in_channels
+        self.funcs = [torch.sin, torch.cos]
+        self.out_channels = in_channels * (len(self.funcs) * N_freqs + 1)
+        if logscale:
+            self.freq_bands = 2 ** torch.linspace(0, N_freqs - 1, N_freqs)
+        else:
+            self.freq_bands = torch.linspace(1, 2 ** (N_freqs - 1), N_freqs)
+        self.logscale = logscale
+
+    def forward(self, x):
+        out = [x]
+        for freq in self.freq_bands:
+            for func in self.funcs:
+                out.append(func(freq * x))
+        return torch.cat(out, -1)
+
+
+_PACK_TABLES = {}        # (device, dtype_code) -> int32 device tensor
+
+
+def _pack_table(device, code):
+    key = (str(device), code)
+    if key not in _PACK_TABLES:
+        n = _lib.lib.sn_pack_table_entries()
+        host = torch.empty((n, 2), dtype=torch.int32)
+        _lib.check(_lib.lib.sn_build_pack_table(code, ctypes.c_void_p(host.data_ptr())), "sn_build_pack_table")
+        _PACK_TABLES[key] = host.to(device)
+    return _PACK_TABLES[key]
+
+
+class NeRF(nn.Module):
+    """``NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False)``.
+
+    Reference ``models/nerf.py:46-148``.  The HIP kernels implement the configuration both reference call sites
+    construct (``sinnerf.py:137,140``, ``eval.py:136-137``): D=8, W=256, 63/27 inputs, skips=[4],
+    ``use_new_activation=True`` (ShiftedSoftplus / WidenedSigmoid heads).  Other configurations raise
+    ``NotImplementedError`` at construction.
+    """
+
+    def __init__(self, D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False,
+                 compute_dtype="fp32"):
+        super().__init__()
+        if (D, W, in_channels_xyz, in_channels_dir, list(skips)) != (8, 256, 63, 27, [4]) or not use_new_activation:
+            raise NotImplementedError(
+                "sinnerf_amd.NeRF implements the SinNeRF configuration NeRF(D=8, W=256, 63, 27, skips=[4], "
+                "use_new_activation=True) (models/sinnerf.py:137,140)")
+        self.D, self.W = D, W
+        self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
+        self.skips = skips
+        self.compute_dtype = compute_dtype
+        for i in range(D):                                           # nerf.py:66-75
+            if i == 0:
+                layer = nn.Linear(in_channels_xyz, W)
+            elif i in skips:
+                layer = nn.Linear(W + in_channels_xyz, W)
+            else:
+                layer = nn.Linear(W, W)
+            setattr(self, f"xyz_encoding_{i+1}", nn.Sequential(layer, nn.ReLU(True)))
+        self.xyz_encoding_final = nn.Linear(W, W)                    # nerf.py:76
+        # nn.Identity stands in for ShiftedSoftplus / WidenedSigmoid (parameter-free, applied in-kernel):
+        # keeps the state_dict keys "dir_encoding.0.*" / "rgb.0.*" of nerf.py:81-90.
+        self.dir_encoding = nn.Sequential(nn.Linear(W + in_channels_dir, W // 2), nn.Identity())
+        self.sigma = nn.Linear(W, 1)
+        self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Identity())
+        self._packed = {}          # dtype_code -> (blob tensor, version signature)
+
+    # ---- packed weights -------------------------------------------------------------------------------
+    def raw_tensors(self):
+        """The 24 parameter tensors in the order of ``include/sinnerf_hip.h`` (= state_dict order)."""
+        out = []
+        for i in range(self.D):
+            lin = getattr(self, f"xyz_encoding_{i+1}")[0]
+            out += [lin.weight, lin.bias]
+        out += [self.xyz_encoding_final.weight, self.xyz_encoding_final.bias,
+                self.dir_encoding[0].weight, self.dir_encoding[0].bias,
+                self.sigma.weight, self.sigma.bias, self.rgb[0].weight, self.rgb[0].bias]
+        return out
+
+    def _signature(self, raws):
+        return tuple((t.data_ptr(), t._version) for t in raws)
+
+    def packed(self, dtype=None):
+        """uint8 device tensor holding the weights in MFMA-fragment order (``csrc/sn_layout.h``); rebuilt
+        (one small gather kernel) whenever a parameter was modified in place or replaced."""
+        code = dtype_code(dtype if dtype is not None else self.compute_dtype)
+        raws = self.raw_tensors()
+        dev = raws[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("sinnerf_amd.NeRF: parameters must live on a ROCm device (no CPU fallback)")
+        sig = self._signature(raws)
+        hit = self._packed.get(code)
+        if hit is not None and hit[1] == sig and hit[0].device == dev:
+            return hit[0]
+        for t in raws:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("sinnerf_amd.NeRF: parameters must be contiguous float32 master weights")
+        blob = hit[0] if (hit is not None and hit[0].device == dev) else \
+            torch.empty(_lib.lib.sn_packed_weights_bytes(code), dtype=torch.uint8, device=dev)
+        arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[t.data_ptr() for t in raws])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.sn_pack_weights(arr, _lib.ptr(_pack_table(dev, code)), _lib.ptr(blob), code,
+                                                _lib.stream_ptr()), "sn_pack_weights")
+        self._packed[code] = (blob, sig)
+        return blob
+
+    # ---- nerf.py:105-148 ------------------------------------------------------------------------------
+    def forward(self, x, sigma_only=False):
+        """x: (B, 63[+27]) embedded input -> (B,4) [rgb, sigma] or (B,1) sigma (``nerf.py:105-148``)."""
+        if not x.is_cuda:
+            raise RuntimeError("sinnerf_amd.NeRF.forward: CUDA/ROCm tensors only (no CPU fallback)")
+        need = self.in_channels_xyz if sigma_only else self.in_channels_xyz + self.in_channels_dir
+        if x.dim() != 2 or x.shape[1] != need:
+            raise RuntimeError(f"expected input of shape (B, {need}), got {tuple(x.shape)}")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import mlp_embedded_autograd
+            return mlp_embedded_autograd(self, x, sigma_only)
+        return self._forward_nograd(x, sigma_only)
+
+    def _forward_nograd(self, x, sigma_only):
+        x = x.contiguous().float()
+        code = dtype_code(self.compute_dtype)
+        out = torch.empty((x.shape[0], 1 if sigma_only else 4), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.sn_mlp_forward_embedded(_lib.ptr(self.packed()), code, _lib.ptr(x), x.shape[0],
+                                                        x.shape[1], int(sigma_only), 0, _lib.ptr(out),
+                                                        _lib.stream_ptr()), "sn_mlp_forward_embedded")
+        return out

@@ -1,0 +1,171 @@
+"""Drop-in ``render_rays`` / ``sample_pdf`` (reference: ``models/rendering.py:15-61, 126-335``).
+
+Same 13-argument signature, same result-dict keys, same consumption order of the global torch RNG
+(perturb ``rand`` -> coarse-noise ``randn`` -> ``u`` ``rand`` -> fine-noise ``randn``; rendering.py:281, :224,
+:43, :224), so it can be monkey-patched over ``models.rendering.render_rays`` and called unchanged from
+``SinNeRF.forward`` (sinnerf.py:177-186) and ``eval.batched_inference`` (eval.py:96-107).
+
+The arithmetic runs in ``libsinnerf_hip.so`` (hand-written HIP for gfx950):
+
+    sn_sample_coarse      rendering.py:264-282   z_vals (+ stratified perturb)
+    sn_mlp_forward        rendering.py:187-212 + nerf.py:36-41,122-148   xyz=o+d*z, both embeddings, whole MLP
+    sn_composite_forward  rendering.py:215-246   alpha compositing
+    sn_sample_pdf         rendering.py:15-61, 310-315   importance sampling + sort
+
+torch is used for allocation, RNG draws and streams only.  There is no CPU fallback: CPU tensors raise.
+"""
+import torch
+
+from . import _lib
+from .nerf import NeRF, dtype_code
+
+__all__ = ["render_rays", "sample_pdf"]
+
+# Optional kernel-level timing hook (bench.py): when set to a list, every MLP launch appends
+# (n_points, sigma_only, start_event, end_event) recorded on the launch stream.
+PROFILE = None
+
+
+def _check_embeddings(embeddings):
+    ex, ed = embeddings[0], embeddings[1]
+    ok = (getattr(ex, "in_channels", None) == 3 and getattr(ex, "N_freqs", None) == 10 and
+          getattr(ed, "in_channels", None) == 3 and getattr(ed, "N_freqs", None) == 4 and
+          getattr(ex, "logscale", True) and getattr(ed, "logscale", True))
+    if not ok:
+        raise NotImplementedError("sinnerf_amd.render_rays fuses Embedding(3,10) / Embedding(3,4) (logscale) into "
+                                  "the MLP kernel (sinnerf.py:133-134, eval.py:134-135); other embeddings are unsupported")
+
+
+def _mlp(model, rays, z_vals, sigma_only, flags=0):
+    """closure ``inference`` of rendering.py:161-212, MLP part: (N,S) depths -> (N,S,4) or (N,S) raw sigma."""
+    n, s = z_vals.shape
+    out = torch.empty((n, s) if sigma_only else (n, s, 4), dtype=torch.float32, device=rays.device)
+    code = dtype_code(model.compute_dtype)
+    blob = model.packed()
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(_lib.lib.sn_mlp_forward(_lib.ptr(blob), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
+                                       int(sigma_only), flags, _lib.ptr(out), _lib.stream_ptr()), "sn_mlp_forward")
+    if PROFILE is not None:
+        ev1.record()
+        PROFILE.append((n * s, bool(sigma_only), ev0, ev1))
+    return out
+
+
+def _composite(raw, has_rgb, z_vals, rays, noise, noise_std, white_back):
+    """closure ``inference`` of rendering.py:214-248, compositing part."""
+    n, s = z_vals.shape
+    dev = rays.device
+    weights = torch.empty((n, s), dtype=torch.float32, device=dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev) if has_rgb else None
+    depth = torch.empty((n,), dtype=torch.float32, device=dev) if has_rgb else None
+    _lib.check(_lib.lib.sn_composite_forward(_lib.ptr(raw), int(has_rgb), _lib.ptr(z_vals), _lib.ptr(rays),
+                                             _lib.ptr(noise), float(noise_std), n, s, int(bool(white_back)),
+                                             _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(weights), _lib.stream_ptr()),
+               "sn_composite_forward")
+    return rgb, depth, weights
+
+
+def _forward_core(models, rays, N_samples, use_disp, perturb, noise_std, N_importance, white_back, test_time,
+                  flags=0, keep=None):
+    """No-grad forward of the whole path.  ``keep`` (dict) receives the intermediates the backward needs."""
+    dev = rays.device
+    n = rays.shape[0]
+    stream = _lib.stream_ptr()
+    perturb_rand = None
+    if perturb > 0:                                                      # rendering.py:281
+        perturb_rand = torch.rand((n, N_samples), device=dev)
+    z_vals = torch.empty((n, N_samples), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib.sn_sample_coarse(_lib.ptr(rays), n, N_samples, int(bool(use_disp)), float(perturb),
+                                         _lib.ptr(perturb_rand), _lib.ptr(z_vals), stream), "sn_sample_coarse")
+    result = {}
+    raw_c = _mlp(models[0], rays, z_vals, sigma_only=bool(test_time), flags=flags)
+    noise_c = torch.randn((n, N_samples), device=dev)                    # always drawn, rendering.py:224
+    rgb_c, depth_c, w_c = _composite(raw_c, not test_time, z_vals, rays, noise_c if noise_std != 0 else None,
+                                     noise_std, white_back)
+    if test_time:                                                        # rendering.py:287-291
+        result["opacity_coarse"] = w_c
+    else:                                                                # rendering.py:303-306
+        result.update(rgb_coarse=rgb_c, depth_coarse=depth_c, opacity_coarse=w_c)
+    if keep is not None:
+        keep.update(z_coarse=z_vals, raw_coarse=raw_c, noise_coarse=noise_c if noise_std != 0 else None)
+    if N_importance > 0:                                                 # rendering.py:308-328
+        u = torch.rand((n, N_importance), device=dev) if perturb > 0 else None      # det = (perturb == 0)
+        z_all = torch.empty((n, N_samples + N_importance), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib.sn_sample_pdf(_lib.ptr(z_vals), _lib.ptr(w_c), _lib.ptr(u), n, N_samples, N_importance,
+                                          None, _lib.ptr(z_all), stream), "sn_sample_pdf")
+        raw_f = _mlp(models[1], rays, z_all, sigma_only=False, flags=flags)
+        noise_f = torch.randn((n, N_samples + N_importance), device=dev)
+        rgb_f, depth_f, w_f = _composite(raw_f, True, z_all, rays, noise_f if noise_std != 0 else None, noise_std,
+                                         white_back)
+        result.update(rgb_fine=rgb_f, depth_fine=depth_f, opacity_fine=w_f)
+        if keep is not None:
+            keep.update(z_fine=z_all, raw_fine=raw_f, noise_fine=noise_f if noise_std != 0 else None)
+    else:                                                                # rendering.py:330-333
+        # (the reference raises NameError here when test_time=True; mirrored as KeyError-free explicit error)
+        if test_time:
+            raise NameError("name 'rgb_coarse' is not defined (render_rays(test_time=True) needs N_importance > 0, "
+                            "as in the reference: rendering.py:331)")
+        result.update(rgb_fine=rgb_c, depth_fine=depth_c, opacity_fine=w_c)
+    return result
+
+
+def render_rays(models,
+                embeddings,
+                rays,
+                N_samples=64,
+                use_disp=False,
+                perturb=0,
+                noise_std=1,
+                N_importance=0,
+                chunk=1024 * 32,
+                white_back=False,
+                test_time=False,
+                detach_coarse=False,
+                noisy_coarse=True,
+                ):
+    """Render rays -- drop-in for reference ``models/rendering.py:126-335`` (same arguments, same dict).
+
+    ``chunk`` only bounds temporary memory in the reference (its results are chunk-invariant); the fused kernel
+    needs no point chunking, so the argument is accepted and ignored.  ``noisy_coarse`` is unused in the
+    reference as well.
+    """
+    if not isinstance(rays, torch.Tensor) or not rays.is_cuda:
+        raise RuntimeError("sinnerf_amd.render_rays: rays must be a CUDA/ROCm tensor (there is no CPU fallback)")
+    if rays.dim() != 2 or rays.shape[1] != 8:
+        raise RuntimeError(f"rays must have shape (N_rays, 8), got {tuple(rays.shape)}")
+    for m in models:
+        if not isinstance(m, NeRF):
+            raise TypeError("sinnerf_amd.render_rays needs sinnerf_amd.NeRF models (state_dict-compatible with "
+                            "the reference NeRF; load reference weights with load_state_dict)")
+    if N_importance > 0 and len(models) < 2:
+        raise IndexError("list index out of range")          # models[1], rendering.py:321
+    _check_embeddings(embeddings)
+    rays = rays.contiguous().float()
+    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
+    with torch.cuda.device(rays.device):
+        if needs_grad:
+            from .autograd import render_rays_autograd
+            return render_rays_autograd(models, rays, N_samples, use_disp, perturb, noise_std, N_importance,
+                                        white_back, test_time, detach_coarse)
+        with torch.no_grad():
+            return _forward_core(models, rays, N_samples, use_disp, perturb, noise_std, N_importance, white_back,
+                                 test_time)
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
+    """Drop-in for reference ``models/rendering.py:15-61``: bins (N, M+1), weights (N, M) -> (N, N_importance)."""
+    if not bins.is_cuda:
+        raise RuntimeError("sinnerf_amd.sample_pdf: CUDA/ROCm tensors only (no CPU fallback)")
+    if abs(eps - 1e-5) > 1e-12:
+        raise NotImplementedError("sample_pdf: eps is fixed to the reference default 1e-5")
+    n, m = weights.shape
+    bins = bins.contiguous().float()
+    weights = weights.detach().contiguous().float()
+    with torch.cuda.device(bins.device):
+        u = None if det else torch.rand((n, N_importance), device=bins.device)        # rendering.py:43
+        out = torch.empty((n, N_importance), dtype=torch.float32, device=bins.device)
+        _lib.check(_lib.lib.sn_sample_pdf_bins(_lib.ptr(bins), _lib.ptr(weights), _lib.ptr(u), n, m, N_importance,
+                                               _lib.ptr(out), _lib.stream_ptr()), "sn_sample_pdf_bins")
+    return out

@@ -1,0 +1,109 @@
+"""Register-level numpy emulation of the fused MLP kernel's dataflow (csrc/sn_mlp_fwd.hip), CPU only.
+
+It follows the kernel slab by slab with the documented gfx950 MFMA semantics
+(/opt/skills/guides/cdna_hip_programming.md §3):
+  v_mfma_f32_32x32x2_f32  A: lane l holds A[i=l&31][k=l>>5] ; B: lane l holds B[k=l>>5][j=l&31]
+  C/D: lane l, register r  <->  D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]
+and consumes the packed blob produced by the library's own pack table, so it validates sn_layout.h (slot maps,
+K permutation, slab order, bias order) and the kernel's schedule against the oracle without a GPU.
+"""
+import ctypes
+
+import numpy as np
+
+LANES = np.arange(64)
+J, H = LANES & 31, LANES >> 5
+
+
+def acc_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def mfma_f32_32x32x2(a, b, acc):
+    """a, b: (64,) per-lane operand registers; acc: (64,16)."""
+    A = np.zeros((32, 2), np.float32); A[J, H] = a
+    B = np.zeros((2, 32), np.float32); B[H, J] = b
+    D = (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)
+    for r in range(16):
+        acc[:, r] += D[acc_row(r, H), J]
+
+
+def pack_blob(lib, params, dtype_code=0):
+    """Run the library's pack table on host numpy arrays (what pack_kernel does on the device)."""
+    order = ([f"xyz_encoding_{i+1}.0" for i in range(8)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"])
+    raws = []
+    for k in order:
+        raws += [params[k + ".weight"].reshape(-1), params[k + ".bias"].reshape(-1)]
+    n = lib.sn_pack_table_entries()
+    table = np.empty((n, 2), np.int32)
+    assert lib.sn_build_pack_table(dtype_code, ctypes.c_void_p(table.ctypes.data)) == 0
+    nbytes = lib.sn_packed_weights_bytes(dtype_code)
+    assert dtype_code == 0
+    blob = np.zeros(nbytes // 4, np.float32)
+    dst, src = table[:, 0] // 4, table[:, 1]
+    vals = np.zeros(n, np.float32)
+    ok = src >= 0
+    tid, off = src[ok] >> 20, src[ok] & 0xFFFFF
+    flat = np.concatenate(raws)
+    starts = np.cumsum([0] + [r.size for r in raws])[:-1]
+    vals[ok] = flat[starts[tid] + off]
+    assert len(np.unique(dst)) == n            # every blob element written exactly once
+    blob[dst] = vals
+    return blob, table
+
+
+def emulate_tile(lib, blob, x_embedded, sigma_only=False):
+    """x_embedded: (32, 90) rows = points of one tile.  Returns (32,4) or (32,)."""
+    from oracle.oracle_np import shifted_softplus, widened_sigmoid
+    n_slabs = lib.sn_layout_n_slabs()
+    slab_k = [lib.sn_layout_slab_k(s) for s in range(n_slabs)]
+    slab_off = np.cumsum([0] + [32 * k for k in slab_k])
+    bias = blob[slab_off[-1]:].reshape(n_slabs, 2, 16)
+
+    xe = np.zeros((64, 32), np.float32)
+    for e in range(32):
+        for h in (0, 1):
+            c = lib.sn_layout_xyz_slot_col(h, e)
+            if c >= 0:
+                xe[H == h, e] = x_embedded[:, c]
+    de = np.zeros((64, 16), np.float32)
+    for e in range(16):
+        for h in (0, 1):
+            c = lib.sn_layout_dir_slot_col(h, e)
+            if c >= 0:
+                de[H == h, e] = x_embedded[:, 63 + c]
+
+    def run_slab(s, segments):
+        acc = bias[s][H].copy()                                     # load_bias(): [h][r]
+        frags = blob[slab_off[s]:slab_off[s + 1]].reshape(-1, 64, 4)   # [group][lane][4]
+        g = 0
+        for b in segments:
+            for q in range(0, b.shape[1], 4):
+                for jj in range(4):
+                    mfma_f32_32x32x2(frags[g, :, jj], b[:, q + jj], acc)
+                g += 1
+        assert g == frags.shape[0]
+        return acc
+
+    s = 0
+    nxt = np.zeros((64, 128), np.float32)
+    for t in range(8):
+        nxt[:, 16 * t:16 * t + 16] = np.maximum(run_slab(s, [xe]), 0); s += 1
+    hid = nxt.copy()
+    for l in range(1, 8):
+        for t in range(8):
+            nxt[:, 16 * t:16 * t + 16] = np.maximum(run_slab(s, [xe, hid] if l == 4 else [hid]), 0); s += 1
+        hid = nxt.copy()
+    sigma = run_slab(s, [hid])[:, 0]; s += 1
+    if sigma_only:
+        return sigma[:32]
+    for t in range(8):
+        nxt[:, 16 * t:16 * t + 16] = run_slab(s, [hid]); s += 1
+    hid = nxt.copy()
+    h2 = np.zeros((64, 64), np.float32)
+    for t in range(4):
+        h2[:, 16 * t:16 * t + 16] = shifted_softplus(run_slab(s, [hid, de])); s += 1
+    acc = run_slab(s, [h2]); s += 1
+    assert s == n_slabs
+    rgb = widened_sigmoid(acc[:32, :3])
+    return np.concatenate([rgb, sigma[:32, None]], 1)

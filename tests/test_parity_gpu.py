@@ -1,0 +1,251 @@
+"""GPU parity tests: the HIP path (through the C ABI, via sinnerf_amd) against the numpy oracle and the
+golden vectors generated from the reference.  Run with `pytest -m gpu` on an MI355X."""
+import contextlib
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_np as O                                              # noqa: E402
+from tests.helpers import (GOLDEN, RENDER_CASES, check_render, load_case, max_abs, max_rel, sample_pdf_tol,  # noqa: E402
+                           well_conditioned)
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def make_model(seed, teacher, dtype="fp32"):
+    import sinnerf_amd
+    m = sinnerf_amd.NeRF(use_new_activation=True, compute_dtype=dtype)
+    p = O.init_params(seed, teacher)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    return m.to(dev()).eval(), p
+
+
+def embeddings():
+    import sinnerf_amd
+    return [sinnerf_amd.Embedding(3, 10), sinnerf_amd.Embedding(3, 4)]
+
+
+@contextlib.contextmanager
+def injected_rng(order):
+    """Make torch.rand / torch.randn return the recorded draws (in the reference's consumption order)."""
+    q = list(order)
+    real_rand, real_randn = torch.rand, torch.randn
+
+    def take(kind, shape):
+        k, arr = q.pop(0)
+        assert k == kind and tuple(arr.shape) == tuple(shape), (k, kind, arr.shape, shape)
+        return torch.from_numpy(arr).to(dev())
+
+    torch.rand = lambda *a, **kw: take("rand", a[0] if isinstance(a[0], (tuple, list)) else a)
+    torch.randn = lambda *a, **kw: take("randn", a[0] if isinstance(a[0], (tuple, list)) else a)
+    try:
+        yield q
+    finally:
+        torch.rand, torch.randn = real_rand, real_randn
+
+
+def rng_order(meta, rng, n):
+    """Draws in consumption order; noise draws are made even when the fixture did not keep them."""
+    order = []
+    s, ni = meta["N_samples"], meta["N_importance"]
+    if meta["perturb"] > 0:
+        order.append(("rand", rng["perturb"]))
+    order.append(("randn", rng.get("noise_coarse", np.zeros((n, s), np.float32))))
+    if ni > 0:
+        if meta["perturb"] > 0:
+            order.append(("rand", rng["u"]))
+        order.append(("randn", rng.get("noise_fine", np.zeros((n, s + ni), np.float32))))
+    return order
+
+
+def to_np(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+# ------------------------------------------------------------------------------------------- stages
+@pytest.mark.parametrize("S,use_disp,perturb", [(64, False, 0.0), (64, False, 1.0), (64, True, 0.5), (24, False, 1.0),
+                                                (128, False, 0.0), (192, True, 1.0)])
+def test_sample_coarse_bit_exact(S, use_disp, perturb):
+    from sinnerf_amd import _lib
+    rays = O.lego_rays(40, 40, seed=1)[::3]
+    n = rays.shape[0]
+    pr = np.random.RandomState(0).uniform(0, 1, (n, S)).astype(np.float32)
+    ref = O.coarse_z_vals(rays, S, use_disp, perturb, pr)
+    r = torch.from_numpy(rays).to(dev())
+    z = torch.empty((n, S), device=dev())
+    prt = torch.from_numpy(pr).to(dev())
+    _lib.check(_lib.lib.sn_sample_coarse(_lib.ptr(r), n, S, int(use_disp), perturb, _lib.ptr(prt) if perturb > 0 else None,
+                                         _lib.ptr(z), None), "sn_sample_coarse")
+    torch.cuda.synchronize()
+    assert np.array_equal(z.cpu().numpy(), ref)            # integer-like bar: identical bits
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("sigma_only", [False, True])
+def test_mlp_forward_vs_oracle(flags, sigma_only):
+    from sinnerf_amd import rendering
+    model, p = make_model(0, True)
+    rays = O.lego_rays(400, 400, seed=0)[::1601][:100]      # 100 rays -> 6400 points (50 workgroups, ragged tail below)
+    n = rays.shape[0]
+    z = O.coarse_z_vals(rays, 67, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n, 67)).astype(np.float32))
+    ref = O._run_model(p, rays, z, O.embedding(rays[:, 3:6], 4), sigma_only, 1 << 20)
+    with torch.no_grad():
+        out = rendering._mlp(model, torch.from_numpy(rays).to(dev()), torch.from_numpy(z).to(dev()), sigma_only, flags)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref) / (np.abs(ref) + 1e-3)
+    assert err.max() <= 2e-4, err.max()
+
+
+def test_nerf_forward_embedded_golden():
+    z = np.load(f"{GOLDEN}/nerf_mlp.npz")
+    model, _ = make_model(int(z["seed"]), bool(z["teacher"]))
+    x = torch.from_numpy(np.concatenate([z["emb_xyz"], z["emb_dir"]], 1)).to(dev())
+    with torch.no_grad():
+        full = model(x).cpu().numpy()
+        sig = model(x[:, :63].contiguous(), sigma_only=True).cpu().numpy()
+    assert full.shape == (300, 4) and sig.shape == (300, 1)
+    assert (np.abs(full - z["out_full"]) / (np.abs(z["out_full"]) + 1e-3)).max() <= 2e-4
+    assert (np.abs(sig - z["out_sigma"]) / (np.abs(z["out_sigma"]) + 1e-3)).max() <= 2e-4
+
+
+@pytest.mark.parametrize("S,white_back,noise_std,has_rgb", [(64, True, 0.0, True), (128, False, 1.0, True),
+                                                            (192, True, 0.5, True), (24, False, 1.0, True),
+                                                            (64, True, 1.0, False), (100, False, 0.0, True)])
+def test_composite_vs_oracle(S, white_back, noise_std, has_rgb):
+    from sinnerf_amd import rendering
+    r = np.random.RandomState(S)
+    rays = O.lego_rays(30, 30, seed=2)[::7]
+    n = rays.shape[0]
+    z = np.sort(r.uniform(2, 6, (n, S)).astype(np.float32), -1)
+    raw = r.uniform(0, 1, (n, S, 4)).astype(np.float32)
+    raw[..., 3] = (r.standard_normal((n, S)) * 3).astype(np.float32)
+    noise = r.standard_normal((n, S)).astype(np.float32)
+    inp = raw if has_rgb else np.ascontiguousarray(raw[..., 3])
+    ref = O.composite(inp, z, rays[:, 3:6], noise if noise_std else None, noise_std, white_back, weights_only=not has_rgb)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    rgb, depth, w = rendering._composite(t(inp), has_rgb, t(z), t(rays), t(noise) if noise_std else None, noise_std, white_back)
+    torch.cuda.synchronize()
+    if has_rgb:
+        assert max_abs(w.cpu().numpy(), ref[2]) <= 2e-7
+        assert max_abs(rgb.cpu().numpy(), ref[0]) <= 1e-6
+        assert max_rel(depth.cpu().numpy(), ref[1]) <= 2e-6
+    else:
+        assert max_abs(w.cpu().numpy(), ref) <= 2e-7
+
+
+def test_sample_pdf_golden_and_oracle():
+    import sinnerf_amd
+    z = np.load(f"{GOLDEN}/sample_pdf.npz")
+    bins, w, u = (torch.from_numpy(z[k]).to(dev()) for k in ("bins", "weights", "u"))
+    det = sinnerf_amd.sample_pdf(bins, w, 64, det=True).cpu().numpy()
+    with injected_rng([("rand", z["u"])]):
+        rnd = sinnerf_amd.sample_pdf(bins, w, 64, det=False).cpu().numpy()
+    lin = O.linspace01(64)[None].repeat(64, 0)
+    for got, ref, uu in ((det, z["out_det"], lin), (rnd, z["out_rand"], z["u"])):
+        ok = well_conditioned(z["bins"], z["weights"], uu)
+        tol = sample_pdf_tol(z["bins"], z["weights"], uu)
+        assert (np.abs(got - ref) <= tol)[ok].all()
+        assert (got >= z["bins"][:, :1] - 1e-6).all() and (got <= z["bins"][:, -1:] + 1e-6).all()
+
+
+def test_sample_pdf_merge_sorted_and_complete():
+    from sinnerf_amd import _lib
+    r = np.random.RandomState(5)
+    for S, NI, rand_u in ((64, 64, False), (64, 128, True), (24, 40, True), (64, 64, True)):
+        rays = O.lego_rays(20, 20, seed=3)[::3]
+        n = rays.shape[0]
+        zc = O.coarse_z_vals(rays, S, False, 1.0, r.uniform(0, 1, (n, S)).astype(np.float32))
+        w = (r.uniform(0, 1, (n, S)) ** 3).astype(np.float32)
+        u = r.uniform(0, 1, (n, NI)).astype(np.float32) if rand_u else None
+        mid = (np.float32(0.5) * (zc[:, :-1] + zc[:, 1:])).astype(np.float32)
+        zf_ref = O.sample_pdf(mid, w[:, 1:-1], NI, det=not rand_u, u=u)
+        t = lambda a: torch.from_numpy(a).to(dev())
+        zf = torch.empty((n, NI), device=dev()); zm = torch.empty((n, S + NI), device=dev())
+        _lib.check(_lib.lib.sn_sample_pdf(_lib.ptr(t(zc)), _lib.ptr(t(w)), _lib.ptr(t(u)) if rand_u else None, n, S, NI,
+                                          _lib.ptr(zf), _lib.ptr(zm), None), "sn_sample_pdf")
+        torch.cuda.synchronize()
+        zf, zm = zf.cpu().numpy(), zm.cpu().numpy()
+        assert (np.diff(zm, axis=-1) >= 0).all()                                   # sortedness
+        assert np.array_equal(zm, np.sort(np.concatenate([zc, zf], -1), -1))       # a permutation of the inputs
+        uu = u if rand_u else O.linspace01(NI)[None].repeat(n, 0)
+        ok = well_conditioned(mid, w[:, 1:-1], uu)
+        assert (np.abs(zf - zf_ref) <= sample_pdf_tol(mid, w[:, 1:-1], uu))[ok].all()
+
+
+# ------------------------------------------------------------------------------------- whole path
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_render_rays_golden(name):
+    import sinnerf_amd
+    rays, meta, rng, ref = load_case(name)
+    mc, _ = make_model(meta["seed_coarse"], bool(meta["teacher"]))
+    mf, _ = make_model(meta["seed_fine"], bool(meta["teacher"]))
+    with torch.no_grad(), injected_rng(rng_order(meta, rng, rays.shape[0])) as left:
+        res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays).to(dev()), meta["N_samples"],
+                                      bool(meta["use_disp"]), meta["perturb"], meta["noise_std"], meta["N_importance"],
+                                      meta["chunk"], bool(meta["white_back"]), test_time=bool(meta["test_time"]))
+        assert not left, "render_rays consumed fewer random draws than the reference"
+    torch.cuda.synchronize()
+    assert set(res.keys()) == set(ref.keys())
+    check_render(to_np(res), ref, tag=name)
+
+
+def test_render_rays_matches_oracle_on_subset_of_full_frame_and_properties():
+    """BASELINE config[1] size: lego 400x400 (160 000 rays), 64+64, fp32.  The oracle is too slow for the full
+    frame, so: (a) a 256-ray subset of the frame against the oracle, (b) size-independent properties on the
+    full frame: ray-chunk invariance (bit-exact), ray-permutation equivariance, weights in
+    [0,1] with sum <= 1, finite outputs."""
+    import sinnerf_amd
+    mc, pc = make_model(0, True)
+    mf, pf = make_model(1, True)
+    rays_np = O.lego_rays(400, 400, seed=0)
+    rays = torch.from_numpy(rays_np).to(dev())
+    kw = dict(N_samples=64, use_disp=False, perturb=0, noise_std=0, N_importance=64, chunk=1 << 19, white_back=True)
+    with torch.no_grad():
+        full = sinnerf_amd.render_rays([mc, mf], embeddings(), rays, **kw)
+        sel = torch.from_numpy(np.random.RandomState(3).permutation(160000)).to(dev())
+        perm = sinnerf_amd.render_rays([mc, mf], embeddings(), rays[sel].contiguous(), **kw)
+        half = sinnerf_amd.render_rays([mc, mf], embeddings(), rays[80000:].contiguous(), **kw)
+    torch.cuda.synchronize()
+    for k, v in full.items():
+        assert torch.isfinite(v).all(), k
+        assert torch.equal(v[sel], perm[k]), f"permutation equivariance broken for {k}"
+        assert torch.equal(v[80000:], half[k]), f"chunk invariance broken for {k}"
+    for k in ("opacity_coarse", "opacity_fine"):
+        assert (full[k] >= 0).all() and (full[k] <= 1).all() and (full[k].sum(1) <= 1 + 1e-5).all()
+    idx = np.random.RandomState(4).choice(160000, 256, replace=False)
+    ref = O.render_rays([pc, pf], rays_np[idx], 64, False, 0, 0, 64, 1 << 19, True, False)
+    check_render({k: v[torch.from_numpy(idx).to(dev())].cpu().numpy() for k, v in full.items()}, ref, tag="frame-subset")
+
+
+def test_psnr_parity_teacher_scene():
+    """SURVEY §8d PSNR protocol: gt = oracle render of the teacher scene + fixed pixel noise; |PSNR(new,gt) -
+    PSNR(oracle,gt)| <= 0.05 dB (north_star)."""
+    import sinnerf_amd
+    mc, pc = make_model(0, True)
+    mf, pf = make_model(1, True)
+    rays_np = O.lego_rays(48, 48, seed=2)
+    ref = O.render_rays([pc, pf], rays_np, 64, False, 0, 0, 64, 1 << 19, True, False)["rgb_fine"]
+    gt = ref + np.random.RandomState(0).normal(0, 0.02, ref.shape).astype(np.float32)
+    with torch.no_grad():
+        got = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays_np).to(dev()), 64, False, 0, 0, 64,
+                                      1 << 19, True)["rgb_fine"].cpu().numpy()
+    assert abs(O.psnr(got, gt) - O.psnr(ref, gt)) <= 0.05
+    assert O.psnr(got, ref) > 80.0
+
+
+def test_errors_are_loud():
+    import sinnerf_amd
+    mc, _ = make_model(0, True)
+    with pytest.raises(RuntimeError):
+        sinnerf_amd.render_rays([mc], embeddings(), torch.zeros(4, 8), 64)          # CPU tensor: no fallback
+    with pytest.raises(NameError):
+        with torch.no_grad():
+            sinnerf_amd.render_rays([mc], embeddings(), torch.zeros(4, 8, device=dev()), 64, test_time=True)
