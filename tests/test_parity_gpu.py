@@ -167,9 +167,12 @@ def test_sample_pdf_merge_sorted_and_complete():
         u = r.uniform(0, 1, (n, NI)).astype(np.float32) if rand_u else None
         mid = (np.float32(0.5) * (zc[:, :-1] + zc[:, 1:])).astype(np.float32)
         zf_ref = O.sample_pdf(mid, w[:, 1:-1], NI, det=not rand_u, u=u)
-        t = lambda a: torch.from_numpy(a).to(dev())
+        # keep every device tensor referenced until the launch has been enqueued (a temporary passed as
+        # `_lib.ptr(t(x))` is freed -- and its block re-used by the next temporary -- before the call)
+        zc_d, w_d = torch.from_numpy(zc).to(dev()), torch.from_numpy(w).to(dev())
+        u_d = torch.from_numpy(u).to(dev()) if rand_u else None
         zf = torch.empty((n, NI), device=dev()); zm = torch.empty((n, S + NI), device=dev())
-        _lib.check(_lib.lib.sn_sample_pdf(_lib.ptr(t(zc)), _lib.ptr(t(w)), _lib.ptr(t(u)) if rand_u else None, n, S, NI,
+        _lib.check(_lib.lib.sn_sample_pdf(_lib.ptr(zc_d), _lib.ptr(w_d), _lib.ptr(u_d), n, S, NI,
                                           _lib.ptr(zf), _lib.ptr(zm), None), "sn_sample_pdf")
         torch.cuda.synchronize()
         zf, zm = zf.cpu().numpy(), zm.cpu().numpy()
