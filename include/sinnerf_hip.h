@@ -51,8 +51,12 @@ long sn_packed_weights_bytes(int dtype);
 long sn_pack_table_entries(void);
 /* fills table_host[2*entries] int32 (dst byte offset, src tensor<<20|offset or -1); upload it once */
 int sn_build_pack_table(int dtype, int32_t* table_host);
-int sn_pack_weights(const float* const* raw_host_array_of_device_ptrs, const int32_t* table, void* blob, int dtype,
-                    void* stream);
+int sn_pack_weights(const float* const* raw_host_array_of_device_ptrs, const int32_t* table, long n_entries,
+                    void* blob, int dtype, void* stream);
+/* transposed-weight blob consumed by sn_mlp_backward_chain (fp32; same table format, same packer) */
+long sn_packed_weights_bytes_bwd(void);
+long sn_pack_table_entries_bwd(void);
+int sn_build_pack_table_bwd(int32_t* table_host);
 
 /* ---- models/rendering.py:264-282  z_vals = near*(1-t)+far*t (or disparity), stratified perturb -----------
  * rays (n_rays,8) = [o(3), d(3), near, far] (rendering.py:257-258); perturb_rand (n_rays,n_samples) = the
@@ -66,6 +70,27 @@ int sn_sample_coarse(const float* rays, long n_rays, int n_samples, int use_disp
  * raw sigma when sigma_only (nerf.py:136-138).  Replaces the chunk loop of rendering.py:196-206.           */
 int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                    int sigma_only, int flags, float* out, void* stream);
+
+/* ---- training forward: sn_mlp_forward + the activations autograd would keep alive --------------
+ * acts (10, n_points, 256): slots 0..7 = outputs of xyz_encoding_1..8 (post-ReLU), 8 = xyz_encoding_final,
+ * 9 = dir_encoding output (128 wide, leading dimension 256).  emb (n_points, 96): columns [0,63) Embedding(xyz),
+ * [64,91) Embedding(dir) in the reference's column order (nerf.py:36-41), other columns zero.               */
+int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
+                         float* out, float* acts, float* emb, void* stream);
+
+/* ---- backward of models/nerf.py:122-148 w.r.t. layer outputs (what loss.backward() at sinnerf.py:551 runs) ----
+ * blob_bwd: transposed-weight blob (sn_build_pack_table_bwd).  out_raw / g_raw (n_points,4): forward output and its
+ * gradient.  Writes g_acts (10, n_points, 256): slots 0..7 = dL/d(pre-activation) of xyz_encoding_1..8, 8 = of
+ * xyz_encoding_final, 9 = of dir_encoding (128 wide); g_out (n_points,4) = dL/d(pre-activation) of rgb (3), sigma (1).
+ * Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.   */
+int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
+                          long n_points, float* g_acts, float* g_out, void* stream);
+
+/* ---- backward of models/rendering.py:215-246 w.r.t. raw=[rgb,sigma]; g_rgb (n_rays,3), g_depth (n_rays),
+ * g_weights (n_rays,n_samples) are upstream gradients (any may be NULL = zeros); g_raw (n_rays,n_samples,4).  */
+int sn_composite_backward(const float* raw, const float* z_vals, const float* rays, const float* noise, float noise_std,
+                          long n_rays, int n_samples, int white_back, const float* g_rgb, const float* g_depth,
+                          const float* g_weights, float* g_raw, void* stream);
 
 /* ---- models/nerf.py:105-148  NeRF.forward(x, sigma_only) on an already embedded matrix --------------------
  * x (n_rows, ld) with columns [0,63) = embedded xyz and [63,90) = embedded dir (ignored when sigma_only).   */

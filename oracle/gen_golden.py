@@ -162,5 +162,58 @@ def main():
     print("done ->", OUT)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--grads" not in sys.argv:
     main()
+
+
+def case_grad(name, rays, seeds, **kw):
+    """Golden parameter gradients from the reference's autograd (train mode) for a linear loss with seeded
+    coefficients; stores per-tensor norms, 256 sampled entries per tensor and the full bias gradients."""
+    mc, _ = ref_model(seeds[0], True)
+    mf, _ = ref_model(seeds[1], True)
+    mc.train(); mf.train()
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    n = rays.shape[0]
+    r = np.random.RandomState(99)
+    coef = {"rgb_coarse": r.standard_normal((n, 3)), "depth_coarse": r.standard_normal(n) * 0.3,
+            "rgb_fine": r.standard_normal((n, 3)), "depth_fine": r.standard_normal(n) * 0.3}
+    coef = {k: v.astype(np.float32) for k, v in coef.items()}
+    torch.manual_seed(4321)
+    with RngTap() as tap:
+        res = ref_rendering.render_rays([mc, mf], emb, torch.from_numpy(rays), kw["N_samples"], False, kw["perturb"],
+                                        kw["noise_std"], kw["N_importance"], 32768, kw["white_back"])
+        loss = sum((res[k] * torch.from_numpy(v)).sum() for k, v in coef.items())
+    loss.backward()
+    draws = [d for _, d in tap.draws]
+    names = ["perturb", "noise_coarse", "u", "noise_fine"] if kw["perturb"] > 0 else ["noise_coarse", "noise_fine"]
+    arrays = {"rays": rays, "loss": np.asarray(loss.item())}
+    arrays.update({"rng_" + k: v for k, v in zip(names, draws)})
+    arrays.update({"coef_" + k: v for k, v in coef.items()})
+    arrays.update({"meta_" + k: np.asarray(v) for k, v in dict(seed_coarse=seeds[0], seed_fine=seeds[1], **kw).items()})
+    arrays.update({"out_" + k: v.detach().numpy() for k, v in res.items()})
+    idx_r = np.random.RandomState(5)
+    for tag, m in (("coarse", mc), ("fine", mf)):
+        for k, p in m.named_parameters():
+            g = p.grad.numpy()
+            arrays[f"gnorm_{tag}.{k}"] = np.asarray(np.linalg.norm(g.astype(np.float64)))
+            if g.ndim == 1:
+                arrays[f"gfull_{tag}.{k}"] = g
+            else:
+                idx = idx_r.choice(g.size, min(256, g.size), replace=False)
+                arrays[f"gidx_{tag}.{k}"] = idx
+                arrays[f"gval_{tag}.{k}"] = g.reshape(-1)[idx]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print(name, "loss", loss.item())
+
+
+def main_grads():
+    lego = O.lego_rays(400, 400, seed=0)
+    sel = np.random.RandomState(17).choice(lego.shape[0], 96, replace=False)
+    case_grad("grad_lego_train", np.ascontiguousarray(lego[sel]), (0, 1), N_samples=64, perturb=1.0, noise_std=1.0,
+              N_importance=64, white_back=True)
+    case_grad("grad_lego_det", np.ascontiguousarray(lego[sel[:48]]), (2, 3), N_samples=64, perturb=0, noise_std=0,
+              N_importance=64, white_back=False)
+
+
+if __name__ == "__main__" and "--grads" in sys.argv:
+    main_grads()

@@ -61,7 +61,7 @@ def _linear(x, w, b):
 
 
 def nerf_forward(params, x, sigma_only=False, D=8, W=256, in_xyz=63, in_dir=27, skips=(4,),
-                 return_hidden=False):
+                 return_hidden=False, cache=None):
     """NeRF MLP forward, reference ``models/nerf.py:122-148`` with
     ``use_new_activation=True`` (both call sites: sinnerf.py:137,140 / eval.py:136-137).
 
@@ -80,14 +80,20 @@ def nerf_forward(params, x, sigma_only=False, D=8, W=256, in_xyz=63, in_dir=27, 
         h = _linear(h, params[f"xyz_encoding_{i+1}.0.weight"], params[f"xyz_encoding_{i+1}.0.bias"])
         h = np.maximum(h, F(0))                                              # ReLU, :73
         hidden.append(h)
+        if cache is not None:
+            cache[f"h{i+1}"] = h
     sigma = _linear(h, params["sigma.weight"], params["sigma.bias"])        # :136
     if sigma_only:
         return sigma
     final = _linear(h, params["xyz_encoding_final.weight"], params["xyz_encoding_final.bias"])  # :140
     d_in = np.concatenate([final, input_dir], -1)                            # :142
-    d = shifted_softplus(_linear(d_in, params["dir_encoding.0.weight"], params["dir_encoding.0.bias"]))  # :143
-    rgb = widened_sigmoid(_linear(d, params["rgb.0.weight"], params["rgb.0.bias"]))                      # :144
+    y2 = _linear(d_in, params["dir_encoding.0.weight"], params["dir_encoding.0.bias"])
+    d = shifted_softplus(y2)                                                 # :143
+    y3 = _linear(d, params["rgb.0.weight"], params["rgb.0.bias"])
+    rgb = widened_sigmoid(y3)                                                # :144
     out = np.concatenate([rgb, sigma], -1)                                   # :146
+    if cache is not None:
+        cache.update(x=x, final=final, y2=y2, d=d, y3=y3)
     if return_hidden:
         return out, hidden + [final, d]
     return out
@@ -261,6 +267,120 @@ def psnr(a, b):
     """``metrics.py:5-15``: -10 log10(mean((a-b)^2))."""
     mse = np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)
     return float(-10.0 * np.log10(mse))
+
+
+# ------------------------------------------------------------ backward (autograd restated)
+def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None):
+    """Parameter gradients of ``nerf_forward`` (non sigma_only) for upstream ``g_out`` (B,4) -- what torch autograd
+    derives from ``models/nerf.py:122-148`` + ``models/activations.py`` (Linear: gW = g^T x, gb = sum g, gx = g W;
+    ReLU(inplace): g*[out>0]; ShiftedSoftplus': sigmoid(x-1); WidenedSigmoid': .2505*(1-tanh(.5x)^2)).
+    float64 accumulation (reference = fp32 autograd; compare with a norm-wise tolerance)."""
+    f8 = np.float64
+    g = {}
+    x = cache["x"].astype(f8)
+    input_xyz, input_dir = x[:, :in_xyz], x[:, in_xyz:]
+    g_rgb, g_sigma = g_out[:, :3].astype(f8), g_out[:, 3:4].astype(f8)
+    t = np.tanh(0.5 * cache["y3"].astype(f8))
+    g_y3 = g_rgb * (0.5 * 1.002 * 0.5) * (1.0 - t * t)
+    d = cache["d"].astype(f8)
+    g["rgb.0.weight"], g["rgb.0.bias"] = g_y3.T @ d, g_y3.sum(0)
+    if gy_out is not None:
+        gy_out["rgb"], gy_out["sigma"] = g_y3, g_sigma
+    g_d = g_y3 @ params["rgb.0.weight"].astype(f8)
+    g_y2 = g_d / (1.0 + np.exp(-(cache["y2"].astype(f8) - 1.0)))
+    d_in = np.concatenate([cache["final"].astype(f8), input_dir], -1)
+    g["dir_encoding.0.weight"], g["dir_encoding.0.bias"] = g_y2.T @ d_in, g_y2.sum(0)
+    g_final = (g_y2 @ params["dir_encoding.0.weight"].astype(f8))[:, :256]
+    if gy_out is not None:
+        gy_out["dir"], gy_out["final"] = g_y2, g_final
+    h8 = cache[f"h{D}"].astype(f8)
+    g["xyz_encoding_final.weight"], g["xyz_encoding_final.bias"] = g_final.T @ h8, g_final.sum(0)
+    g["sigma.weight"], g["sigma.bias"] = g_sigma.T @ h8, g_sigma.sum(0)
+    g_h = g_final @ params["xyz_encoding_final.weight"].astype(f8) + g_sigma @ params["sigma.weight"].astype(f8)
+    for i in reversed(range(D)):
+        h_out = cache[f"h{i+1}"]
+        g_y = g_h * (h_out > 0)
+        if gy_out is not None:
+            gy_out[f"l{i+1}"] = g_y
+        if i == 0:
+            xin = input_xyz
+        else:
+            xin = cache[f"h{i}"].astype(f8)
+            if i in skips:
+                xin = np.concatenate([input_xyz, xin], -1)
+        g[f"xyz_encoding_{i+1}.0.weight"], g[f"xyz_encoding_{i+1}.0.bias"] = g_y.T @ xin, g_y.sum(0)
+        if i > 0:
+            g_x = g_y @ params[f"xyz_encoding_{i+1}.0.weight"].astype(f8)
+            g_h = g_x[:, in_xyz:] if i in skips else g_x
+    return g
+
+
+def composite_backward(rgbsigma, z_vals, rays_d, noise, noise_std, white_back, g_rgb, g_depth, g_w=None):
+    """Gradient of ``composite`` w.r.t. ``rgbsigma`` (N,S,4): autograd of ``rendering.py:215-246`` (z_vals / deltas
+    carry no gradient: z is data, the fine z_vals are detached at :312).  float64."""
+    f8 = np.float64
+    z = np.asarray(z_vals, F)
+    rgbs, sigmas = rgbsigma[..., :3].astype(f8), rgbsigma[..., 3]
+    deltas = (z[:, 1:] - z[:, :-1]).astype(F)
+    deltas = np.concatenate([deltas, np.full_like(deltas[:, :1], 1e10)], -1)
+    dnorm = np.sqrt(np.sum((rays_d * rays_d).astype(F), -1, keepdims=True, dtype=F)).astype(F)
+    deltas = (deltas * dnorm).astype(F).astype(f8)
+    nz = np.zeros_like(sigmas) if noise is None else (np.asarray(noise, F) * F(noise_std)).astype(F)
+    s_pre = (sigmas + nz).astype(F)
+    s = np.maximum(s_pre, F(0)).astype(f8)
+    e = np.exp(-deltas * s)
+    alphas = 1.0 - e
+    f = 1.0 - alphas + 1e-10
+    trans = np.cumprod(np.concatenate([np.ones_like(f[:, :1]), f], -1), -1)[:, :-1]
+    w = alphas * trans
+    G = (g_rgb.astype(f8)[:, None, :] * rgbs).sum(-1) + g_depth.astype(f8)[:, None] * z.astype(f8)
+    if g_w is not None:
+        G = G + g_w.astype(f8)
+    if white_back:
+        G = G - g_rgb.astype(f8).sum(-1, keepdims=True)
+    Gw = G * w
+    suffix = np.flip(np.cumsum(np.flip(Gw, -1), -1), -1) - Gw          # sum_{i>j} G_i w_i
+    g_alpha = G * trans - suffix / f
+    g_sigma = g_alpha * deltas * e * (s_pre > 0)
+    g_raw = np.concatenate([w[..., None] * g_rgb.astype(f8)[:, None, :], g_sigma[..., None]], -1)
+    return g_raw
+
+
+def render_rays_backward(models, rays, upstream, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
+                         white_back=False, rng=None):
+    """Parameter gradients of ``render_rays`` for upstream gradients ``upstream`` = dict with any of
+    ``rgb_coarse, depth_coarse, opacity_coarse, rgb_fine, depth_fine, opacity_fine``.  Returns [grads_coarse,
+    grads_fine] (state_dict-keyed, float64).  ``sample_pdf`` is detached (rendering.py:312)."""
+    rng = rng or {}
+    rays = np.asarray(rays, F)
+    n = rays.shape[0]
+    rays_d = rays[:, 3:6]
+    dir_emb = embedding(rays_d, 4)
+    out = []
+
+    def one(params, z, noise, tag):
+        s = z.shape[1]
+        xyz = _points(rays, z).reshape(-1, 3)
+        xin = np.concatenate([embedding(xyz, 10), np.repeat(dir_emb, s, 0)], 1)
+        cache = {}
+        raw = nerf_forward(params, xin, cache=cache).reshape(n, s, 4)
+        zero3, zero1 = np.zeros((n, 3)), np.zeros((n,))
+        g_raw = composite_backward(raw, z, rays_d, noise, noise_std, white_back,
+                                   upstream.get("rgb_" + tag, zero3), upstream.get("depth_" + tag, zero1),
+                                   upstream.get("opacity_" + tag))
+        return raw, nerf_backward(params, cache, g_raw.reshape(-1, 4))
+
+    z = coarse_z_vals(rays, N_samples, use_disp, perturb, rng.get("perturb"))
+    raw_c, g_c = one(models[0], z, rng.get("noise_coarse"), "coarse")
+    out.append(g_c)
+    if N_importance > 0:
+        _, _, w_c = composite(raw_c, z, rays_d, rng.get("noise_coarse"), noise_std, white_back)
+        mid = (F(0.5) * (z[:, :-1] + z[:, 1:]).astype(F)).astype(F)
+        z_f = sample_pdf(mid, w_c[:, 1:-1], N_importance, det=(perturb == 0), u=rng.get("u"))
+        z_all = np.sort(np.concatenate([z, z_f], -1), -1)
+        _, g_f = one(models[1], z_all, rng.get("noise_fine"), "fine")
+        out.append(g_f)
+    return out
 
 
 # ------------------------------------------------------------------ synthetic inputs

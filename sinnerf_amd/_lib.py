@@ -29,9 +29,15 @@ SIGNATURES = {
     "sn_packed_weights_bytes": (_long, [_int]),
     "sn_pack_table_entries": (_long, []),
     "sn_build_pack_table": (_int, [_int, c_vp]),
-    "sn_pack_weights": (_int, [ctypes.POINTER(c_vp), c_vp, c_vp, _int, c_vp]),
+    "sn_pack_weights": (_int, [ctypes.POINTER(c_vp), c_vp, _long, c_vp, _int, c_vp]),
+    "sn_packed_weights_bytes_bwd": (_long, []),
+    "sn_pack_table_entries_bwd": (_long, []),
+    "sn_build_pack_table_bwd": (_int, [c_vp]),
     "sn_sample_coarse": (_int, [c_fp, _long, _int, _int, _float, c_fp, c_fp, c_vp]),
     "sn_mlp_forward": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
+    "sn_mlp_forward_train": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, c_fp, c_fp, c_fp, c_vp]),
+    "sn_mlp_backward_chain": (_int, [c_vp, _int, c_fp, c_fp, c_fp, _long, c_fp, c_fp, c_vp]),
+    "sn_composite_backward": (_int, [c_fp, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_fp, c_vp]),
     "sn_mlp_forward_embedded": (_int, [c_vp, _int, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
     "sn_composite_forward": (_int, [c_fp, _int, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_vp]),
     "sn_sample_pdf": (_int, [c_fp, c_fp, c_fp, _long, _int, _int, c_fp, c_fp, c_vp]),

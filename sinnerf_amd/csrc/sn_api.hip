@@ -5,7 +5,13 @@
 
 extern "C" {
 int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                              int sigma_only, int input_mode, int use_dma, float* out, hipStream_t stream);
+                              int sigma_only, int input_mode, int use_dma, float* out, float* acts, float* emb,
+                              hipStream_t stream);
+int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                     long n_points, float* G, float* g_out, hipStream_t stream);
+int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
+                                 float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
+                                 const float* g_depth, const float* g_w, float* g_raw, hipStream_t stream);
 int sn_sample_coarse_launch(const float* rays, long n_rays, int n_samples, int use_disp, float perturb,
                             const float* perturb_rand, float* z_out, hipStream_t stream);
 int sn_composite_forward_launch(const float* raw, int has_rgb, const float* z_vals, const float* rays,
@@ -28,18 +34,19 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 }
 
 __global__ void __launch_bounds__(256)
-pack_kernel(RawPtrs raw, const snl::PackEntry* __restrict__ table, long n, char* __restrict__ blob, long bias_off, int dtype) {
+pack_kernel(RawPtrs raw, const snl::PackEntry* __restrict__ table, long n, char* __restrict__ blob, int dtype) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const snl::PackEntry e = table[i];
     float v = 0.0f;
+    const bool as_f32 = (e.src == -2) || (e.src >= 0 && (e.src & snl::SRC_F32_FLAG));
     if (e.src >= 0) {
-      const int t = e.src >> 20, off = e.src & 0xfffff;
+      const int t = (e.src >> 20) & 0x3ff, off = e.src & 0xfffff;
       const float* src = raw.p[0];
 #pragma unroll
       for (int k = 1; k < snl::N_RAW; ++k) src = (t == k) ? raw.p[k] : src;
       v = src[off];
     }
-    if (dtype == snl::DT_F32 || e.dst >= bias_off) *reinterpret_cast<float*>(blob + e.dst) = v;
+    if (dtype == snl::DT_F32 || as_f32) *reinterpret_cast<float*>(blob + e.dst) = v;
     else *reinterpret_cast<unsigned short*>(blob + e.dst) = f32_to_bf16_rne(v);
   }
 }
@@ -80,18 +87,24 @@ int sn_build_pack_table(int dtype, int32_t* table_host) {
   return 0;
 }
 
-int sn_pack_weights(const float* const* raw, const int32_t* table, void* blob, int dtype, void* stream) {
+long sn_packed_weights_bytes_bwd(void) { return snl::bblob_bytes(); }
+long sn_pack_table_entries_bwd(void) { return snl::B_TOTAL_ELEMS; }
+int sn_build_pack_table_bwd(int32_t* table_host) {
+  if (!table_host) return SN_E_BADARG;
+  snl::build_pack_table_bwd(reinterpret_cast<snl::PackEntry*>(table_host));
+  return 0;
+}
+
+int sn_pack_weights(const float* const* raw, const int32_t* table, long n_entries, void* blob, int dtype, void* stream) {
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
-  if (!raw || !table || !blob) return SN_E_BADARG;
+  if (!raw || !table || !blob || n_entries <= 0) return SN_E_BADARG;
   RawPtrs rp;
   for (int i = 0; i < snl::N_RAW; ++i) {
     if (!raw[i]) return SN_E_BADARG;
     rp.p[i] = raw[i];
   }
-  const long n = snl::table_entries();
   hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, rp,
-                     reinterpret_cast<const snl::PackEntry*>(table), n, reinterpret_cast<char*>(blob),
-                     snl::bias_byte_offset(dtype), dtype);
+                     reinterpret_cast<const snl::PackEntry*>(table), n_entries, reinterpret_cast<char*>(blob), dtype);
   return (int)hipGetLastError();
 }
 
@@ -106,7 +119,30 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
   if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
-                                   (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1, out, (hipStream_t)stream);
+                                   (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1, out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
+                         float* out, float* acts, float* emb, void* stream) {
+  if (!blob || !rays || !z_vals || !out || !acts || !emb || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
+  return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, 0, 0, 1, out, acts, emb,
+                                   (hipStream_t)stream);
+}
+
+int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
+                          long n_points, float* g_acts, float* g_out, void* stream) {
+  if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;
+  if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
+  return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, g_acts, g_out, (hipStream_t)stream);
+}
+
+int sn_composite_backward(const float* raw, const float* z_vals, const float* rays, const float* noise, float noise_std,
+                          long n_rays, int n_samples, int white_back, const float* g_rgb, const float* g_depth,
+                          const float* g_weights, float* g_raw, void* stream) {
+  if (!raw || !z_vals || !rays || !g_raw || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  return sn_composite_backward_launch(raw, z_vals, rays, noise, noise_std, n_rays, n_samples, white_back, g_rgb, g_depth,
+                                      g_weights, g_raw, (hipStream_t)stream);
 }
 
 int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_rows, int ld, int sigma_only,
@@ -115,7 +151,7 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   if (ld < (sigma_only ? 63 : 90)) return SN_E_BADSHAPE;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1,
-                                   out, (hipStream_t)stream);
+                                   out, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int sn_composite_forward(const float* raw, int has_rgb, const float* z_vals, const float* rays, const float* noise,

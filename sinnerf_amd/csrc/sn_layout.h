@@ -127,9 +127,11 @@ constexpr int raw_cols(int raw_w) {
 
 // ---- host-side table: one entry per blob element.
 //  dst : byte offset into the blob
-//  src : -1 -> zero ; else (raw_tensor_id << 20) | flat element offset in that raw fp32 tensor
-//  The element is written as the weight dtype for dst < bias_byte_offset(dt), as fp32 otherwise.
+//  src : -1 -> zero (weight dtype) ; -2 -> zero (fp32) ; else
+//        [SRC_F32_FLAG] | (raw_tensor_id << 20) | flat element offset in that raw fp32 tensor
+//  Entries carrying SRC_F32_FLAG (biases) are stored as fp32 whatever the weight dtype.
 struct PackEntry { int32_t dst; int32_t src; };
+constexpr int32_t SRC_F32_FLAG = 1 << 30;
 constexpr long table_entries() { return TOTAL_W_ELEMS + BIAS_FLOATS; }
 
 inline void build_pack_table(int dt, PackEntry* out) {
@@ -169,9 +171,64 @@ inline void build_pack_table(int dt, PackEntry* out) {
         const int row = acc_row(r, h);
         PackEntry e;
         e.dst = (int32_t)(bias_byte_offset(dt) + ((long)s * 32 + h * 16 + r) * 4);
-        e.src = row < rows ? ((rb << 20) | (row0 + row)) : -1;
+        e.src = row < rows ? (SRC_F32_FLAG | (rb << 20) | (row0 + row)) : -2;
         out[n++] = e;
       }
+  }
+}
+
+// ================================================================================================
+// Backward-chain blob: TRANSPOSED weights for  g_x[in_feature, point] = W^T * g_y   (same register-resident
+// scheme as the forward: the masked accumulators of one transposed layer are the B operand of the next).
+// Slabs in execution order (one 32-row tile of INPUT features x padded K of OUTPUT features in K-slot order):
+//   0.. 3  RGBT  K= 32  rows = h2 features (inputs of rgb.0);          k-slots: rows 0..2 of the rgb tile
+//   4..11  DIRT  K=128  rows = final features (dir_encoding.0[:, :256]) k-slots: 4 tiles of g_y2
+//  12..19  FINT  K=288  rows = h8 features; k = [g_final (256) | sigma tile (32: slot 0 / half 0 = g_sigma)]
+//  20..75  LT    K=256  layers i = 7,6,5,4,3,2,1 (xyz_encoding_{i+1}^T), 8 tiles each, rows = hidden inputs of layer i
+//                       (for the skip layer i=4 the hidden part = columns 63..318 of its weight, nerf.py:133)
+// fp32 only (the training path of configs[1] is fp32); no bias area.
+constexpr int NB_SLABS = 76;
+constexpr int BSLAB_DIRT = 4, BSLAB_FINT = 12, BSLAB_LT = 20;
+constexpr int bslab_k(int s) { return s < 4 ? 32 : s < 12 ? 128 : s < 20 ? 288 : 256; }
+constexpr long bslab_elem_offset(int s) {
+  long o = 0;
+  for (int i = 0; i < s; ++i) o += 32 * bslab_k(i);
+  return o;
+}
+constexpr long B_TOTAL_ELEMS = bslab_elem_offset(NB_SLABS);
+constexpr long bblob_bytes() { return B_TOTAL_ELEMS * 4; }
+constexpr int B_MAX_SLAB_K = 288;
+
+inline void build_pack_table_bwd(PackEntry* out) {
+  long n = 0;
+  for (int s = 0; s < NB_SLABS; ++s) {
+    const int K = bslab_k(s);
+    const long base = bslab_elem_offset(s);
+    for (int g = 0; g < K / 8; ++g)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 4; ++j) {
+          const int i = lane & 31, h = lane >> 5, q = 4 * g + j;
+          int32_t src = -1;
+          if (s < BSLAB_DIRT) {                               // rgb.0^T : W_r (3 x 128)
+            const int out_f = acc_row(q, h), in_f = 32 * s + i;
+            if (out_f < 3) src = (RAW_RGB << 20) | (out_f * 128 + in_f);
+          } else if (s < BSLAB_FINT) {                        // dir_encoding.0^T : W_d (128 x 283), cols 0..255
+            const int out_f = hid_slot_feature(q, h), in_f = 32 * (s - BSLAB_DIRT) + i;
+            src = (RAW_DIR << 20) | (out_f * 283 + in_f);
+          } else if (s < BSLAB_LT) {                          // [xyz_encoding_final ; sigma]^T
+            const int in_f = 32 * (s - BSLAB_FINT) + i;
+            if (q < 128) src = (RAW_FIN << 20) | (hid_slot_feature(q, h) * 256 + in_f);
+            else if (q == 128 && h == 0) src = (RAW_SIG << 20) | in_f;
+          } else {                                            // xyz_encoding_{li+1}^T, li = 7..1
+            const int li = 7 - (s - BSLAB_LT) / 8, t = (s - BSLAB_LT) % 8;
+            const int ncol = raw_cols(2 * li), coloff = (li == 4) ? 63 : 0;
+            src = ((2 * li) << 20) | (hid_slot_feature(q, h) * ncol + coloff + 32 * t + i);
+          }
+          PackEntry e;
+          e.dst = (int32_t)((base + ((long)g * 64 + lane) * 4 + j) * 4);
+          e.src = src;
+          out[n++] = e;
+        }
   }
 }
 

@@ -1,0 +1,184 @@
+// sn_mlp_bwd.hip -- backward "chain" of the fused NeRF MLP for gfx950 (fp32): input-gradient propagation
+//   g_x[in_feature, point] = W^T * g_y ,  g_y = g_h (.) act'(.)
+// for every layer, what torch autograd derives from models/nerf.py:122-148 (+ models/activations.py).
+// Same scheme as the forward kernel (sn_mlp_fwd.hip): the gradient w.r.t. a layer's output lives in the MFMA
+// accumulator layout and is fed unchanged as the B operand of the next transposed layer; transposed weights
+// stream L2 -> LDS as pre-packed A fragments (sn_layout.h, "backward-chain blob").
+//
+// The kernel WRITES the per-layer pre-activation gradients g_y (row-major [P][256]) -- the left operands of the
+// weight-gradient contractions  dW_l = g_y_l^T X_l  over all points, which run as plain big-K GEMMs afterwards.
+// Activation derivatives come from the stored forward activations:
+//   ReLU (nerf.py:73)            : [h > 0]
+//   ShiftedSoftplus (act.py:33)  : sigmoid(y-1) = 1 - exp(-softplus(y-1)) = 1 - exp(-h2)
+//   WidenedSigmoid (act.py:18)   : .2505 * (1 - t^2),  t = tanh(.5 y) = (2*rgb - 1)/1.002
+#include "sn_mlp_common.h"
+
+namespace snk {
+
+constexpr int BWD_SLAB_LDS_BYTES = snl::B_MAX_SLAB_K * 128;      // 36864
+constexpr int MLP_BWD_LDS_BYTES = 2 * BWD_SLAB_LDS_BYTES;
+
+__device__ __forceinline__ int bslab_k_rt(int s) { return s < 4 ? 32 : s < 12 ? 128 : s < 20 ? 288 : 256; }
+
+SN_DEV f32x16 zero_acc() {
+  f32x16 a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+  return a;
+}
+
+// acts / G slots: 0..7 = h1..h8 (resp. g_y of xyz_encoding_1..8), 8 = final, 9 = h2 / g_y2 (128 wide, ld 256)
+__global__ void __launch_bounds__(256)
+mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict__ acts, const float* __restrict__ out_raw,
+                         const float* __restrict__ g_raw, long P, float* __restrict__ G, float* __restrict__ g_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const buf0 = smem;
+  char* const buf1 = smem + BWD_SLAB_LDS_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  const long p_raw = ((long)blockIdx.x * 4 + wave) * 32 + j;
+  const bool valid = p_raw < P;
+  const long p = valid ? p_raw : P - 1;
+
+  Stager<true> st;
+  const char* gnext = bblob;
+  st.issue(gnext, buf0, snl::bslab_k(0) / 32, tid);
+  gnext += snl::bslab_k(0) * 128;
+
+  float b_rgb[16], b_sig[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { b_rgb[i] = 0.0f; b_sig[i] = 0.0f; }
+  if (h == 0) {
+    const float4 g = reinterpret_cast<const float4*>(g_raw)[p];
+    const float4 o = reinterpret_cast<const float4*>(out_raw)[p];
+    const float k = 0.5f * 1.002f * 0.5f;
+    const float tx = (2.0f * o.x - 1.0f) * (1.0f / 1.002f), ty = (2.0f * o.y - 1.0f) * (1.0f / 1.002f),
+                tz = (2.0f * o.z - 1.0f) * (1.0f / 1.002f);
+    float4 gy;
+    gy.x = valid ? g.x * k * (1.0f - tx * tx) : 0.0f;
+    gy.y = valid ? g.y * k * (1.0f - ty * ty) : 0.0f;
+    gy.z = valid ? g.z * k * (1.0f - tz * tz) : 0.0f;
+    gy.w = valid ? g.w : 0.0f;
+    b_rgb[0] = gy.x; b_rgb[1] = gy.y; b_rgb[2] = gy.z;
+    b_sig[0] = gy.w;
+    if (valid) reinterpret_cast<float4*>(g_out)[p_raw] = gy;      // g_y of rgb.0 (3) and of sigma (1)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int s = 0;
+  const int last_slab = snl::NB_SLABS - 1;
+
+#define SNB_BEGIN(cur, oth)                                                  \
+  {                                                                          \
+    if (s < last_slab) {                                                     \
+      const int kn = bslab_k_rt(s + 1);                                      \
+      st.issue(gnext, (oth), kn >> 5, tid);                                  \
+      gnext += kn * 128;                                                     \
+    }                                                                        \
+  }                                                                          \
+  f32x16 acc = zero_acc();                                                   \
+  const char* lw = (cur) + lane * 16;
+#define SNB_END()                                                            \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
+  __syncthreads();                                                           \
+  ++s;
+  // forward activation tile for the derivative mask (same 4 x float4 pattern as the forward's store)
+#define SNB_LOAD_ACT(slot, t)                                                                          \
+  f32x4 av[4];                                                                                         \
+  {                                                                                                    \
+    const float* src = acts + ((long)(slot) * P + p) * 256 + 32 * (t) + 4 * h;                         \
+    _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) av[q4] = *reinterpret_cast<const f32x4*>(src + 8 * q4); \
+  }
+#define SNB_STORE_G(slot, t, arr, off)                                                                 \
+  if (valid) {                                                                                         \
+    float* dst = G + ((long)(slot) * P + p_raw) * 256 + 32 * (t) + 4 * h;                              \
+    _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                 \
+      float4 v;                                                                                        \
+      v.x = arr[(off) + 4 * q4 + 0]; v.y = arr[(off) + 4 * q4 + 1];                                    \
+      v.z = arr[(off) + 4 * q4 + 2]; v.w = arr[(off) + 4 * q4 + 3];                                    \
+      *reinterpret_cast<float4*>(dst + 8 * q4) = v;                                                    \
+    }                                                                                                  \
+  }
+
+  // ---- rgb.0^T : g_h2 = W_r^T g_y3 ; g_y2 = g_h2 * (1 - exp(-h2))
+  float g2[64];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    SNB_BEGIN((t & 1) ? buf1 : buf0, (t & 1) ? buf0 : buf1)
+    SNB_LOAD_ACT(9, t)
+    mma_f32<4>(acc, lw, b_rgb);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g2[16 * t + r] = acc[r] * (1.0f - expf(-av[r >> 2][r & 3]));
+    SNB_STORE_G(9, t, g2, 16 * t)
+    SNB_END()
+  }
+  // ---- dir_encoding.0^T (first 256 inputs): g_final = W_d[:, :256]^T g_y2   (xyz_encoding_final has no activation)
+  float gh[128], nxt[128];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    SNB_BEGIN((t & 1) ? buf1 : buf0, (t & 1) ? buf0 : buf1)
+    mma_f32<16>(acc, lw, g2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nxt[16 * t + r] = acc[r];
+    SNB_STORE_G(8, t, nxt, 16 * t)
+    SNB_END()
+  }
+#pragma unroll
+  for (int i = 0; i < 128; ++i) gh[i] = nxt[i];
+  // ---- [xyz_encoding_final ; sigma]^T : g_h8 = W_f^T g_final + W_sigma^T g_sigma ; g_y8 = g_h8 * [h8 > 0]
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    SNB_BEGIN((t & 1) ? buf1 : buf0, (t & 1) ? buf0 : buf1)
+    SNB_LOAD_ACT(7, t)
+    mma_f32<32>(acc, lw, gh);
+    mma_f32<4>(acc, lw + 32 * 1024, b_sig);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nxt[16 * t + r] = (av[r >> 2][r & 3] > 0.0f) ? acc[r] : 0.0f;
+    SNB_STORE_G(7, t, nxt, 16 * t)
+    SNB_END()
+  }
+#pragma unroll
+  for (int i = 0; i < 128; ++i) gh[i] = nxt[i];
+  // ---- xyz_encoding_{li+1}^T for li = 7..1 : g_h_li = W^T g_y ; g_y_{li-1} = g_h_li * [h_li > 0]
+#pragma unroll 1
+  for (int li = 7; li >= 1; --li) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      SNB_BEGIN((t & 1) ? buf1 : buf0, (t & 1) ? buf0 : buf1)
+      SNB_LOAD_ACT(li - 1, t)
+      mma_f32<32>(acc, lw, gh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nxt[16 * t + r] = (av[r >> 2][r & 3] > 0.0f) ? acc[r] : 0.0f;
+      SNB_STORE_G(li - 1, t, nxt, 16 * t)
+      SNB_END()
+    }
+#pragma unroll
+    for (int i = 0; i < 128; ++i) gh[i] = nxt[i];
+  }
+#undef SNB_BEGIN
+#undef SNB_END
+#undef SNB_LOAD_ACT
+#undef SNB_STORE_G
+}
+
+}  // namespace snk
+
+extern "C" int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw,
+                                                const float* g_raw, long n_points, float* G, float* g_out,
+                                                hipStream_t stream) {
+  using namespace snk;
+  if (n_points <= 0) return 0;
+  const long tiles = (n_points + 127) / 128;
+  if (tiles > 0x7fffffffL) return -2;
+  auto kfn = mlp_bwd_chain_f32_kernel;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)MLP_BWD_LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(256), MLP_BWD_LDS_BYTES, stream,
+                     reinterpret_cast<const char*>(bblob), acts, out_raw, g_raw, n_points, G, g_out);
+  return (int)hipGetLastError();
+}

@@ -11,79 +11,9 @@
 // Work decomposition: a wave owns 32 consecutive points (MFMA columns); a 256-thread workgroup = 4 waves
 // = 128 points shares each weight slab through LDS (double buffered, one barrier per slab).
 // Per point tile: 296 x 32 MFMAs of 64 cycles -> MFMA-bound by construction (fp32 roofline 157.3 TF).
-#include "sn_device.h"
-#include "sn_layout.h"
+#include "sn_mlp_common.h"
 
 namespace snk {
-
-constexpr int BIAS_LDS_BYTES = 10240;                       // 78*32*4 = 9984, padded
-constexpr int SLAB_LDS_BYTES_F32 = snl::MAX_SLAB_K * 128;   // 40960
-constexpr int MLP_F32_LDS_BYTES = BIAS_LDS_BYTES + 2 * SLAB_LDS_BYTES_F32;   // 92160
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_cvoid;
-
-// ---- slab staging: copy n_iter*4096 bytes global -> LDS, 16 B per thread per iteration -------------
-// DMA variant: global_load_lds_dwordx4 (LDS address = wave-uniform base + lane*16, no VGPR round trip).
-template <bool DMA>
-struct Stager {
-  float4 pre[10];
-  int n;
-  SN_DEV void issue(const char* __restrict__ g, char* lds, int n_iter, int tid) {
-    n = n_iter;
-    if (DMA) {
-      char* lw = lds + __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
-#pragma unroll
-      for (int i = 0; i < 10; ++i)
-        if (i < n_iter)
-          __builtin_amdgcn_global_load_lds((gbl_cvoid*)(g + i * 4096 + tid * 16), (lds_void*)(lw + i * 4096), 16, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 10; ++i)
-        if (i < n_iter) pre[i] = *reinterpret_cast<const float4*>(g + i * 4096 + tid * 16);
-    }
-  }
-  SN_DEV void commit(char* lds, int tid) {
-    if (!DMA) {
-#pragma unroll
-      for (int i = 0; i < 10; ++i)
-        if (i < n) *reinterpret_cast<float4*>(lds + i * 4096 + tid * 16) = pre[i];
-    }
-  }
-};
-
-__device__ __forceinline__ int slab_k_rt(int s) {
-  return s < 8 ? snl::K_L0 : s < 32 ? snl::K_HID : s < 40 ? snl::K_SKIP : s < 73 ? snl::K_HID : s < 77 ? snl::K_DIR : snl::K_RGB;
-}
-
-// NG groups of 4 k-steps: one ds_read_b128 (4 A operands) + 4 MFMAs per group.  The A fragments of group
-// g+1 are requested before the MFMAs of group g issue, so the LDS latency hides under 4x64 MFMA cycles.
-template <int NG>
-SN_DEV void mma_f32(f32x16& acc, const char* lds_lane, const float* b) {
-  f32x4 a_cur = *reinterpret_cast<const f32x4*>(lds_lane);
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    f32x4 a_nxt;
-    if (g + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(lds_lane + (g + 1) * 1024);
-    __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this group's MFMAs
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[4 * g + 0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[4 * g + 1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[4 * g + 2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[4 * g + 3], acc, 0, 0, 0);
-    if (g + 1 < NG) a_cur = a_nxt;
-  }
-}
-
-SN_DEV f32x16 load_bias(const float* lds_bias, int s, int h) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(lds_bias + s * 32 + h * 16);
-  f32x16 acc;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 v = p[q];
-    acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
-  }
-  return acc;
-}
 
 // Slots this lane half computes for the first layer / skip layer (sn_layout.h: xyz_slot_col).
 SN_DEV void embed_xyz(float x, float y, float z, int h, float* xe) {
@@ -115,10 +45,12 @@ SN_DEV void embed_dir(float x, float y, float z, int h, float* de) {
 
 // INPUT_MODE 0: points from (rays, z_vals):  p -> ray = p / S, xyz = o + d*z     (render_rays path)
 // INPUT_MODE 1: pre-embedded rows x[p, 0:63(+27)] with leading dimension ld       (NeRF.forward path)
-template <bool DMA, bool SIGMA_ONLY, int INPUT_MODE>
+// STORE: training forward -- additionally writes every layer's activations (acts[10][P][256]: h1..h8, final, h2) and the
+// embedded inputs (emb[P][96]: xyz columns 0..62, dir columns 64..90, reference column order) for the backward pass.
+template <bool DMA, bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1,
-                   long P, int S, float* __restrict__ out) {
+                   long P, int S, float* __restrict__ out, float* __restrict__ acts, float* __restrict__ emb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_bias = reinterpret_cast<float*>(smem);
   char* const buf0 = smem + BIAS_LDS_BYTES;
@@ -180,6 +112,34 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   int s = 0;                                     // index of the slab being consumed
   const int last_slab = SIGMA_ONLY ? snl::SLAB_SIG : snl::N_SLABS - 1;
   float hid[128], nxt[128];
+  // activation tile store (accumulator layout -> row-major [P][256]): 4 x 16 B per lane per 32-feature tile
+#define SN_STORE_TILE(slot, t, arr, off)                                                               \
+  if (STORE && valid) {                                                                                \
+    float* dst = acts + ((long)(slot) * P + p_raw) * 256 + 32 * (t) + 4 * h;                           \
+    _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                 \
+      float4 v;                                                                                        \
+      v.x = arr[(off) + 4 * q4 + 0]; v.y = arr[(off) + 4 * q4 + 1];                                    \
+      v.z = arr[(off) + 4 * q4 + 2]; v.w = arr[(off) + 4 * q4 + 3];                                    \
+      *reinterpret_cast<float4*>(dst + 8 * q4) = v;                                                    \
+    }                                                                                                  \
+  }
+  if (STORE && valid) {
+    float* er = emb + p_raw * 96;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
+      const int c = h ? c1 : c0;
+      if (c >= 0) er[c] = xe[e];
+    }
+    if (h == 1) er[63] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
+      const int c = h ? c1 : c0;
+      if (c >= 0) er[64 + c] = de[e];
+    }
+    if (h == 1) { er[91] = 0.0f; er[92] = 0.0f; er[93] = 0.0f; er[94] = 0.0f; er[95] = 0.0f; }
+  }
 
   // Common per-slab prologue / epilogue.  `cur`/`oth` are compile-time buffer choices.
 #define SN_SLAB_BEGIN(cur, oth)                                             \
@@ -205,6 +165,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     mma_f32<8>(acc, lw, xe);
 #pragma unroll
     for (int r = 0; r < 16; ++r) nxt[16 * t + r] = fmaxf(acc[r], 0.0f);
+    SN_STORE_TILE(0, t, nxt, 16 * t)
     SN_SLAB_END((t & 1) ? buf0 : buf1)
   }
 #pragma unroll
@@ -221,6 +182,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
         mma_f32<32>(acc, lw + 8 * 1024, hid);
 #pragma unroll
         for (int r = 0; r < 16; ++r) nxt[16 * t + r] = fmaxf(acc[r], 0.0f);
+        SN_STORE_TILE(l, t, nxt, 16 * t)
         SN_SLAB_END((t & 1) ? buf0 : buf1)
       }
     } else {
@@ -230,6 +192,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
         mma_f32<32>(acc, lw, hid);
 #pragma unroll
         for (int r = 0; r < 16; ++r) nxt[16 * t + r] = fmaxf(acc[r], 0.0f);
+        SN_STORE_TILE(l, t, nxt, 16 * t)
         SN_SLAB_END((t & 1) ? buf0 : buf1)
       }
     }
@@ -257,6 +220,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     mma_f32<32>(acc, lw, hid);
 #pragma unroll
     for (int r = 0; r < 16; ++r) nxt[16 * t + r] = acc[r];
+    SN_STORE_TILE(8, t, nxt, 16 * t)
     SN_SLAB_END((t & 1) ? buf1 : buf0)
   }
 #pragma unroll
@@ -271,6 +235,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     mma_f32<4>(acc, lw + 32 * 1024, de);
 #pragma unroll
     for (int r = 0; r < 16; ++r) h2[16 * t + r] = shifted_softplus(acc[r]);
+    SN_STORE_TILE(9, t, h2, 16 * t)
     SN_SLAB_END((t & 1) ? buf1 : buf0)
   }
 
@@ -289,33 +254,38 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   }
 #undef SN_SLAB_BEGIN
 #undef SN_SLAB_END
+#undef SN_STORE_TILE
 }
 
 }  // namespace snk
 
 // ---------------------------------------------------------------------------------------------------
 extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                                         int sigma_only, int input_mode, int use_dma, float* out, hipStream_t stream) {
+                                         int sigma_only, int input_mode, int use_dma, float* out, float* acts, float* emb,
+                                         hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
   if (tiles > 0x7fffffffL) return -2;
+  const bool store = acts != nullptr;
+  if (store && (sigma_only || input_mode != 0 || emb == nullptr)) return -1;
   dim3 grid((unsigned)tiles), block(256);
   const size_t lds = MLP_F32_LDS_BYTES;
   const char* b = reinterpret_cast<const char*>(blob);
-#define SN_LAUNCH(DMA, SO, IM)                                                                                   \
+#define SN_LAUNCH(DMA, SO, IM, ST)                                                                               \
   do {                                                                                                           \
-    auto kfn = mlp_fwd_f32_kernel<DMA, SO, IM>;                                                                  \
+    auto kfn = mlp_fwd_f32_kernel<DMA, SO, IM, ST>;                                                              \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                          \
-    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out);                      \
+    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb);           \
   } while (0)
-  if (input_mode == 0) {
-    if (use_dma) { if (sigma_only) SN_LAUNCH(true, true, 0); else SN_LAUNCH(true, false, 0); }
-    else         { if (sigma_only) SN_LAUNCH(false, true, 0); else SN_LAUNCH(false, false, 0); }
+  if (store) {
+    SN_LAUNCH(true, false, 0, true);
+  } else if (input_mode == 0) {
+    if (use_dma) { if (sigma_only) SN_LAUNCH(true, true, 0, false); else SN_LAUNCH(true, false, 0, false); }
+    else         { if (sigma_only) SN_LAUNCH(false, true, 0, false); else SN_LAUNCH(false, false, 0, false); }
   } else {
-    if (use_dma) { if (sigma_only) SN_LAUNCH(true, true, 1); else SN_LAUNCH(true, false, 1); }
-    else         { if (sigma_only) SN_LAUNCH(false, true, 1); else SN_LAUNCH(false, false, 1); }
+    if (sigma_only) SN_LAUNCH(true, true, 1, false); else SN_LAUNCH(true, false, 1, false);
   }
 #undef SN_LAUNCH
   return (int)hipGetLastError();

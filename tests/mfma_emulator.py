@@ -43,7 +43,7 @@ def pack_blob(lib, params, dtype_code=0):
     dst, src = table[:, 0] // 4, table[:, 1]
     vals = np.zeros(n, np.float32)
     ok = src >= 0
-    tid, off = src[ok] >> 20, src[ok] & 0xFFFFF
+    tid, off = (src[ok] >> 20) & 0x3FF, src[ok] & 0xFFFFF
     flat = np.concatenate(raws)
     starts = np.cumsum([0] + [r.size for r in raws])[:-1]
     vals[ok] = flat[starts[tid] + off]
@@ -107,3 +107,91 @@ def emulate_tile(lib, blob, x_embedded, sigma_only=False):
     assert s == n_slabs
     rgb = widened_sigmoid(acc[:32, :3])
     return np.concatenate([rgb, sigma[:32, None]], 1)
+
+
+def pack_blob_bwd(lib, params):
+    order = ([f"xyz_encoding_{i+1}.0" for i in range(8)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"])
+    raws = []
+    for k in order:
+        raws += [params[k + ".weight"].reshape(-1), params[k + ".bias"].reshape(-1)]
+    n = lib.sn_pack_table_entries_bwd()
+    table = np.empty((n, 2), np.int32)
+    assert lib.sn_build_pack_table_bwd(ctypes.c_void_p(table.ctypes.data)) == 0
+    blob = np.zeros(lib.sn_packed_weights_bytes_bwd() // 4, np.float32)
+    dst, src = table[:, 0] // 4, table[:, 1]
+    ok = src >= 0
+    flat = np.concatenate(raws)
+    starts = np.cumsum([0] + [r.size for r in raws])[:-1]
+    vals = np.zeros(n, np.float32)
+    vals[ok] = flat[starts[(src[ok] >> 20) & 0x3FF] + (src[ok] & 0xFFFFF)]
+    assert len(np.unique(dst)) == n
+    blob[dst] = vals
+    return blob
+
+
+def emulate_bwd_tile(blob, acts, out_raw, g_raw):
+    """csrc/sn_mlp_bwd.hip for one 32-point tile.  acts: dict slot -> (32,256) forward activations (h1..h8, final, h2);
+    out_raw, g_raw: (32,4).  Returns G: dict slot -> (32,256) and g_out (32,4)."""
+    ks = [32] * 4 + [128] * 8 + [288] * 8 + [256] * 56
+    off = np.cumsum([0] + [32 * k for k in ks])
+
+    def tile_from_acc(acc, width_tile=None):
+        # accumulator layout -> (32 points, 32 features)
+        out = np.zeros((32, 32), np.float32)
+        for r in range(16):
+            out[J, acc_row(r, H)] = acc[:, r]
+        return out
+
+    def act_tile(slot, t):                 # (64 lanes,16 regs) values of acts[slot][:, 32t + row(r,h)]
+        a = acts[slot]
+        v = np.zeros((64, 16), np.float32)
+        for r in range(16):
+            v[:, r] = a[J, 32 * t + acc_row(r, H)]
+        return v
+
+    def run_slab(s, segments):
+        acc = np.zeros((64, 16), np.float32)
+        frags = blob[off[s]:off[s + 1]].reshape(-1, 64, 4)
+        g = 0
+        for b in segments:
+            for q in range(0, b.shape[1], 4):
+                for jj in range(4):
+                    mfma_f32_32x32x2(frags[g, :, jj], b[:, q + jj], acc)
+                g += 1
+        assert g == frags.shape[0]
+        return acc
+
+    k = np.float32(0.5 * 1.002 * 0.5)
+    t3 = (2 * out_raw[:, :3] - 1) / np.float32(1.002)
+    gy3 = g_raw[:, :3] * k * (1 - t3 * t3)
+    b_rgb = np.zeros((64, 16), np.float32); b_sig = np.zeros((64, 16), np.float32)
+    b_rgb[:32, :3] = gy3
+    b_sig[:32, 0] = g_raw[:, 3]
+    g_out = np.concatenate([gy3, g_raw[:, 3:4]], 1)
+    G = {}
+    s = 0
+    g2 = np.zeros((64, 64), np.float32); G[9] = np.zeros((32, 256), np.float32)
+    for t in range(4):
+        acc = run_slab(s, [b_rgb]); s += 1
+        g2[:, 16 * t:16 * t + 16] = acc * (1 - np.exp(-act_tile(9, t)))
+        G[9][:, 32 * t:32 * t + 32] = tile_from_acc(g2[:, 16 * t:16 * t + 16])
+    gh = np.zeros((64, 128), np.float32); G[8] = np.zeros((32, 256), np.float32)
+    for t in range(8):
+        acc = run_slab(s, [g2]); s += 1
+        gh[:, 16 * t:16 * t + 16] = acc
+        G[8][:, 32 * t:32 * t + 32] = tile_from_acc(acc)
+    nxt = np.zeros_like(gh); G[7] = np.zeros((32, 256), np.float32)
+    for t in range(8):
+        acc = run_slab(s, [gh, b_sig]); s += 1
+        nxt[:, 16 * t:16 * t + 16] = np.where(act_tile(7, t) > 0, acc, 0)
+        G[7][:, 32 * t:32 * t + 32] = tile_from_acc(nxt[:, 16 * t:16 * t + 16])
+    gh = nxt.copy()
+    for li in range(7, 0, -1):
+        G[li - 1] = np.zeros((32, 256), np.float32)
+        for t in range(8):
+            acc = run_slab(s, [gh]); s += 1
+            nxt[:, 16 * t:16 * t + 16] = np.where(act_tile(li - 1, t) > 0, acc, 0)
+            G[li - 1][:, 32 * t:32 * t + 32] = tile_from_acc(nxt[:, 16 * t:16 * t + 16])
+        gh = nxt.copy()
+    assert s == 76
+    return G, g_out

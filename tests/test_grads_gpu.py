@@ -1,0 +1,99 @@
+"""GPU: the training path (backward kernels + autograd glue) against the oracle's restated backward and against
+golden parameter gradients from the reference's autograd."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_np as O                                                    # noqa: E402
+from tests.test_oracle_grads import GRAD_CASES, check_grads, load_grad_case         # noqa: E402
+from tests.test_parity_gpu import dev, embeddings, injected_rng, make_model, rng_order   # noqa: E402
+
+ORDER = ([f"xyz_encoding_{i+1}.0" for i in range(8)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"])
+
+
+def model_grads(m):
+    return {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("S,white_back,noise_std,with_gw", [(64, True, 1.0, False), (128, False, 0.0, True),
+                                                            (192, True, 0.5, True), (24, False, 1.0, False)])
+def test_composite_backward_vs_oracle(S, white_back, noise_std, with_gw):
+    from sinnerf_amd.autograd import _CompositeFn
+    r = np.random.RandomState(S)
+    rays = O.lego_rays(30, 30, seed=2)[::9]
+    n = rays.shape[0]
+    z = np.sort(r.uniform(2, 6, (n, S)).astype(np.float32), -1)
+    raw = r.uniform(0, 1, (n, S, 4)).astype(np.float32)
+    raw[..., 3] = (r.standard_normal((n, S)) * 2).astype(np.float32)
+    noise = r.standard_normal((n, S)).astype(np.float32)
+    g_rgb, g_depth = r.standard_normal((n, 3)).astype(np.float32), r.standard_normal(n).astype(np.float32)
+    g_w = r.standard_normal((n, S)).astype(np.float32) if with_gw else None
+    ref = O.composite_backward(raw, z, rays[:, 3:6], noise if noise_std else None, noise_std, white_back, g_rgb, g_depth, g_w)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    raw_t = t(raw).requires_grad_(True)
+    rgb, depth, w = _CompositeFn.apply(raw_t, t(z), t(rays), t(noise) if noise_std else None, noise_std, white_back)
+    loss = (rgb * t(g_rgb)).sum() + (depth * t(g_depth)).sum()
+    if with_gw:
+        loss = loss + (w * t(g_w)).sum()
+    loss.backward()
+    got = raw_t.grad.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-5 * scale, (np.abs(got - ref).max(), scale)
+
+
+def test_mlp_backward_vs_oracle():
+    from sinnerf_amd.autograd import _MLPFn
+    from sinnerf_amd import rendering
+    model, p = make_model(3, True)
+    model.train()
+    rays = O.lego_rays(400, 400, seed=0)[::2503][:60]
+    n, S = rays.shape[0], 37                        # 2220 points: ragged last workgroup
+    z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n, S)).astype(np.float32))
+    g = np.random.RandomState(2).standard_normal((n, S, 4)).astype(np.float32)
+    rays_t, z_t = torch.from_numpy(rays).to(dev()), torch.from_numpy(z).to(dev())
+    out = _MLPFn.apply(model, rays_t, z_t, *model.raw_tensors())
+    with torch.no_grad():
+        out_inf = rendering._mlp(model, rays_t, z_t, False)
+    assert torch.equal(out.detach(), out_inf)                 # training forward == inference forward, bit for bit
+    (out * torch.from_numpy(g).to(dev())).sum().backward()
+    got = model_grads(model)
+    xin = np.concatenate([O.embedding(O._points(rays, z).reshape(-1, 3), 10),
+                          np.repeat(O.embedding(rays[:, 3:6], 4), S, 0)], 1)
+    cache = {}
+    O.nerf_forward(p, xin, cache=cache)
+    ref = O.nerf_backward(p, cache, g.reshape(-1, 4))
+    for k, v in ref.items():
+        e = np.linalg.norm(got[k] - v) / max(np.linalg.norm(v), 1e-12)
+        assert e <= 2e-5, (k, e)
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_render_rays_gradients_golden(name):
+    import sinnerf_amd
+    z, meta, rng, coef = load_grad_case(name)
+    rays = z["rays"]
+    mc, _ = make_model(meta["seed_coarse"], True)
+    mf, _ = make_model(meta["seed_fine"], True)
+    mc.train(); mf.train()
+    with injected_rng(rng_order(dict(meta, use_disp=0), rng, rays.shape[0])) as left:
+        res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays).to(dev()), meta["N_samples"], False,
+                                      meta["perturb"], meta["noise_std"], meta["N_importance"], 32768, bool(meta["white_back"]))
+        assert not left
+    loss = sum((res[k] * torch.from_numpy(v).to(dev())).sum() for k, v in coef.items())
+    assert abs(loss.item() - float(z["loss"])) <= 2e-4 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    check_grads(z, [model_grads(mc), model_grads(mf)], rel_coarse=2e-5, rel_fine=1e-2)
+
+
+def test_detach_coarse_and_frozen_params():
+    import sinnerf_amd
+    mc, _ = make_model(0, True)
+    mf, _ = make_model(1, True)
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::5000]).to(dev())
+    res = sinnerf_amd.render_rays([mc, mf], embeddings(), rays, 64, False, 1.0, 1.0, 64, 32768, True, detach_coarse=True)
+    assert not res["rgb_coarse"].requires_grad and res["rgb_fine"].requires_grad
+    (res["rgb_fine"].sum() + res["depth_fine"].sum()).backward()
+    assert all(p.grad is None for p in mc.parameters())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mf.parameters())

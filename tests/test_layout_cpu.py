@@ -7,7 +7,7 @@ import re
 import numpy as np
 
 from oracle import oracle_np as O
-from tests.mfma_emulator import emulate_tile, pack_blob
+from tests.mfma_emulator import emulate_bwd_tile, emulate_tile, pack_blob, pack_blob_bwd
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -55,3 +55,29 @@ def test_emulated_kernel_matches_oracle():
     assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
     got_s = emulate_tile(L.lib, blob, xin, sigma_only=True)
     assert np.abs(got_s - ref[:, 3]).max() <= 5e-5 * max(1.0, np.abs(ref[:, 3]).max())
+
+
+def test_emulated_backward_chain_matches_oracle():
+    L = _lib()
+    p = O.init_params(4, True)
+    bblob = pack_blob_bwd(L.lib, p)
+    r = np.random.RandomState(1)
+    x = O.embedding(r.uniform(-3, 3, (32, 3)).astype(np.float32), 10)
+    d = O.embedding(r.uniform(-1, 1, (32, 3)).astype(np.float32), 4)
+    xin = np.concatenate([x, d], 1)
+    cache = {}
+    out = O.nerf_forward(p, xin, cache=cache)
+    g_raw = r.standard_normal((32, 4)).astype(np.float32)
+    gy = {}
+    O.nerf_backward(p, cache, g_raw, gy_out=gy)
+    acts = {i: cache[f"h{i+1}"] for i in range(8)}
+    acts[8] = cache["final"]
+    acts[9] = np.concatenate([cache["d"], np.zeros((32, 128), np.float32)], 1)
+    G, g_out = emulate_bwd_tile(bblob, acts, out, g_raw)
+    ref = {i: gy[f"l{i+1}"] for i in range(8)}
+    ref[8] = gy["final"]
+    ref[9] = np.concatenate([gy["dir"], np.zeros((32, 128))], 1)
+    assert np.abs(g_out - np.concatenate([gy["rgb"], gy["sigma"]], 1)).max() <= 1e-6
+    for slot in range(10):
+        scale = max(np.abs(ref[slot]).max(), 1e-9)
+        assert np.abs(G[slot] - ref[slot]).max() <= 2e-5 * scale, (slot, np.abs(G[slot] - ref[slot]).max(), scale)
