@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""One-shot GPU diagnostics (run under gpurun): stage-by-stage error statistics of the HIP path against the
-oracle, written to gpurun_out/diag.json -- more informative than a failing assert when no GPU is at hand."""
+"""GPU diagnostics for the backward path: per-slot comparison of stored activations / chain gradients with the
+oracle on a ragged point count.  Writes gpurun_out/diag.json."""
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -12,60 +11,49 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle_np as O                      # noqa: E402
 import sinnerf_amd                                     # noqa: E402
-from sinnerf_amd import _lib, rendering               # noqa: E402
+from sinnerf_amd import _lib                           # noqa: E402
 
 dev = torch.device("cuda:0")
-out = {"device": torch.cuda.get_device_name(0)}
-t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-
-
-def stats(got, ref):
-    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    d = np.abs(got - ref)
-    return {"max_abs": float(d.max()), "max_rel": float((d / (np.abs(ref) + 1e-3)).max()), "mean_abs": float(d.mean()),
-            "nan": int(np.isnan(got).sum()), "ref_absmax": float(np.abs(ref).max())}
-
-
-p = O.init_params(0, True)
+out = {}
+p = O.init_params(3, True)
 m = sinnerf_amd.NeRF(use_new_activation=True)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
-m = m.to(dev).eval()
-rays = O.lego_rays(400, 400, 0)[::1601][:100]
-z = O.coarse_z_vals(rays, 64, False, 0, None)
-for flags in (0, 1):
-    for so in (False, True):
-        ref = O._run_model(p, rays, z, O.embedding(rays[:, 3:6], 4), so, 1 << 20)
-        try:
-            with torch.no_grad():
-                got = rendering._mlp(m, t(rays), t(z), so, flags).cpu().numpy()
-            torch.cuda.synchronize()
-            out[f"mlp_flags{flags}_sigma{int(so)}"] = stats(got, ref)
-            if not so:
-                out[f"mlp_flags{flags}_percol"] = [stats(got[..., c], ref[..., c]) for c in range(4)]
-        except Exception as e:                          # noqa: BLE001
-            out[f"mlp_flags{flags}_sigma{int(so)}"] = {"error": repr(e)}
-
-# embedded-input path: per-layer insight is not available, but the first rows help when the layout is wrong
-xin = np.concatenate([O.embedding(O._points(rays, z).reshape(-1, 3), 10), np.repeat(O.embedding(rays[:, 3:6], 4), 64, 0)], 1)
-with torch.no_grad():
-    got = m(t(xin)).cpu().numpy()
-ref = O.nerf_forward(p, xin)
-out["mlp_embedded"] = stats(got, ref)
-out["mlp_embedded_first_rows"] = {"got": got[:3].tolist(), "ref": ref[:3].tolist()}
-
-# timing of the MLP kernel alone at frame size
-rays_f = t(O.lego_rays(400, 400, 0))
-zf = torch.empty((160000, 128), device=dev)
-_lib.check(_lib.lib.sn_sample_coarse(_lib.ptr(rays_f), 160000, 128, 0, 0.0, None, _lib.ptr(zf), None), "coarse")
-for flags in (0, 1):
-    with torch.no_grad():
-        rendering._mlp(m, rays_f, zf, False, flags)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        rendering._mlp(m, rays_f, zf, False, flags)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    out[f"mlp_frame_fine_flags{flags}"] = {"ms": dt * 1e3, "tflops": 1186816 * 160000 * 128 / dt / 1e12}
+m = m.to(dev)
+for (n, S) in ((60, 37), (64, 64)):
+    rays = O.lego_rays(400, 400, seed=0)[::2503][:n]
+    z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n, S)).astype(np.float32))
+    g = np.random.RandomState(2).standard_normal((n, S, 4)).astype(np.float32)
+    P = n * S
+    rays_t, z_t, g_t = (torch.from_numpy(a).to(dev) for a in (rays, z, g))
+    raw = torch.empty((n, S, 4), device=dev); acts = torch.full((10, P, 256), float("nan"), device=dev)
+    emb = torch.full((P, 96), float("nan"), device=dev)
+    _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m.packed()), 0, _lib.ptr(rays_t), _lib.ptr(z_t), n, S, _lib.ptr(raw),
+                                             _lib.ptr(acts), _lib.ptr(emb), None), "fwd")
+    G = torch.full((10, P, 256), float("nan"), device=dev); g_o = torch.full((P, 4), float("nan"), device=dev)
+    _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m.packed_bwd()), 0, _lib.ptr(acts), _lib.ptr(raw), _lib.ptr(g_t), P,
+                                              _lib.ptr(G), _lib.ptr(g_o), None), "bwd")
+    torch.cuda.synchronize()
+    xin = np.concatenate([O.embedding(O._points(rays, z).reshape(-1, 3), 10), np.repeat(O.embedding(rays[:, 3:6], 4), S, 0)], 1)
+    cache, gy = {}, {}
+    O.nerf_forward(p, xin, cache=cache)
+    O.nerf_backward(p, cache, g.reshape(-1, 4), gy_out=gy)
+    ref_act = {i: cache[f"h{i+1}"] for i in range(8)}; ref_act[8] = cache["final"]; ref_act[9] = cache["d"]
+    ref_g = {i: gy[f"l{i+1}"] for i in range(8)}; ref_g[8] = gy["final"]; ref_g[9] = gy["dir"]
+    res = {}
+    A, Gn = acts.cpu().numpy(), G.cpu().numpy()
+    for slot in range(10):
+        w = ref_act[slot].shape[1]
+        da = np.abs(A[slot][:, :w] - ref_act[slot]); dg = np.abs(Gn[slot][:, :w] - ref_g[slot])
+        res[f"slot{slot}"] = {"act_max_err": float(np.nanmax(da)), "act_nan": int(np.isnan(A[slot][:, :w]).sum()),
+                              "act_worst_row": int(np.nanargmax(da.max(1))), "g_max_err": float(np.nanmax(dg)),
+                              "g_nan": int(np.isnan(Gn[slot][:, :w]).sum()), "g_worst_row": int(np.nanargmax(dg.max(1))),
+                              "g_scale": float(np.abs(ref_g[slot]).max()),
+                              "g_bad_rows": np.nonzero(dg.max(1) > 1e-4 * np.abs(ref_g[slot]).max())[0][:20].tolist()}
+    e = emb.cpu().numpy()
+    res["emb_xyz_err"] = float(np.nanmax(np.abs(e[:, :63] - xin[:, :63]))); res["emb_dir_err"] = float(np.nanmax(np.abs(e[:, 64:91] - xin[:, 63:])))
+    res["emb_nan"] = int(np.isnan(e).sum())
+    res["g_o_err"] = float(np.abs(g_o.cpu().numpy() - np.concatenate([gy["rgb"], gy["sigma"]], 1)).max())
+    out[f"n{n}_S{S}"] = res
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/diag.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

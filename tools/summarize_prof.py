@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof/* (rocprofv3 CSV outputs of tools/gpu_round.sh) into profiles/<tag>_*.
+usage: python tools/summarize_prof.py r01_run2"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = "gpurun_out/prof"
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(f"{src}/stats_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] --output-format csv -- python bench.py --steps N --warmup W --no-cpu-baseline",
+       "note": "PMC passes are separate runs (pmc1: SQ/GRBM, pmc2: FETCH_SIZE, pmc3: WRITE_SIZE); values per dispatch of the fused MLP kernel"}
+per = collections.defaultdict(dict)
+for f in ("pmc1", "pmc2", "pmc3"):
+    p = f"{src}/{f}_counter_collection.csv"
+    if not os.path.exists(p):
+        continue
+    for r in csv.DictReader(open(p)):
+        if "mlp_fwd" not in r["Kernel_Name"]:
+            continue
+        key = (f, int(r["Dispatch_Id"]))
+        per[key]["grid"] = int(r["Grid_Size"])
+        per[key]["dur_ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        per[key]["vgpr"] = int(r["VGPR_Count"]); per[key]["agpr"] = int(r["Accum_VGPR_Count"]); per[key]["lds"] = int(r["LDS_Block_Size"])
+        per[key][r["Counter_Name"]] = float(r["Counter_Value"])
+disp = []
+for (f, d), v in sorted(per.items()):
+    v = dict(v, pass_=f, dispatch=d, points=v["grid"] // 256 * 128)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles are summed over 1024 SIMDs
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        v["clock_ghz"] = cyc / (v["dur_ms"] * 1e6)
+        v["mfma_busy_frac"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc
+        v["wave_parked_frac(SQ_WAIT_ANY/SQ_WAVE_CYCLES)"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
+    disp.append(v)
+out["dispatches"] = disp
+# HBM traffic of the dominant launch (largest grid): FETCH_SIZE / WRITE_SIZE are in KiB.  The gfx950 2x correction of
+# MI355X_MICROARCH.md applies to wide (16 B/lane) coalesced reads; this kernel's reads are 4 B/lane z_vals + L2-resident
+# weights, so the raw FETCH_SIZE is reported and the corrected value given alongside.
+big = max((v["grid"] for v in disp), default=0)
+f = [v for v in disp if v["grid"] == big and "FETCH_SIZE" in v]
+w = [v for v in disp if v["grid"] == big and "WRITE_SIZE" in v]
+if f and w:
+    fetch, write = f[0]["FETCH_SIZE"] * 1024, w[0]["WRITE_SIZE"] * 1024
+    out["traffic"] = {"kernel": "mlp_fwd_f32_kernel fine pass", "points": f[0]["points"], "fetch_bytes": fetch,
+                      "fetch_bytes_2x_corrected": 2 * fetch, "write_bytes": write, "hbm_bytes": 2 * fetch + write,
+                      "algorithmic_bytes": f[0]["points"] * 20}
+json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+if "traffic" in out:
+    json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json"), open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:3500])
