@@ -16,28 +16,72 @@ from . import _lib
 from .nerf import dtype_code
 
 
+_VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64)}
+_KB = 16                      # csrc/sn_dw.hip: points per staged chunk
+_TARGET_WGS = 248             # one workgroup per CU per launch, a little slack for the small problems
+
+
 def _weight_grads(model, acts, emb, G, g_o, needs):
-    """Contractions over all sample points.  Plain GEMMs (hipBLASLt through torch.mm): dW = g^T X, db = sum g.
+    """dW_l = g_l^T X_l, db_l = sum_p g_l over all sample points (autograd of the nn.Linear layers, nerf.py:66-103).
+    The ten wide contractions run in ONE launch of the K-split MFMA kernel (sn_dw_gemm, csrc/sn_dw.hip) followed by a
+    deterministic sum of the K-split partials; sigma (1 row) and rgb (3 rows) are tiny and go through torch.mm.
     Order of the returned list = NeRF.raw_tensors()."""
+    import numpy as np
+    P = acts.shape[1]
+    dev = acts.device
+    fsz = 4
+    # (key, A tensor, A col, lda, B tensor, B col, ldb, variant, want_bias)
+    probs = []
+    for i in range(8):                                       # xyz_encoding_{i+1}
+        if i == 0:
+            probs.append((("w", 0), G[0], 0, 256, emb, 0, 128, 1, True))
+        else:
+            probs.append((("w", i), G[i], 0, 256, acts[i - 1], 0, 256, 0, True))
+            if i == 4:                                       # skip: cat([input_xyz, h4])  nerf.py:133
+                probs.append((("w4e", 4), G[4], 0, 256, emb, 0, 128, 1, False))
+    probs.append((("w", 8), G[8], 0, 256, acts[7], 0, 256, 0, True))          # xyz_encoding_final
+    probs.append((("w", 9), G[9], 0, 256, acts[8], 0, 256, 2, True))          # dir_encoding[:, :256]
+    probs.append((("w9e", 9), G[9], 0, 256, emb, 64, 128, 3, False))          # dir_encoding[:, 256:]
+    work = [_VARIANT_MN[p[7]][0] * _VARIANT_MN[p[7]][1] for p in probs]
+    tot = float(sum(work))
+    max_split = max(1, P // (4 * _KB))
+    rows, outs = [], []
+    for pr, w in zip(probs, work):
+        key, A, ac, lda, B, bc, ldb, var, want_b = pr
+        M, N = _VARIANT_MN[var]
+        ns = int(min(max_split, max(1, round(_TARGET_WGS * w / tot))))
+        per = -(-P // ns)
+        per = -(-per // _KB) * _KB
+        ns = -(-P // per)
+        cpart = torch.empty((ns, M, N), dtype=torch.float32, device=dev)
+        bpart = torch.empty((ns, M), dtype=torch.float32, device=dev) if want_b else None
+        outs.append((key, cpart, bpart))
+        a_ptr, b_ptr = A.data_ptr() + ac * fsz, B.data_ptr() + bc * fsz
+        for j in range(ns):
+            rows.append((a_ptr, b_ptr, cpart.data_ptr() + j * M * N * fsz,
+                         (bpart.data_ptr() + j * M * fsz) if want_b else 0,
+                         j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | (var << 32)))
+    tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+    _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], _lib.stream_ptr()), "sn_dw_gemm")
+    res = {k: (c.sum(0), b.sum(0) if b is not None else None) for k, c, b in outs}
+
     grads = []
 
     def add(gw, gb, k):
         grads.append(gw if needs[2 * k] else None)
         grads.append(gb if needs[2 * k + 1] else None)
 
-    for i in range(8):                                       # xyz_encoding_{i+1}  (nerf.py:66-75)
-        gy = G[i]
+    for i in range(8):
+        gw, gb = res[("w", i)]
         if i == 0:
-            gw = gy.t() @ emb[:, :63]
-        elif i == 4:                                         # skip: cat([input_xyz, h4])  nerf.py:133
-            gw = torch.cat([gy.t() @ emb[:, :63], gy.t() @ acts[3]], 1)
-        else:
-            gw = gy.t() @ acts[i - 1]
-        add(gw, gy.sum(0), i)
+            gw = gw[:, :63]
+        elif i == 4:
+            gw = torch.cat([res[("w4e", 4)][0][:, :63], gw], 1)
+        add(gw.contiguous(), gb, i)
+    add(*res[("w", 8)], 8)
+    gw, gb = res[("w", 9)]
+    add(torch.cat([gw, res[("w9e", 9)][0][:, :27]], 1), gb, 9)
     h8 = acts[7]
-    add(G[8].t() @ h8, G[8].sum(0), 8)                       # xyz_encoding_final  (nerf.py:76)
-    gd = G[9][:, :128]
-    add(torch.cat([gd.t() @ acts[8], gd.t() @ emb[:, 64:91]], 1), gd.sum(0), 9)       # dir_encoding (nerf.py:142-143)
     gs = g_o[:, 3:4]
     add(gs.t() @ h8, gs.sum(0), 10)                          # sigma (nerf.py:136)
     gr = g_o[:, :3]
@@ -54,7 +98,7 @@ class _MLPFn(torch.autograd.Function):
         code = dtype_code(model.compute_dtype)
         out = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
         acts = torch.empty((10, P, 256), dtype=torch.float32, device=dev)
-        emb = torch.empty((P, 96), dtype=torch.float32, device=dev)
+        emb = torch.zeros((P, 128), dtype=torch.float32, device=dev)
         _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                                  _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), _lib.stream_ptr()),
                    "sn_mlp_forward_train")

@@ -9,6 +9,7 @@ int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* i
                               hipStream_t stream);
 int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                      long n_points, float* G, float* g_out, hipStream_t stream);
+int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
                                  const float* g_depth, const float* g_w, float* g_raw, hipStream_t stream);
@@ -135,6 +136,11 @@ int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, co
   if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, g_acts, g_out, (hipStream_t)stream);
+}
+
+int sn_dw_gemm(const void* tasks, int n_tasks, void* stream) {
+  if (!tasks || n_tasks < 0) return SN_E_BADARG;
+  return sn_dw_launch(tasks, n_tasks, (hipStream_t)stream);
 }
 
 int sn_composite_backward(const float* raw, const float* z_vals, const float* rays, const float* noise, float noise_std,

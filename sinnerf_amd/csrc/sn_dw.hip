@@ -1,0 +1,157 @@
+// sn_dw.hip -- weight-gradient contractions of the NeRF MLP backward for gfx950 (fp32):
+//     dW[m, n] = sum_p  G[p, m] * X[p, n]          (+ optionally  db[m] = sum_p G[p, m])
+// i.e. the "gW = g_y^T x" terms torch autograd accumulates for every nn.Linear of models/nerf.py:66-103, with the
+// contraction running over ALL sample points p (K = 0.25..1 M) and a small M x N <= 256 x 256 result.
+//
+// G (pre-activation gradients, written by sn_mlp_bwd.hip) and X (activations / embedded inputs, written by the
+// training forward) are row-major [P][ld]: a row = one point.  With v_mfma_f32_32x32x2_f32 the A operand is
+// A[i][k] = G[p=k][m0+i] and the B operand B[k][j] = X[p=k][n0+j]: both read 32 CONSECUTIVE floats of a row per lane
+// half, so the tiles are staged row-major (global_load_lds DMA, lane-linear) and fragment reads are conflict-free
+// ds_read_b32 -- no transposes anywhere.
+//
+// One workgroup = one task = (problem, K-range): 2x2 waves, each wave owns an (MT*32) x (NT*32) block of accumulators
+// (MT=NT=4: 256 accumulator registers) and walks its K-range in chunks of 16 points (double-buffered LDS, one barrier
+// per chunk, 16 MFMAs per k-step at MT=NT=4).  Partial results go to a per-task slab; the K-split partials are summed
+// afterwards (deterministic, no atomics).
+#include "sn_device.h"
+
+namespace snd {
+
+constexpr int KB = 16;                          // points per staged chunk
+constexpr int DW_LDS_BYTES = 2 * KB * (256 + 256) * 4;   // 65536
+
+struct Task {                                   // 64 bytes, built on the host (sinnerf_amd/autograd.py)
+  const float* a;                               // G  + column offset
+  const float* b;                               // X  + column offset
+  float* c;                                     // partial dW  [M_wg][ldc]
+  float* bias;                                  // partial db  [M_wg] or nullptr
+  long k0, k1;                                  // point range
+  int lda, ldb;
+  int ldc, variant;                             // variant: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+// copy ROWS x W floats (row-major, W*4 bytes per row) global -> LDS, clamping rows to < k_end
+template <int W>
+SN_DEV void stage_rows(const float* __restrict__ g, int ld, long k, long k_end, char* lds, int tid) {
+  constexpr int CHUNKS = KB * W / 4;            // 16-byte chunks
+  constexpr int PER_ROW = W / 4;
+  const int wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+#pragma unroll
+  for (int it = 0; it < (CHUNKS + 255) / 256; ++it) {
+    const int c = it * 256 + tid;
+    if (CHUNKS % 256 == 0 || c < CHUNKS) {
+      long row = k + c / PER_ROW;
+      row = row < k_end ? row : k_end - 1;
+      const float* src = g + row * ld + (c % PER_ROW) * 4;
+      __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(lds + it * 4096 + wbase), 16, 0, 0);
+    }
+  }
+}
+
+template <int MT, int NT>
+SN_DEV void run_task(const Task& t, char* smem, int tid) {
+  constexpr int WA = 2 * MT * 32, WB = 2 * NT * 32;
+  constexpr int A_BYTES = KB * WA * 4, B_BYTES = KB * WB * 4, BUF = A_BYTES + B_BYTES;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = wr * MT * 32, n0 = wc * NT * 32;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  float bsum[MT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) bsum[a] = 0.0f;
+
+  const long k0 = t.k0, k1 = t.k1;
+  if (k0 >= k1) return;
+  stage_rows<WA>(t.a, t.lda, k0, k1, smem, tid);
+  stage_rows<WB>(t.b, t.ldb, k0, k1, smem + A_BYTES, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (long k = k0; k < k1; k += KB) {
+    char* bc = smem + cur * BUF;
+    char* bn = smem + (cur ^ 1) * BUF;
+    if (k + KB < k1) {
+      stage_rows<WA>(t.a, t.lda, k + KB, k1, bn, tid);
+      stage_rows<WB>(t.b, t.ldb, k + KB, k1, bn + A_BYTES, tid);
+    }
+    const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;
+    const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
+    const bool full = (k + KB <= k1);
+#pragma unroll
+    for (int s = 0; s < KB / 2; ++s) {
+      float av[MT], bv[NT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) av[a] = la[(2 * s) * WA + 32 * a];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) bv[b] = lb[(2 * s) * WB + 32 * b];
+      if (!full) {                               // ragged tail: rows >= k1 are clamped copies, zero their A side
+        const bool ok = (k + 2 * s + h) < k1;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) av[a] = ok ? av[a] : 0.0f;
+      }
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        bsum[a] += av[a];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  // epilogue: accumulator (row = (r&3)+8(r>>2)+4h, col = i) -> c[m][n], 128 B per lane-half per store
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        t.c[(long)m * t.ldc + n0 + 32 * b + i] = acc[a][b][r];
+      }
+  if (t.bias != nullptr && wc == 0) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+      if (h == 0) t.bias[m0 + 32 * a + i] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Task t = tasks[blockIdx.x];
+  const int tid = threadIdx.x;
+  switch (t.variant) {
+    case 0: run_task<4, 4>(t, smem, tid); break;
+    case 1: run_task<4, 1>(t, smem, tid); break;
+    case 2: run_task<2, 4>(t, smem, tid); break;
+    default: run_task<2, 1>(t, smem, tid); break;
+  }
+}
+
+}  // namespace snd
+
+extern "C" int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream) {
+  using namespace snd;
+  if (n_tasks <= 0) return 0;
+  static_assert(sizeof(Task) == 64, "Task must be 64 bytes (host packs it as 8 x int64)");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)DW_LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(dw_kernel, dim3((unsigned)n_tasks), dim3(256), DW_LDS_BYTES, stream,
+                     reinterpret_cast<const Task*>(tasks));
+  return (int)hipGetLastError();
+}

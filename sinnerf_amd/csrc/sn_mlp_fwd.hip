@@ -46,7 +46,7 @@ SN_DEV void embed_dir(float x, float y, float z, int h, float* de) {
 // INPUT_MODE 0: points from (rays, z_vals):  p -> ray = p / S, xyz = o + d*z     (render_rays path)
 // INPUT_MODE 1: pre-embedded rows x[p, 0:63(+27)] with leading dimension ld       (NeRF.forward path)
 // STORE: training forward -- additionally writes every layer's activations (acts[10][P][256]: h1..h8, final, h2) and the
-// embedded inputs (emb[P][96]: xyz columns 0..62, dir columns 64..90, reference column order) for the backward pass.
+// embedded inputs (emb[P][128], zero-filled by the caller: xyz columns 0..62, dir columns 64..90, reference column order) for the backward pass.
 template <bool DMA, bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1,
@@ -124,21 +124,19 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     }                                                                                                  \
   }
   if (STORE && valid) {
-    float* er = emb + p_raw * 96;
+    float* er = emb + p_raw * 128;        // caller zero-fills emb: pad columns 63, 91..127 stay 0
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
       const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
       const int c = h ? c1 : c0;
       if (c >= 0) er[c] = xe[e];
     }
-    if (h == 1) er[63] = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
       const int c = h ? c1 : c0;
       if (c >= 0) er[64 + c] = de[e];
     }
-    if (h == 1) { er[91] = 0.0f; er[92] = 0.0f; er[93] = 0.0f; er[94] = 0.0f; er[95] = 0.0f; }
   }
 
   // Common per-slab prologue / epilogue.  `cur`/`oth` are compile-time buffer choices.

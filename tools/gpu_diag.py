@@ -26,7 +26,7 @@ for (n, S) in ((60, 37), (64, 64)):
     P = n * S
     rays_t, z_t, g_t = (torch.from_numpy(a).to(dev) for a in (rays, z, g))
     raw = torch.empty((n, S, 4), device=dev); acts = torch.full((10, P, 256), float("nan"), device=dev)
-    emb = torch.full((P, 96), float("nan"), device=dev)
+    emb = torch.zeros((P, 128), device=dev)
     _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m.packed()), 0, _lib.ptr(rays_t), _lib.ptr(z_t), n, S, _lib.ptr(raw),
                                              _lib.ptr(acts), _lib.ptr(emb), None), "fwd")
     G = torch.full((10, P, 256), float("nan"), device=dev); g_o = torch.full((P, 4), float("nan"), device=dev)
