@@ -16,9 +16,9 @@ from . import _lib
 from .nerf import dtype_code
 
 
-_VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64)}
+_VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64), 4: (32, 256), 5: (32, 128)}
 _KB = 16                      # csrc/sn_dw.hip: points per staged chunk
-_TARGET_WGS = 248             # one workgroup per CU per launch, a little slack for the small problems
+_TARGET_WGS = 256             # exactly one workgroup per CU per launch
 
 
 def _weight_grads(model, acts, emb, G, g_o, needs):
@@ -42,14 +42,24 @@ def _weight_grads(model, acts, emb, G, g_o, needs):
     probs.append((("w", 8), G[8], 0, 256, acts[7], 0, 256, 0, True))          # xyz_encoding_final
     probs.append((("w", 9), G[9], 0, 256, acts[8], 0, 256, 2, True))          # dir_encoding[:, :256]
     probs.append((("w9e", 9), G[9], 0, 256, emb, 64, 128, 3, False))          # dir_encoding[:, 256:]
+    # rows 0..2 = g_y of rgb, row 3 = g_y of sigma (zero-padded 32-wide block at G[9][:, 128:160], sn_mlp_bwd.hip)
+    probs.append((("sig", 10), G[9], 128, 256, acts[7], 0, 256, 4, False))    # sigma  (nerf.py:136)
+    probs.append((("rgb", 11), G[9], 128, 256, acts[9], 0, 256, 5, True))     # rgb    (nerf.py:144)
     work = [_VARIANT_MN[p[7]][0] * _VARIANT_MN[p[7]][1] for p in probs]
     tot = float(sum(work))
     max_split = max(1, P // (4 * _KB))
+    # K-splits proportional to the work of a problem, summing to _TARGET_WGS (largest remainders get the slack)
+    ideal = [_TARGET_WGS * w / tot for w in work]
+    splits = [max(1, int(x)) for x in ideal]
+    for j in sorted(range(len(work)), key=lambda j: ideal[j] - int(ideal[j]), reverse=True):
+        if sum(splits) >= _TARGET_WGS:
+            break
+        splits[j] += 1
     rows, outs = [], []
-    for pr, w in zip(probs, work):
+    for pr, ns in zip(probs, splits):
         key, A, ac, lda, B, bc, ldb, var, want_b = pr
         M, N = _VARIANT_MN[var]
-        ns = int(min(max_split, max(1, round(_TARGET_WGS * w / tot))))
+        ns = int(min(max_split, ns))
         per = -(-P // ns)
         per = -(-per // _KB) * _KB
         ns = -(-P // per)
@@ -81,11 +91,9 @@ def _weight_grads(model, acts, emb, G, g_o, needs):
     add(*res[("w", 8)], 8)
     gw, gb = res[("w", 9)]
     add(torch.cat([gw, res[("w9e", 9)][0][:, :27]], 1), gb, 9)
-    h8 = acts[7]
-    gs = g_o[:, 3:4]
-    add(gs.t() @ h8, gs.sum(0), 10)                          # sigma (nerf.py:136)
-    gr = g_o[:, :3]
-    add(gr.t() @ acts[9][:, :128], gr.sum(0), 11)            # rgb (nerf.py:144)
+    gb4 = res[("rgb", 11)][1]                                # column sums of [g_rgb(3), g_sigma(1), 0...]
+    add(res[("sig", 10)][0][3:4].contiguous(), gb4[3:4].contiguous(), 10)
+    add(res[("rgb", 11)][0][:3].contiguous(), gb4[:3].contiguous(), 11)
     return grads
 
 

@@ -10,15 +10,17 @@
 // ds_read_b32 -- no transposes anywhere.
 //
 // One workgroup = one task = (problem, K-range): 2x2 waves, each wave owns an (MT*32) x (NT*32) block of accumulators
-// (MT=NT=4: 256 accumulator registers) and walks its K-range in chunks of 16 points (double-buffered LDS, one barrier
-// per chunk, 16 MFMAs per k-step at MT=NT=4).  Partial results go to a per-task slab; the K-split partials are summed
-// afterwards (deterministic, no atomics).
+// (MT=NT=4: 256 accumulator registers) and walks its K-range in chunks of 16 points.  G and X stream from HBM exactly
+// once per problem, so unlike the L2-resident weight slabs of the MLP kernels the DMA needs depth: a 4-deep LDS ring,
+// three chunks in flight, COUNTED s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the queue).
+// Partial results go to a per-task slab; the K-split partials are summed afterwards (deterministic, no atomics).
 #include "sn_device.h"
 
 namespace snd {
 
 constexpr int KB = 16;                          // points per staged chunk
-constexpr int DW_LDS_BYTES = 2 * KB * (256 + 256) * 4;   // 65536
+constexpr int NBUF = 4;                         // LDS ring depth (NBUF-1 chunks in flight)
+constexpr int DW_LDS_BYTES = NBUF * KB * (256 + 256) * 4;   // 131072
 
 struct Task {                                   // 64 bytes, built on the host (sinnerf_amd/autograd.py)
   const float* a;                               // G  + column offset
@@ -27,7 +29,7 @@ struct Task {                                   // 64 bytes, built on the host (
   float* bias;                                  // partial db  [M_wg] or nullptr
   long k0, k1;                                  // point range
   int lda, ldb;
-  int ldc, variant;                             // variant: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64
+  int ldc, variant;                             // M x N: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64, 4 = 32x256, 5 = 32x128
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -51,13 +53,23 @@ SN_DEV void stage_rows(const float* __restrict__ g, int ld, long k, long k_end, 
   }
 }
 
-template <int MT, int NT>
+template <int N>
+SN_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// WM x WN waves, each wave an (MT*32) x (NT*32) accumulator block.
+template <int MT, int NT, int WM, int WN>
 SN_DEV void run_task(const Task& t, char* smem, int tid) {
-  constexpr int WA = 2 * MT * 32, WB = 2 * NT * 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int WA = WM * MT * 32, WB = WN * NT * 32;
   constexpr int A_BYTES = KB * WA * 4, B_BYTES = KB * WB * 4, BUF = A_BYTES + B_BYTES;
-  const int lane = tid & 63, wave = tid >> 6;
+  // DMA instructions per thread per chunk.  A 32-wide A tile (variants 4/5) is only 128 16-byte pieces: waves 2,3 issue
+  // none of it, so their vmcnt budget is one instruction per chunk smaller (the wait must be exact per wave).
+  constexpr int CH_A = KB * WA / 4, CH_B = KB * WB / 4;
+  static_assert(CH_B % 256 == 0 && CH_A % 64 == 0, "stage_rows predicates must be wave-uniform");
+  constexpr int IT_A = (CH_A + 255) / 256, IT_B = CH_B / 256, PART_A = (CH_A % 256) / 64;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int m0 = wr * MT * 32, n0 = wc * NT * 32;
 
   f32x16 acc[MT][NT];
@@ -73,18 +85,26 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
 
   const long k0 = t.k0, k1 = t.k1;
   if (k0 >= k1) return;
-  stage_rows<WA>(t.a, t.lda, k0, k1, smem, tid);
-  stage_rows<WB>(t.b, t.ldb, k0, k1, smem + A_BYTES, tid);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (long k = k0; k < k1; k += KB) {
-    char* bc = smem + cur * BUF;
-    char* bn = smem + (cur ^ 1) * BUF;
-    if (k + KB < k1) {
-      stage_rows<WA>(t.a, t.lda, k + KB, k1, bn, tid);
-      stage_rows<WB>(t.b, t.ldb, k + KB, k1, bn + A_BYTES, tid);
+  const int n_chunks = (int)((k1 - k0 + KB - 1) / KB);
+  // prologue: NBUF-1 chunks in flight (chunks past the end are staged as clamped copies and never consumed)
+#pragma unroll
+  for (int c = 0; c < NBUF - 1; ++c) {
+    stage_rows<WA>(t.a, t.lda, k0 + (long)c * KB, k1, smem + c * BUF, tid);
+    stage_rows<WB>(t.b, t.ldb, k0 + (long)c * KB, k1, smem + c * BUF + A_BYTES, tid);
+  }
+  for (int c = 0; c < n_chunks; ++c) {
+    const long k = k0 + (long)c * KB;
+    // chunk c was issued NBUF-1 chunks ago: everything but the (NBUF-2) younger chunks must have landed
+    if (PART_A != 0 && wave >= PART_A) wait_vmcnt<(NBUF - 2) * (IT_A - 1 + IT_B)>();
+    else wait_vmcnt<(NBUF - 2) * (IT_A + IT_B)>();
+    __builtin_amdgcn_s_barrier();               // all waves' pieces of chunk c landed; chunk c-1 fully consumed
+    {
+      const int slot = (c + NBUF - 1) % NBUF;   // = slot of chunk c-1
+      char* bn = smem + slot * BUF;
+      stage_rows<WA>(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, bn, tid);
+      stage_rows<WB>(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, bn + A_BYTES, tid);
     }
+    char* bc = smem + (c % NBUF) * BUF;
     const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;
     const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
     const bool full = (k + KB <= k1);
@@ -107,10 +127,8 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
   }
+  wait_vmcnt<0>();                               // drain the over-issued tail chunks before the LDS is released
   // epilogue: accumulator (row = (r&3)+8(r>>2)+4h, col = i) -> c[m][n], 128 B per lane-half per store
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -135,10 +153,12 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks)
   const Task t = tasks[blockIdx.x];
   const int tid = threadIdx.x;
   switch (t.variant) {
-    case 0: run_task<4, 4>(t, smem, tid); break;
-    case 1: run_task<4, 1>(t, smem, tid); break;
-    case 2: run_task<2, 4>(t, smem, tid); break;
-    default: run_task<2, 1>(t, smem, tid); break;
+    case 0: run_task<4, 4, 2, 2>(t, smem, tid); break;
+    case 1: run_task<4, 1, 2, 2>(t, smem, tid); break;
+    case 2: run_task<2, 4, 2, 2>(t, smem, tid); break;
+    case 3: run_task<2, 1, 2, 2>(t, smem, tid); break;
+    case 4: run_task<1, 2, 1, 4>(t, smem, tid); break;
+    default: run_task<1, 1, 1, 4>(t, smem, tid); break;
   }
 }
 

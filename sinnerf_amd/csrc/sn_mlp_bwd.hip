@@ -64,7 +64,15 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
     gy.w = valid ? g.w : 0.0f;
     b_rgb[0] = gy.x; b_rgb[1] = gy.y; b_rgb[2] = gy.z;
     b_sig[0] = gy.w;
-    if (valid) reinterpret_cast<float4*>(g_out)[p_raw] = gy;      // g_y of rgb.0 (3) and of sigma (1)
+    if (valid) {
+      reinterpret_cast<float4*>(g_out)[p_raw] = gy;               // g_y of rgb.0 (3) and of sigma (1)
+      // the same 4 values as a zero-padded 32-wide block in the unused half of slot 9 (columns 128..159): the A operand
+      // of the rgb / sigma weight-gradient contractions (sn_dw.hip variants 4/5)
+      float4* row = reinterpret_cast<float4*>(G + ((long)9 * P + p_raw) * 256 + 128);
+      row[0] = gy;
+#pragma unroll
+      for (int q = 1; q < 8; ++q) row[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
