@@ -17,6 +17,10 @@ from .nerf import dtype_code
 
 
 _VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64), 4: (32, 256), 5: (32, 128)}
+# cost of one point of a K-range on one CU, in cycles: max(MFMA issue time of the wave block, tile bytes / ~8 B/clk of
+# per-CU streaming bandwidth) -- the narrow problems are DMA-bound, not MFMA-bound (measured: splitting by FLOPs alone left
+# the 32x128 problem streaming 168 MB through a single CU, 2.5x the kernel time of the balanced split)
+_VARIANT_COST = {0: 512, 1: 160, 2: 256, 3: 96, 4: 144, 5: 80}
 _KB = 16                      # csrc/sn_dw.hip: points per staged chunk
 _TARGET_WGS = 256             # exactly one workgroup per CU per launch
 
@@ -45,7 +49,7 @@ def _weight_grads(model, acts, emb, G, g_o, needs):
     # rows 0..2 = g_y of rgb, row 3 = g_y of sigma (zero-padded 32-wide block at G[9][:, 128:160], sn_mlp_bwd.hip)
     probs.append((("sig", 10), G[9], 128, 256, acts[7], 0, 256, 4, False))    # sigma  (nerf.py:136)
     probs.append((("rgb", 11), G[9], 128, 256, acts[9], 0, 256, 5, True))     # rgb    (nerf.py:144)
-    work = [_VARIANT_MN[p[7]][0] * _VARIANT_MN[p[7]][1] for p in probs]
+    work = [_VARIANT_COST[p[7]] for p in probs]
     tot = float(sum(work))
     max_split = max(1, P // (4 * _KB))
     # K-splits proportional to the work of a problem, summing to _TARGET_WGS (largest remainders get the slack)

@@ -107,24 +107,34 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
     char* bc = smem + (c % NBUF) * BUF;
     const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;
     const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
-    const bool full = (k + KB <= k1);
+    if (k + KB <= k1) {
 #pragma unroll
-    for (int s = 0; s < KB / 2; ++s) {
-      float av[MT], bv[NT];
+      for (int s = 0; s < KB / 2; ++s) {
+        float av[MT], bv[NT];
 #pragma unroll
-      for (int a = 0; a < MT; ++a) av[a] = la[(2 * s) * WA + 32 * a];
+        for (int a = 0; a < MT; ++a) av[a] = la[(2 * s) * WA + 32 * a];
 #pragma unroll
-      for (int b = 0; b < NT; ++b) bv[b] = lb[(2 * s) * WB + 32 * b];
-      if (!full) {                               // ragged tail: rows >= k1 are clamped copies, zero their A side
+        for (int b = 0; b < NT; ++b) bv[b] = lb[(2 * s) * WB + 32 * b];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          bsum[a] += av[a];
+#pragma unroll
+          for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+      }
+    } else {                                     // ragged last chunk: rows >= k1 are clamped copies, zero their A side
+#pragma unroll 1
+      for (int s = 0; s < KB / 2; ++s) {
         const bool ok = (k + 2 * s + h) < k1;
 #pragma unroll
-        for (int a = 0; a < MT; ++a) av[a] = ok ? av[a] : 0.0f;
-      }
+        for (int a = 0; a < MT; ++a) {
+          float av = la[(2 * s) * WA + 32 * a];
+          av = ok ? av : 0.0f;
+          bsum[a] += av;
 #pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        bsum[a] += av[a];
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lb[(2 * s) * WB + 32 * b], acc[a][b], 0, 0, 0);
+        }
       }
     }
   }
