@@ -72,26 +72,29 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
                    int sigma_only, int flags, float* out, void* stream);
 
 /* ---- training forward: sn_mlp_forward + the activations autograd would keep alive --------------
- * acts (10, n_points, 256): slots 0..7 = outputs of xyz_encoding_1..8 (post-ReLU), 8 = xyz_encoding_final,
- * 9 = dir_encoding output (128 wide, leading dimension 256).  emb (n_points, 128), ZERO-FILLED by the caller:
+ * slot_rows >= n_points = rows allocated per slot (callers round it up to a multiple of 16 and zero the pad rows so
+ * that sn_dw_gemm can walk whole 16-point chunks).
+ * acts (10, slot_rows, 256): slots 0..7 = outputs of xyz_encoding_1..8 (post-ReLU), 8 = xyz_encoding_final,
+ * 9 = dir_encoding output (128 wide, leading dimension 256).  emb (slot_rows, 128), ZERO-FILLED by the caller:
  * the kernel writes columns [0,63) = Embedding(xyz) and [64,91) = Embedding(dir) in the reference's column
  * order (nerf.py:36-41).                                                                                     */
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
-                         float* out, float* acts, float* emb, void* stream);
+                         float* out, float* acts, float* emb, long slot_rows, void* stream);
 
 /* ---- backward of models/nerf.py:122-148 w.r.t. layer outputs (what loss.backward() at sinnerf.py:551 runs) ----
  * blob_bwd: transposed-weight blob (sn_build_pack_table_bwd).  out_raw / g_raw (n_points,4): forward output and its
- * gradient.  Writes g_acts (10, n_points, 256): slots 0..7 = dL/d(pre-activation) of xyz_encoding_1..8, 8 = of
+ * gradient.  Writes g_acts (10, slot_rows, 256): slots 0..7 = dL/d(pre-activation) of xyz_encoding_1..8, 8 = of
  * xyz_encoding_final, 9 = of dir_encoding (128 wide); g_out (n_points,4) = dL/d(pre-activation) of rgb (3), sigma (1).
  * Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.   */
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
-                          long n_points, float* g_acts, float* g_out, void* stream);
+                          long n_points, long slot_rows, float* g_acts, float* g_out, void* stream);
 
 /* ---- weight gradients  dW[m,n] = sum_p G[p,m] X[p,n],  db[m] = sum_p G[p,m]  (autograd of every nn.Linear of
  * models/nerf.py:66-103: gW = g_y^T x, gb = sum g_y) as K-split MFMA contractions over all sample points.
  * tasks: DEVICE array of n_tasks 64-byte records (one workgroup each):
  *   { const float* a;  const float* b;  float* c;  float* bias_or_NULL;  int64 k0, k1;  int32 lda, ldb;  int32 ldc, variant; }
- * a = G + column offset (row-major [P][lda]), b = X + column offset ([P][ldb]), point range [k0,k1);
+ * a = G + column offset (row-major [P][lda]), b = X + column offset ([P][ldb]), point range [k0,k1) with
+ * (k1-k0) % 16 == 0 and every row readable (zero-padded G rows contribute nothing);
  * variant 0: M x N = 256x256, 1: 256x64, 2: 128x256, 3: 128x64.  c receives the PARTIAL M x N result of that K-range
  * (row-major, leading dimension ldc), bias the partial column sums of a; the caller sums the partials of a problem. */
 int sn_dw_gemm(const void* tasks, int n_tasks, void* stream);

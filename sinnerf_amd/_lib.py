@@ -35,8 +35,8 @@ SIGNATURES = {
     "sn_build_pack_table_bwd": (_int, [c_vp]),
     "sn_sample_coarse": (_int, [c_fp, _long, _int, _int, _float, c_fp, c_fp, c_vp]),
     "sn_mlp_forward": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
-    "sn_mlp_forward_train": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, c_fp, c_fp, c_fp, c_vp]),
-    "sn_mlp_backward_chain": (_int, [c_vp, _int, c_fp, c_fp, c_fp, _long, c_fp, c_fp, c_vp]),
+    "sn_mlp_forward_train": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, c_fp, c_fp, c_fp, _long, c_vp]),
+    "sn_mlp_backward_chain": (_int, [c_vp, _int, c_fp, c_fp, c_fp, _long, _long, c_fp, c_fp, c_vp]),
     "sn_dw_gemm": (_int, [c_vp, _int, c_vp]),
     "sn_composite_backward": (_int, [c_fp, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_fp, c_vp]),
     "sn_mlp_forward_embedded": (_int, [c_vp, _int, c_fp, _long, _int, _int, _int, c_fp, c_vp]),

@@ -31,7 +31,7 @@ def _weight_grads(model, acts, emb, G, g_o, needs):
     deterministic sum of the K-split partials; sigma (1 row) and rgb (3 rows) are tiny and go through torch.mm.
     Order of the returned list = NeRF.raw_tensors()."""
     import numpy as np
-    P = acts.shape[1]
+    P = acts.shape[1]                                        # padded to a multiple of 16 (pad rows of G are zero)
     dev = acts.device
     fsz = 4
     # (key, A tensor, A col, lda, B tensor, B col, ldb, variant, want_bias)
@@ -109,12 +109,16 @@ class _MLPFn(torch.autograd.Function):
         dev = rays.device
         code = dtype_code(model.compute_dtype)
         out = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
-        acts = torch.empty((10, P, 256), dtype=torch.float32, device=dev)
-        emb = torch.zeros((P, 128), dtype=torch.float32, device=dev)
+        rows = -(-P // _KB) * _KB                      # sn_dw_gemm walks whole 16-point chunks: pad rows are zero
+        acts = torch.empty((10, rows, 256), dtype=torch.float32, device=dev)
+        if rows > P:
+            acts[:, P:].zero_()
+        emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
         _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
-                                                 _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), _lib.stream_ptr()),
+                                                 _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
                    "sn_mlp_forward_train")
         ctx.model = model
+        ctx.n_points = P
         ctx.save_for_backward(acts, emb, out)
         return out
 
@@ -122,14 +126,16 @@ class _MLPFn(torch.autograd.Function):
     def backward(ctx, g_out):
         acts, emb, out = ctx.saved_tensors
         model = ctx.model
-        P = acts.shape[1]
+        P, rows = ctx.n_points, acts.shape[1]
         dev = acts.device
         g_out = g_out.contiguous().float()
-        G = torch.empty((10, P, 256), dtype=torch.float32, device=dev)
+        G = torch.empty((10, rows, 256), dtype=torch.float32, device=dev)
+        if rows > P:
+            G[:, P:].zero_()
         g_o = torch.empty((P, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd()), dtype_code(model.compute_dtype),
-                                                      _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, _lib.ptr(G),
+                                                      _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")
             needs = ctx.needs_input_grad[3:]
             grads = _weight_grads(model, acts, emb, G, g_o, needs)

@@ -6,9 +6,9 @@
 extern "C" {
 int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                               int sigma_only, int input_mode, int use_dma, float* out, float* acts, float* emb,
-                              hipStream_t stream);
+                              long slot_rows, hipStream_t stream);
 int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
-                                     long n_points, float* G, float* g_out, hipStream_t stream);
+                                     long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
@@ -120,22 +120,23 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
   if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
-                                   (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1, out, nullptr, nullptr, (hipStream_t)stream);
+                                   (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
-                         float* out, float* acts, float* emb, void* stream) {
+                         float* out, float* acts, float* emb, long slot_rows, void* stream) {
   if (!blob || !rays || !z_vals || !out || !acts || !emb || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, 0, 0, 1, out, acts, emb,
-                                   (hipStream_t)stream);
+                                   slot_rows, (hipStream_t)stream);
 }
 
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
-                          long n_points, float* g_acts, float* g_out, void* stream) {
+                          long n_points, long slot_rows, float* g_acts, float* g_out, void* stream) {
   if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
-  return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, g_acts, g_out, (hipStream_t)stream);
+  return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
+                                          (hipStream_t)stream);
 }
 
 int sn_dw_gemm(const void* tasks, int n_tasks, void* stream) {
@@ -157,7 +158,7 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   if (ld < (sigma_only ? 63 : 90)) return SN_E_BADSHAPE;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1,
-                                   out, nullptr, nullptr, (hipStream_t)stream);
+                                   out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int sn_composite_forward(const float* raw, int has_rgb, const float* z_vals, const float* rays, const float* noise,

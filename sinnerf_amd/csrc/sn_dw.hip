@@ -27,7 +27,7 @@ struct Task {                                   // 64 bytes, built on the host (
   const float* b;                               // X  + column offset
   float* c;                                     // partial dW  [M_wg][ldc]
   float* bias;                                  // partial db  [M_wg] or nullptr
-  long k0, k1;                                  // point range
+  long k0, k1;                                  // point range: (k1-k0) % 16 == 0, rows [k0,k1) readable (callers zero-pad G)
   int lda, ldb;
   int ldc, variant;                             // M x N: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64, 4 = 32x256, 5 = 32x128
 };
@@ -35,7 +35,7 @@ struct Task {                                   // 64 bytes, built on the host (
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
-// copy ROWS x W floats (row-major, W*4 bytes per row) global -> LDS, clamping rows to < k_end
+// copy KB x W floats (row-major, W*4 bytes per row) global -> LDS; rows past k_end (prefetch overrun) are clamped
 template <int W>
 SN_DEV void stage_rows(const float* __restrict__ g, int ld, long k, long k_end, char* lds, int tid) {
   constexpr int CHUNKS = KB * W / 4;            // 16-byte chunks
@@ -107,34 +107,18 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
     char* bc = smem + (c % NBUF) * BUF;
     const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;
     const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
-    if (k + KB <= k1) {
 #pragma unroll
-      for (int s = 0; s < KB / 2; ++s) {
-        float av[MT], bv[NT];
+    for (int s = 0; s < KB / 2; ++s) {
+      float av[MT], bv[NT];
 #pragma unroll
-        for (int a = 0; a < MT; ++a) av[a] = la[(2 * s) * WA + 32 * a];
+      for (int a = 0; a < MT; ++a) av[a] = la[(2 * s) * WA + 32 * a];
 #pragma unroll
-        for (int b = 0; b < NT; ++b) bv[b] = lb[(2 * s) * WB + 32 * b];
+      for (int b = 0; b < NT; ++b) bv[b] = lb[(2 * s) * WB + 32 * b];
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
-          bsum[a] += av[a];
+      for (int a = 0; a < MT; ++a) {
+        bsum[a] += av[a];
 #pragma unroll
-          for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-        }
-      }
-    } else {                                     // ragged last chunk: rows >= k1 are clamped copies, zero their A side
-#pragma unroll 1
-      for (int s = 0; s < KB / 2; ++s) {
-        const bool ok = (k + 2 * s + h) < k1;
-#pragma unroll
-        for (int a = 0; a < MT; ++a) {
-          float av = la[(2 * s) * WA + 32 * a];
-          av = ok ? av : 0.0f;
-          bsum[a] += av;
-#pragma unroll
-          for (int b = 0; b < NT; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lb[(2 * s) * WB + 32 * b], acc[a][b], 0, 0, 0);
-        }
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
       }
     }
   }

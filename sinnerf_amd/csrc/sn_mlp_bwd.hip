@@ -30,7 +30,8 @@ SN_DEV f32x16 zero_acc() {
 // acts / G slots: 0..7 = h1..h8 (resp. g_y of xyz_encoding_1..8), 8 = final, 9 = h2 / g_y2 (128 wide, ld 256)
 __global__ void __launch_bounds__(256)
 mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict__ acts, const float* __restrict__ out_raw,
-                         const float* __restrict__ g_raw, long P, float* __restrict__ G, float* __restrict__ g_out) {
+                         const float* __restrict__ g_raw, long P, long slot_rows, float* __restrict__ G,
+                         float* __restrict__ g_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const buf0 = smem;
   char* const buf1 = smem + BWD_SLAB_LDS_BYTES;
@@ -68,7 +69,7 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
       reinterpret_cast<float4*>(g_out)[p_raw] = gy;               // g_y of rgb.0 (3) and of sigma (1)
       // the same 4 values as a zero-padded 32-wide block in the unused half of slot 9 (columns 128..159): the A operand
       // of the rgb / sigma weight-gradient contractions (sn_dw.hip variants 4/5)
-      float4* row = reinterpret_cast<float4*>(G + ((long)9 * P + p_raw) * 256 + 128);
+      float4* row = reinterpret_cast<float4*>(G + ((long)9 * slot_rows + p_raw) * 256 + 128);
       row[0] = gy;
 #pragma unroll
       for (int q = 1; q < 8; ++q) row[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -98,12 +99,12 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
 #define SNB_LOAD_ACT(slot, t)                                                                          \
   f32x4 av[4];                                                                                         \
   {                                                                                                    \
-    const float* src = acts + ((long)(slot) * P + p) * 256 + 32 * (t) + 4 * h;                         \
+    const float* src = acts + ((long)(slot) * slot_rows + p) * 256 + 32 * (t) + 4 * h;                 \
     _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) av[q4] = *reinterpret_cast<const f32x4*>(src + 8 * q4); \
   }
 #define SNB_STORE_G(slot, t, arr, off)                                                                 \
   if (valid) {                                                                                         \
-    float* dst = G + ((long)(slot) * P + p_raw) * 256 + 32 * (t) + 4 * h;                              \
+    float* dst = G + ((long)(slot) * slot_rows + p_raw) * 256 + 32 * (t) + 4 * h;                      \
     _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                 \
       float4 v;                                                                                        \
       v.x = arr[(off) + 4 * q4 + 0]; v.y = arr[(off) + 4 * q4 + 1];                                    \
@@ -176,10 +177,11 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
 }  // namespace snk
 
 extern "C" int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw,
-                                                const float* g_raw, long n_points, float* G, float* g_out,
-                                                hipStream_t stream) {
+                                                const float* g_raw, long n_points, long slot_rows, float* G,
+                                                float* g_out, hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
+  if (slot_rows < n_points) return -1;
   const long tiles = (n_points + 127) / 128;
   if (tiles > 0x7fffffffL) return -2;
   auto kfn = mlp_bwd_chain_f32_kernel;
@@ -187,6 +189,6 @@ extern "C" int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* 
                                      (int)MLP_BWD_LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(256), MLP_BWD_LDS_BYTES, stream,
-                     reinterpret_cast<const char*>(bblob), acts, out_raw, g_raw, n_points, G, g_out);
+                     reinterpret_cast<const char*>(bblob), acts, out_raw, g_raw, n_points, slot_rows, G, g_out);
   return (int)hipGetLastError();
 }

@@ -50,7 +50,7 @@ SN_DEV void embed_dir(float x, float y, float z, int h, float* de) {
 template <bool DMA, bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1,
-                   long P, int S, float* __restrict__ out, float* __restrict__ acts, float* __restrict__ emb) {
+                   long P, int S, float* __restrict__ out, float* __restrict__ acts, float* __restrict__ emb, long slot_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_bias = reinterpret_cast<float*>(smem);
   char* const buf0 = smem + BIAS_LDS_BYTES;
@@ -115,7 +115,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   // activation tile store (accumulator layout -> row-major [P][256]): 4 x 16 B per lane per 32-feature tile
 #define SN_STORE_TILE(slot, t, arr, off)                                                               \
   if (STORE && valid) {                                                                                \
-    float* dst = acts + ((long)(slot) * P + p_raw) * 256 + 32 * (t) + 4 * h;                           \
+    float* dst = acts + ((long)(slot) * slot_rows + p_raw) * 256 + 32 * (t) + 4 * h;                   \
     _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                 \
       float4 v;                                                                                        \
       v.x = arr[(off) + 4 * q4 + 0]; v.y = arr[(off) + 4 * q4 + 1];                                    \
@@ -260,13 +260,13 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 // ---------------------------------------------------------------------------------------------------
 extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                          int sigma_only, int input_mode, int use_dma, float* out, float* acts, float* emb,
-                                         hipStream_t stream) {
+                                         long slot_rows, hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
   if (tiles > 0x7fffffffL) return -2;
   const bool store = acts != nullptr;
-  if (store && (sigma_only || input_mode != 0 || emb == nullptr)) return -1;
+  if (store && (sigma_only || input_mode != 0 || emb == nullptr || slot_rows < n_points)) return -1;
   dim3 grid((unsigned)tiles), block(256);
   const size_t lds = MLP_F32_LDS_BYTES;
   const char* b = reinterpret_cast<const char*>(blob);
@@ -275,7 +275,7 @@ extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, con
     auto kfn = mlp_fwd_f32_kernel<DMA, SO, IM, ST>;                                                              \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                          \
-    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb);           \
+    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows); \
   } while (0)
   if (store) {
     SN_LAUNCH(true, false, 0, true);

@@ -28,9 +28,9 @@ for (n, S) in ((60, 37), (64, 64)):
     raw = torch.empty((n, S, 4), device=dev); acts = torch.full((10, P, 256), float("nan"), device=dev)
     emb = torch.zeros((P, 128), device=dev)
     _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m.packed()), 0, _lib.ptr(rays_t), _lib.ptr(z_t), n, S, _lib.ptr(raw),
-                                             _lib.ptr(acts), _lib.ptr(emb), None), "fwd")
+                                             _lib.ptr(acts), _lib.ptr(emb), P, None), "fwd")
     G = torch.full((10, P, 256), float("nan"), device=dev); g_o = torch.full((P, 4), float("nan"), device=dev)
-    _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m.packed_bwd()), 0, _lib.ptr(acts), _lib.ptr(raw), _lib.ptr(g_t), P,
+    _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m.packed_bwd()), 0, _lib.ptr(acts), _lib.ptr(raw), _lib.ptr(g_t), P, P,
                                               _lib.ptr(G), _lib.ptr(g_o), None), "bwd")
     torch.cuda.synchronize()
     xin = np.concatenate([O.embedding(O._points(rays, z).reshape(-1, 3), 10), np.repeat(O.embedding(rays[:, 3:6], 4), S, 0)], 1)

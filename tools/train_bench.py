@@ -66,10 +66,10 @@ def timed(fn, reps=3):
 P = N * 128
 ms_fwd, raw = timed(lambda: A._MLPFn.apply(m, rays, z, *m.raw_tensors()))
 acts, embt, outt = raw.grad_fn.saved_tensors if raw.grad_fn is not None else (None, None, None)
-G = torch.empty((10, P, 256), device=dev); g_o = torch.empty((P, 4), device=dev)
+G = torch.empty((10, acts.shape[1], 256), device=dev); g_o = torch.empty((P, 4), device=dev)
 from sinnerf_amd import _lib                           # noqa: E402
 ms_chain, _ = timed(lambda: _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m.packed_bwd()), 0, _lib.ptr(acts), _lib.ptr(outt),
-                                                                      _lib.ptr(g), P, _lib.ptr(G), _lib.ptr(g_o), None), "chain"))
+                                                                      _lib.ptr(g), P, acts.shape[1], _lib.ptr(G), _lib.ptr(g_o), None), "chain"))
 ms_dw, _ = timed(lambda: A._weight_grads(m, acts, embt, G, g_o, [True] * 24))
 with torch.no_grad():
     ms_inf, _ = timed(lambda: sinnerf_amd.rendering._mlp(m, rays, z, False))
