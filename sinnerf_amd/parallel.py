@@ -1,0 +1,97 @@
+"""Multi-GPU support of the hot path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+Reference: the only parallelism in SinNeRF is Lightning DDP (``train.py:51-52``: ``distributed_backend='ddp'``): model
+replicas, each rank renders its own patches, gradients are mean-reduced by DDP's bucketed all-reduce.  SURVEY.md §8e:
+
+* inference: every ray is independent -> ``shard_rays`` partitions the (H*W, 8) ray array contiguously across ranks,
+  **no collective** on the data path (an optional gather of the (N/R, 3) rgb tiles to rank 0 for display);
+* training: replicas + **one** all-reduce per step of a single flat fp32 buffer holding the gradients of both NeRFs
+  (1 191 688 floats = 4.77 MB).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a 4.77 MB ring all-reduce is
+  ~55 us, far below a >= 10 ms step, so it is issued once after backward, un-bucketed, on the compute stream.
+
+``FlatGradBuffer`` makes every ``param.grad`` a view into the flat buffer, so autograd accumulates straight into it
+and the all-reduce needs no gather/scatter copies.  Works with any backend (gloo on CPU in the tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous [lo, hi) slice of n items owned by ``rank`` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_rays(rays, rank=None, world=None):
+    """This rank's contiguous share of a ray tensor (N, 8) -- the inference partition (no collective needed)."""
+    if rank is None:
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    lo, hi = shard_bounds(rays.shape[0], rank, world)
+    return rays[lo:hi]
+
+
+def gather_rows(local, n_total, dst=0):
+    """Optional: collect per-rank row blocks (e.g. (N/R, 3) rgb tiles) on ``dst`` in ray order.  Returns the full
+    tensor on ``dst`` and None elsewhere.  Not on the timed path."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
+    pad = max(hi - lo for lo, hi in sizes)
+    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], 0)
+
+
+class FlatGradBuffer:
+    """One flat fp32 gradient buffer for a list of modules; ``param.grad`` are views into it."""
+
+    def __init__(self, modules):
+        self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        """Replaces ``optimizer.zero_grad()``: one memset, views stay attached."""
+        self.flat.zero_()
+        lo = self.flat.data_ptr()
+        hi = lo + self.flat.numel() * self.flat.element_size()
+        for p in self.params:                      # re-attach if someone set grads to None / replaced them
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                self._reattach()
+                break
+
+    def _reattach(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def all_reduce_mean(self, group=None):
+        """The single exchange step of a training iteration: sum over ranks, then scale by 1/world (DDP semantics)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.mul_(1.0 / dist.get_world_size(group))
+        return self.flat
+
+
+def broadcast_parameters(modules, src=0):
+    """Make replicas identical at start-up (what DDP's constructor does)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=src)

@@ -1,0 +1,118 @@
+"""System surface around the hot path -- the hooks ``train.py`` / Lightning 0.10 call on ``SinNeRF``
+(reference ``models/sinnerf.py:124-586``), restricted to what touches the accelerated path.
+
+In scope (SURVEY.md §8b "System surface"): ``nerf_coarse`` / ``nerf_fine`` / ``models`` / ``embeddings`` attributes
+(``sinnerf.py:133-141``, used by ``train.py:29-30``), ``forward(rays)`` with the ray-chunk loop (``sinnerf.py:171-193``),
+``configure_optimizers`` (``sinnerf.py:202-210`` with ``utils/__init__.py:11-57`` defaults: Adam eps=1e-8, MultiStepLR),
+an MSE(+SmoothL1-depth) ``training_step`` (``losses.py:12-22``, ``sinnerf.py:310-319``) and ``validation_step`` PSNR
+(``sinnerf.py:556-577``, ``metrics.py:5-15``).  Out of scope and kept on stock PyTorch by ``north_star``: datasets /
+dataloaders, discriminator + DiffAugment, DINO-ViT loss, warping helpers, TensorBoard logging -- a full SinNeRF run plugs
+those in around this class exactly as the reference does around its own.
+
+pytorch_lightning 0.10.0 is not installable offline, so the class is a plain ``nn.Module`` exposing the same hook names
+and return shapes (duck-type compatible with the PL 0.10 Trainer loop); ``train_step`` below is the minimal driver used by
+tests and benchmarks (zero -> forward -> loss -> backward -> one flat all-reduce -> Adam).
+"""
+from collections import defaultdict
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from .nerf import Embedding, NeRF
+from .parallel import FlatGradBuffer, broadcast_parameters
+from .rendering import render_rays
+
+DEFAULT_HPARAMS = dict(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=1.0, chunk=32 * 1024,
+                       lr=5e-4, weight_decay=0.0, decay_step=[20], decay_gamma=0.1, depth_weight=0.0, white_back=True,
+                       compute_dtype="fp32")
+
+
+def psnr(image_pred, image_gt):
+    """``metrics.py:5-15``."""
+    return -10.0 * torch.log10(torch.mean((image_pred - image_gt) ** 2))
+
+
+class SinNeRFSystem(nn.Module):
+    def __init__(self, hparams=None, **kw):
+        super().__init__()
+        hp = dict(DEFAULT_HPARAMS)
+        hp.update(vars(hparams) if hasattr(hparams, "__dict__") else (hparams or {}))
+        hp.update(kw)
+        self.hparams = SimpleNamespace(**hp)
+        self.embedding_xyz = Embedding(3, 10)                                    # sinnerf.py:133
+        self.embedding_dir = Embedding(3, 4)                                     # sinnerf.py:134
+        self.embeddings = [self.embedding_xyz, self.embedding_dir]
+        self.nerf_coarse = NeRF(use_new_activation=True, compute_dtype=hp["compute_dtype"])   # sinnerf.py:137
+        self.models = [self.nerf_coarse]
+        if hp["N_importance"] > 0:
+            self.nerf_fine = NeRF(use_new_activation=True, compute_dtype=hp["compute_dtype"])  # sinnerf.py:140
+            self.models.append(self.nerf_fine)
+        self.white_back = hp["white_back"]       # dataset property in the reference (blender/dtu True, llff False)
+        self._flat = None
+
+    # ---- sinnerf.py:171-193 -------------------------------------------------------------------------------------
+    def forward(self, rays):
+        B = rays.shape[0]
+        results = defaultdict(list)
+        hp = self.hparams
+        for i in range(0, B, hp.chunk):
+            chunk_res = render_rays(self.models, self.embeddings, rays[i:i + hp.chunk], hp.N_samples, hp.use_disp,
+                                    hp.perturb, hp.noise_std, hp.N_importance, hp.chunk, self.white_back)
+            for k, v in chunk_res.items():
+                results[k].append(v)
+        return {k: torch.cat(v, 0) for k, v in results.items()}
+
+    # ---- sinnerf.py:202-210 + utils/__init__.py:11-57 -----------------------------------------------------------
+    def configure_optimizers(self):
+        hp = self.hparams
+        params = [p for m in self.models for p in m.parameters()]
+        self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=1e-8, weight_decay=hp.weight_decay)
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=hp.decay_step, gamma=hp.decay_gamma)
+        return [self.optimizer], [scheduler]
+
+    # ---- losses.py:12-22 (MSE coarse + fine) + SmoothL1 depth (sinnerf.py:32-42, 310-319) ------------------------
+    def loss(self, results, rgbs, depths=None):
+        loss = torch.mean((results["rgb_coarse"] - rgbs) ** 2)
+        if "rgb_fine" in results:
+            loss = loss + torch.mean((results["rgb_fine"] - rgbs) ** 2)
+        if depths is not None and self.hparams.depth_weight > 0:
+            loss = loss + self.hparams.depth_weight * torch.nn.functional.smooth_l1_loss(results["depth_fine"], depths)
+        return loss
+
+    def training_step(self, batch, batch_idx=0, optimizer_idx=0):
+        rays, rgbs = batch["rays"], batch["rgbs"]
+        rays, rgbs = rays.reshape(-1, 8), rgbs.reshape(-1, 3)
+        results = self(rays)
+        loss = self.loss(results, rgbs, batch.get("depths"))
+        with torch.no_grad():
+            p = psnr(results["rgb_fine"], rgbs)
+        return {"loss": loss, "progress_bar": {"train_psnr": p}, "log": {"train/loss": loss.detach(), "train/psnr": p}}
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        rays, rgbs = batch["rays"].reshape(-1, 8), batch["rgbs"].reshape(-1, 3)
+        results = self(rays)
+        return {"val_loss": self.loss(results, rgbs), "val_psnr": psnr(results["rgb_fine"], rgbs)}
+
+    def validation_epoch_end(self, outputs):
+        mean_psnr = torch.stack([x["val_psnr"] for x in outputs]).mean()
+        return {"progress_bar": {"val_psnr": mean_psnr}, "log": {"val/psnr": mean_psnr}}
+
+    # ---- minimal driver: one optimisation step with the single flat all-reduce -----------------------
+    def setup_distributed(self):
+        broadcast_parameters(self.models)
+        self._flat = FlatGradBuffer(self.models)
+        return self._flat
+
+    def train_step(self, batch):
+        if not hasattr(self, "optimizer"):
+            self.configure_optimizers()
+        if self._flat is None:
+            self._flat = FlatGradBuffer(self.models)
+        self._flat.zero()
+        out = self.training_step(batch)
+        out["loss"].backward()
+        self._flat.all_reduce_mean()             # the one exchange step
+        self.optimizer.step()
+        return out

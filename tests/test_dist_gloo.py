@@ -1,0 +1,87 @@
+"""CPU, world_size 2, gloo: the multi-process host logic of the hot path (ray sharding with no collective, the single
+flat-buffer gradient all-reduce, replica broadcast).  The kernels themselves are exercised by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sinnerf_amd import NeRF
+from sinnerf_amd.parallel import FlatGradBuffer, broadcast_parameters, gather_rows, shard_bounds, shard_rays
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                        # replicas start different ...
+        models = [NeRF(use_new_activation=True), NeRF(use_new_activation=True)]
+        broadcast_parameters(models)                         # ... and are made identical
+        w0 = torch.cat([p.detach().reshape(-1) for m in models for p in m.parameters()])
+        flat = FlatGradBuffer(models)
+        assert flat.numel == 1191688                         # the all-reduce payload, 4.77 MB
+        flat.zero()
+        g = torch.Generator().manual_seed(7 + rank)
+        local = []
+        for p in flat.params:                                # stand-in for loss.backward(): accumulate INTO the views
+            d = torch.randn(p.shape, generator=g)
+            p.grad.add_(d); local.append(d.reshape(-1))
+        local = torch.cat(local)
+        assert torch.equal(flat.flat, local)                 # views alias the flat buffer
+        red = flat.all_reduce_mean().clone()
+        # rays: contiguous shards, every ray exactly once, no collective on the data path
+        rays = torch.arange(1003 * 8, dtype=torch.float32).reshape(1003, 8)
+        mine = shard_rays(rays)
+        lo, hi = shard_bounds(1003, rank, world)
+        assert torch.equal(mine, rays[lo:hi])
+        full = gather_rows(mine[:, :3].contiguous(), 1003)
+        if rank == 0:
+            assert torch.equal(full, rays[:, :3])
+        q.put((rank, w0.double().sum().item(), local.double().numpy(), red.double().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_allreduce_and_sharding_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]                            # broadcast made the replicas identical
+    mean = (res[0][2] + res[1][2]) / 2
+    for r in res:
+        assert np.allclose(r[3], mean, rtol=0, atol=1e-6)    # every rank holds the mean gradient
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 160000, 190512):
+        for world in (1, 2, 3, 4, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def test_system_surface_shapes():
+    from sinnerf_amd.system import SinNeRFSystem
+    s = SinNeRFSystem(N_importance=64)
+    assert [type(m).__name__ for m in s.models] == ["NeRF", "NeRF"] and s.models[0] is s.nerf_coarse
+    (opt,), (sched,) = s.configure_optimizers()
+    assert opt.defaults["eps"] == 1e-8 and len(opt.param_groups[0]["params"]) == 48
+    sd = s.state_dict()
+    assert "nerf_coarse.xyz_encoding_1.0.weight" in sd and "nerf_fine.rgb.0.bias" in sd      # PL checkpoint key names
+    with pytest.raises(RuntimeError):
+        s(torch.zeros(4, 8))                                 # CPU tensors: no fallback
