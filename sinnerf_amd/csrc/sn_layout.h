@@ -45,15 +45,16 @@ constexpr int K_RGB = W_HID / 2;
 //  8..31  L1-3 (xyz_encoding_2..4)         K_HID
 // 32..39  L4   (xyz_encoding_5, skip)      K_SKIP
 // 40..63  L5-7 (xyz_encoding_6..8)         K_HID
-// 64      SIG  (sigma, row 0 of the tile)  K_HID
-// 65..72  FIN  (xyz_encoding_final)        K_HID
-// 73..76  DIR  (dir_encoding)              K_DIR
-// 77      RGB  (rgb, rows 0..2)            K_RGB
-constexpr int N_SLABS = 78;
-constexpr int SLAB_SIG = 64, SLAB_FIN = 65, SLAB_DIR = 73, SLAB_RGB = 77;
+// 64..71  FIN  (xyz_encoding_final)        K_HID
+// 72..75  DIR  (dir_encoding)              K_DIR
+// The two narrow heads -- sigma (1 row, nerf.py:86) and rgb (3 rows, nerf.py:89) -- are NOT padded to 32-row MFMA tiles:
+// their weights live in the "aux" table behind the biases (K-slot order, per lane half) and are applied on the VALU
+// straight from the register-resident activations.
+constexpr int N_SLABS = 76;
+constexpr int SLAB_FIN = 64, SLAB_DIR = 72;
 
 constexpr int slab_k(int s) {
-  return s < 8 ? K_L0 : s < 32 ? K_HID : s < 40 ? K_SKIP : s < 73 ? K_HID : s < 77 ? K_DIR : K_RGB;
+  return s < 8 ? K_L0 : s < 32 ? K_HID : s < 40 ? K_SKIP : s < 72 ? K_HID : K_DIR;
 }
 // elements (of the weight dtype) per slab = 32 rows x K
 constexpr int slab_elems(int s) { return 32 * slab_k(s); }
@@ -66,7 +67,10 @@ constexpr long TOTAL_W_ELEMS = slab_elem_offset(N_SLABS);           // 606208
 constexpr int esize(int dt) { return dt == DT_F32 ? 4 : 2; }
 constexpr long bias_byte_offset(int dt) { return TOTAL_W_ELEMS * esize(dt); }
 constexpr int BIAS_FLOATS = N_SLABS * 32;
-constexpr long blob_bytes(int dt) { return bias_byte_offset(dt) + (long)BIAS_FLOATS * 4; }
+// aux table (fp32) behind the biases:  sigma_w[2][128] | rgb_w[3][2][64] | sigma_b, rgb_b[3] | pad  -> 648 floats
+constexpr int AUX_SIGW = 0, AUX_RGBW = 256, AUX_HEADB = 640, AUX_FLOATS = 648;
+constexpr int TAIL_FLOATS = BIAS_FLOATS + AUX_FLOATS;                // 3080 floats = 12320 B (16 B multiple)
+constexpr long blob_bytes(int dt) { return bias_byte_offset(dt) + (long)TAIL_FLOATS * 4; }
 constexpr int MAX_SLAB_K = K_SKIP;
 
 // ---- raw tensor ids (order of NeRF.state_dict(): nerf.py:66-103)
@@ -106,21 +110,17 @@ constexpr int slab_raw_col(int slab, int q, int h) {
     if (q < 32) return xyz_slot_col(h, q);
     return 63 + hid_slot_feature(q - 32, h);
   }
-  if (slab >= SLAB_DIR && slab < SLAB_RGB) {                                // dir: [hid(final) | dir]
+  if (slab >= SLAB_DIR) {                                                   // dir: [hid(final) | dir]
     if (q < 128) return hid_slot_feature(q, h);
     int c = dir_slot_col(h, q - 128);
     return c < 0 ? -1 : 256 + c;
   }
-  return hid_slot_feature(q, h);                                            // hidden / sig / fin / rgb (K=128: q<64)
+  return hid_slot_feature(q, h);                                            // hidden / fin
 }
 // slab -> raw weight tensor id, first raw row of the tile, number of valid rows
-constexpr int slab_raw_w(int s) {
-  return s < 64 ? 2 * (s / 8) : s == SLAB_SIG ? RAW_SIG : s < SLAB_DIR ? RAW_FIN : s < SLAB_RGB ? RAW_DIR : RAW_RGB;
-}
-constexpr int slab_row0(int s) {
-  return s < 64 ? 32 * (s % 8) : s == SLAB_SIG ? 0 : s < SLAB_DIR ? 32 * (s - SLAB_FIN) : s < SLAB_RGB ? 32 * (s - SLAB_DIR) : 0;
-}
-constexpr int slab_rows(int s) { return s == SLAB_SIG ? 1 : s == SLAB_RGB ? 3 : 32; }
+constexpr int slab_raw_w(int s) { return s < 64 ? 2 * (s / 8) : s < SLAB_DIR ? RAW_FIN : RAW_DIR; }
+constexpr int slab_row0(int s) { return s < 64 ? 32 * (s % 8) : s < SLAB_DIR ? 32 * (s - SLAB_FIN) : 32 * (s - SLAB_DIR); }
+constexpr int slab_rows(int) { return 32; }
 constexpr int raw_cols(int raw_w) {
   return raw_w == 0 ? 63 : raw_w == 8 ? 319 : raw_w == RAW_DIR ? 283 : raw_w == RAW_RGB ? 128 : 256;
 }
@@ -132,7 +132,7 @@ constexpr int raw_cols(int raw_w) {
 //  Entries carrying SRC_F32_FLAG (biases) are stored as fp32 whatever the weight dtype.
 struct PackEntry { int32_t dst; int32_t src; };
 constexpr int32_t SRC_F32_FLAG = 1 << 30;
-constexpr long table_entries() { return TOTAL_W_ELEMS + BIAS_FLOATS; }
+constexpr long table_entries() { return TOTAL_W_ELEMS + TAIL_FLOATS; }
 
 inline void build_pack_table(int dt, PackEntry* out) {
   long n = 0;
@@ -174,6 +174,25 @@ inline void build_pack_table(int dt, PackEntry* out) {
         e.src = row < rows ? (SRC_F32_FLAG | (rb << 20) | (row0 + row)) : -2;
         out[n++] = e;
       }
+  }
+  // aux table: head weights in K-slot order (slot q of lane half h  <->  hid_slot_feature(q, h))
+  const long aux0 = bias_byte_offset(dt) + (long)BIAS_FLOATS * 4;
+  for (int a = 0; a < AUX_FLOATS; ++a) {
+    PackEntry e;
+    e.dst = (int32_t)(aux0 + (long)a * 4);
+    e.src = -2;
+    if (a < AUX_RGBW) {                                   // sigma_w[h][q], q < 128  (sigma.weight is 1 x 256)
+      const int h = a / 128, q = a % 128;
+      e.src = SRC_F32_FLAG | (RAW_SIG << 20) | hid_slot_feature(q, h);
+    } else if (a < AUX_HEADB) {                           // rgb_w[c][h][q], q < 64   (rgb.0.weight is 3 x 128)
+      const int c = (a - AUX_RGBW) / 128, h = ((a - AUX_RGBW) % 128) / 64, q = (a - AUX_RGBW) % 64;
+      e.src = SRC_F32_FLAG | (RAW_RGB << 20) | (c * 128 + hid_slot_feature(q, h));
+    } else if (a == AUX_HEADB) {
+      e.src = SRC_F32_FLAG | ((RAW_SIG + 1) << 20) | 0;
+    } else if (a < AUX_HEADB + 4) {
+      e.src = SRC_F32_FLAG | ((RAW_RGB + 1) << 20) | (a - AUX_HEADB - 1);
+    }
+    out[n++] = e;
   }
 }
 

@@ -42,7 +42,7 @@ struct Stager {
 };
 
 __device__ __forceinline__ int slab_k_rt(int s) {
-  return s < 8 ? snl::K_L0 : s < 32 ? snl::K_HID : s < 40 ? snl::K_SKIP : s < 73 ? snl::K_HID : s < 77 ? snl::K_DIR : snl::K_RGB;
+  return s < 8 ? snl::K_L0 : s < 32 ? snl::K_HID : s < 40 ? snl::K_SKIP : s < 72 ? snl::K_HID : snl::K_DIR;
 }
 
 // NG groups of 4 k-steps: one ds_read_b128 (4 A operands) + 4 MFMAs per group.  The A fragments of group

@@ -9,9 +9,10 @@
 // A fragments (sn_layout.h), contractions run on v_mfma_f32_32x32x2_f32 (exact fp32, fmaf-chain order).
 //
 // Work decomposition: a wave owns 32 consecutive points (MFMA columns); a 256-thread workgroup = 4 waves
-// = 128 points shares each weight slab through LDS (double buffered, one barrier per slab).
-// Per point tile: 296 x 32 MFMAs of 64 cycles -> MFMA-bound by construction (fp32 roofline 157.3 TF).
-#include "sn_mlp_common.h"
+// = 128 points shares each weight slab through LDS (3-slot ring, one mid-slab barrier per slab: sn_mlp_pipe.h).
+// Per point tile: 290 x 32 MFMAs of 64 cycles (289.75 algorithmic: only the 63->64 input pad) -> MFMA-bound by
+// construction (fp32 roofline 157.3 TF).  The 1-row sigma and 3-row rgb heads run on the VALU from registers.
+#include "sn_mlp_pipe.h"
 
 namespace snk {
 
@@ -45,16 +46,16 @@ SN_DEV void embed_dir(float x, float y, float z, int h, float* de) {
 
 // INPUT_MODE 0: points from (rays, z_vals):  p -> ray = p / S, xyz = o + d*z     (render_rays path)
 // INPUT_MODE 1: pre-embedded rows x[p, 0:63(+27)] with leading dimension ld       (NeRF.forward path)
-// STORE: training forward -- additionally writes every layer's activations (acts[10][P][256]: h1..h8, final, h2) and the
-// embedded inputs (emb[P][128], zero-filled by the caller: xyz columns 0..62, dir columns 64..90, reference column order) for the backward pass.
-template <bool DMA, bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
+// STORE: training forward -- additionally writes every layer's activations (acts[10][slot_rows][256]: h1..h8, final, h2)
+// and the embedded inputs (emb[slot_rows][128], zero-filled by the caller: xyz columns 0..62, dir columns 64..90,
+// reference column order) for the backward pass.
+template <bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1,
                    long P, int S, float* __restrict__ out, float* __restrict__ acts, float* __restrict__ emb, long slot_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_bias = reinterpret_cast<float*>(smem);
-  char* const buf0 = smem + BIAS_LDS_BYTES;
-  char* const buf1 = buf0 + SLAB_LDS_BYTES_F32;
+  const float* lds_aux = lds_bias + snl::BIAS_FLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -65,15 +66,20 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   const bool valid = p_raw < P;
   const long p = valid ? p_raw : P - 1;
 
-  Stager<DMA> st;
-  const char* gnext = blob;
-  // stage slab 0 and the bias table while the embeddings are computed
-  st.issue(gnext, buf0, snl::slab_k(0) / 32, tid);
-  gnext += snl::slab_k(0) * 128;
+  Ring ring;
+  ring.gnext = blob;
+  ring.base = smem + TAIL_LDS_BYTES;
+  ring.nstage = 0;
+  ring.last = SIGMA_ONLY ? (snl::SLAB_FIN - 1) : (snl::N_SLABS - 1);
+  ring.tid = tid;
+  ring.wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+  ring.pieces = 0; ring.piece = 0;
+  ring.stage_whole();                            // slab 0
+  ring.stage_whole();                            // slab 1
   {
     const float4* gb = reinterpret_cast<const float4*>(blob + snl::bias_byte_offset(snl::DT_F32));
     float4* lb = reinterpret_cast<float4*>(lds_bias);
-    for (int i = tid; i < snl::BIAS_FLOATS / 4; i += 256) lb[i] = gb[i];
+    for (int i = tid; i < snl::TAIL_FLOATS / 4; i += 256) lb[i] = gb[i];
   }
 
   float xe[32], de[16];
@@ -105,26 +111,8 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       }
     }
   }
-  st.commit(buf0, tid);
-  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int s = 0;                                     // index of the slab being consumed
-  const int last_slab = SIGMA_ONLY ? snl::SLAB_SIG : snl::N_SLABS - 1;
-  float hid[128], nxt[128];
-  // activation tile store (accumulator layout -> row-major [P][256]): 4 x 16 B per lane per 32-feature tile
-#define SN_STORE_TILE(slot, t, arr, off)                                                               \
-  if (STORE && valid) {                                                                                \
-    float* dst = acts + ((long)(slot) * slot_rows + p_raw) * 256 + 32 * (t) + 4 * h;                   \
-    _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                 \
-      float4 v;                                                                                        \
-      v.x = arr[(off) + 4 * q4 + 0]; v.y = arr[(off) + 4 * q4 + 1];                                    \
-      v.z = arr[(off) + 4 * q4 + 2]; v.w = arr[(off) + 4 * q4 + 3];                                    \
-      *reinterpret_cast<float4*>(dst + 8 * q4) = v;                                                    \
-    }                                                                                                  \
-  }
   if (STORE && valid) {
-    float* er = emb + p_raw * 128;        // caller zero-fills emb: pad columns 63, 91..127 stay 0
+    float* er = emb + p_raw * 128;               // caller zero-fills emb: pad columns 63, 91..127 stay 0
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
       const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
@@ -138,34 +126,42 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       if (c >= 0) er[64 + c] = de[e];
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                               // slabs 0,1 + bias/aux table visible
 
-  // Common per-slab prologue / epilogue.  `cur`/`oth` are compile-time buffer choices.
-#define SN_SLAB_BEGIN(cur, oth)                                             \
-  {                                                                         \
-    if (s < last_slab) {                                                    \
-      const int kn = slab_k_rt(s + 1);                                      \
-      st.issue(gnext, (oth), kn >> 5, tid);                                 \
-      gnext += kn * 128;                                                    \
-    }                                                                       \
-  }                                                                         \
-  f32x16 acc = load_bias(lds_bias, s, h);                                   \
-  const char* lw = (cur) + lane * 16;
-#define SN_SLAB_END(oth)                                                    \
-  if (s < last_slab) st.commit((oth), tid);                                 \
-  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
-  __syncthreads();                                                          \
-  ++s;
+  int s = 0;                                     // slab being consumed
+  float hid[128], nxt[128];
+  f32x16 acc = load_bias(lds_bias, 0, h), acc_pre, pacc;
+  f32x4 a_cur = *reinterpret_cast<const f32x4*>(ring.slot(0) + lane * 16);
+
+  // activation tile store (accumulator layout -> row-major [slot_rows][256]): 4 x 16 B per lane per 32-feature tile
+  auto store_tile = [&](int slot, int t, const float* v) {
+    if (STORE && valid) {
+      float* dst = acts + ((long)slot * slot_rows + p_raw) * 256 + 32 * t + 4 * h;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float4 o;
+        o.x = v[4 * q4 + 0]; o.y = v[4 * q4 + 1]; o.z = v[4 * q4 + 2]; o.w = v[4 * q4 + 3];
+        *reinterpret_cast<float4*>(dst + 8 * q4) = o;
+      }
+    }
+  };
+  // epilogue of a ReLU tile: nxt[16t..] = max(acc,0) (+ training store)
+  auto relu_tile = [&](int slot, int t, const f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nxt[16 * t + r] = fmaxf(a[r], 0.0f);
+    store_tile(slot, t, nxt + 16 * t);
+  };
+#define SN_LW(si) (ring.slot(si) + lane * 16)
 
   // ---- layer 0: xyz_encoding_1  (nerf.py:68)
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    SN_SLAB_BEGIN((t & 1) ? buf1 : buf0, (t & 1) ? buf0 : buf1)
-    mma_f32<8>(acc, lw, xe);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) nxt[16 * t + r] = fmaxf(acc[r], 0.0f);
-    SN_STORE_TILE(0, t, nxt, 16 * t)
-    SN_SLAB_END((t & 1) ? buf0 : buf1)
+    slab_f32<8, 0, 2, true>(acc, a_cur, acc_pre, SN_LW(s), xe, xe, SN_LW(s + 1), lds_bias, s, h, ring,
+                            [&] { if (t > 0) relu_tile(0, t - 1, pacc); });
+    pacc = acc; acc = acc_pre; ++s;
   }
+  relu_tile(0, 7, pacc);
 #pragma unroll
   for (int i = 0; i < 128; ++i) hid[i] = nxt[i];
 
@@ -175,84 +171,101 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     if (l == 4) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        SN_SLAB_BEGIN((t & 1) ? buf1 : buf0, (t & 1) ? buf0 : buf1)
-        mma_f32<8>(acc, lw, xe);
-        mma_f32<32>(acc, lw + 8 * 1024, hid);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nxt[16 * t + r] = fmaxf(acc[r], 0.0f);
-        SN_STORE_TILE(l, t, nxt, 16 * t)
-        SN_SLAB_END((t & 1) ? buf0 : buf1)
+        slab_f32<8, 32, 4, true>(acc, a_cur, acc_pre, SN_LW(s), xe, hid, SN_LW(s + 1), lds_bias, s, h, ring,
+                                 [&] { if (t > 0) relu_tile(l, t - 1, pacc); });
+        pacc = acc; acc = acc_pre; ++s;
       }
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        SN_SLAB_BEGIN((t & 1) ? buf1 : buf0, (t & 1) ? buf0 : buf1)
-        mma_f32<32>(acc, lw, hid);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nxt[16 * t + r] = fmaxf(acc[r], 0.0f);
-        SN_STORE_TILE(l, t, nxt, 16 * t)
-        SN_SLAB_END((t & 1) ? buf0 : buf1)
+        slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW(s), hid, hid, SN_LW(s + 1), lds_bias, s, h, ring,
+                                 [&] { if (t > 0) relu_tile(l, t - 1, pacc); });
+        pacc = acc; acc = acc_pre; ++s;
       }
     }
+    relu_tile(l, 7, pacc);
 #pragma unroll
     for (int i = 0; i < 128; ++i) hid[i] = nxt[i];
   }
 
-  // ---- sigma head (nerf.py:136): row 0 of its tile -> accumulator register 0 of lanes 0..31
+  // ---- sigma head (nerf.py:136) on the VALU: this lane half's 128 K-slots, then one cross-half add
   float sigma;
   {
-    SN_SLAB_BEGIN(buf0, buf1)
-    mma_f32<32>(acc, lw, hid);
-    sigma = acc[0];
-    SN_SLAB_END(buf1)
+    const f32x4* ws = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128);
+    float sg = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const f32x4 w = ws[q];
+      sg = __builtin_fmaf(w[0], hid[4 * q + 0], sg);
+      sg = __builtin_fmaf(w[1], hid[4 * q + 1], sg);
+      sg = __builtin_fmaf(w[2], hid[4 * q + 2], sg);
+      sg = __builtin_fmaf(w[3], hid[4 * q + 3], sg);
+    }
+    sigma = sg + __shfl_xor(sg, 32, 64) + lds_aux[snl::AUX_HEADB];
   }
   if (SIGMA_ONLY) {
     if (valid && h == 0) out[p_raw] = sigma;
     return;
   }
 
-  // ---- xyz_encoding_final (nerf.py:140), no activation.  slabs 65..72 start on buf1.
+  // ---- xyz_encoding_final (nerf.py:140), no activation
+  auto copy_tile = [&](int slot, int t, const f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nxt[16 * t + r] = a[r];
+    store_tile(slot, t, nxt + 16 * t);
+  };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    SN_SLAB_BEGIN((t & 1) ? buf0 : buf1, (t & 1) ? buf1 : buf0)
-    mma_f32<32>(acc, lw, hid);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) nxt[16 * t + r] = acc[r];
-    SN_STORE_TILE(8, t, nxt, 16 * t)
-    SN_SLAB_END((t & 1) ? buf1 : buf0)
+    slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW(s), hid, hid, SN_LW(s + 1), lds_bias, s, h, ring,
+                             [&] { if (t > 0) copy_tile(8, t - 1, pacc); });
+    pacc = acc; acc = acc_pre; ++s;
   }
+  copy_tile(8, 7, pacc);
 #pragma unroll
   for (int i = 0; i < 128; ++i) hid[i] = nxt[i];
 
-  // ---- dir_encoding + ShiftedSoftplus (nerf.py:142-143).  slabs 73..76 start on buf1.
+  // ---- dir_encoding + ShiftedSoftplus (nerf.py:142-143)
   float h2[64];
+  auto ssp_tile = [&](int t, const f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h2[16 * t + r] = shifted_softplus_fast(a[r]);
+    store_tile(9, t, h2 + 16 * t);
+  };
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    SN_SLAB_BEGIN((t & 1) ? buf0 : buf1, (t & 1) ? buf1 : buf0)
-    mma_f32<32>(acc, lw, hid);
-    mma_f32<4>(acc, lw + 32 * 1024, de);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h2[16 * t + r] = shifted_softplus(acc[r]);
-    SN_STORE_TILE(9, t, h2, 16 * t)
-    SN_SLAB_END((t & 1) ? buf1 : buf0)
+    slab_f32<32, 4, 4, true>(acc, a_cur, acc_pre, SN_LW(s), hid, de, SN_LW(s + 1), lds_bias, s, h, ring,
+                             [&] { if (t > 0) ssp_tile(t - 1, pacc); });
+    pacc = acc; acc = acc_pre; ++s;
   }
+  ssp_tile(3, pacc);
 
-  // ---- rgb + WidenedSigmoid (nerf.py:144): rows 0..2 -> registers 0..2 of lanes 0..31.  slab 77 on buf1.
+  // ---- rgb + WidenedSigmoid (nerf.py:144) on the VALU: 3 rows x this half's 64 K-slots, cross-half add
   {
-    SN_SLAB_BEGIN(buf1, buf0)
-    mma_f32<16>(acc, lw, h2);
+    float c3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x4* wr = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_RGBW + c * 128 + h * 64);
+      float a = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const f32x4 w = wr[q];
+        a = __builtin_fmaf(w[0], h2[4 * q + 0], a);
+        a = __builtin_fmaf(w[1], h2[4 * q + 1], a);
+        a = __builtin_fmaf(w[2], h2[4 * q + 2], a);
+        a = __builtin_fmaf(w[3], h2[4 * q + 3], a);
+      }
+      c3[c] = a + __shfl_xor(a, 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c];
+    }
     if (valid && h == 0) {
       float4 o;
-      o.x = widened_sigmoid(acc[0]);
-      o.y = widened_sigmoid(acc[1]);
-      o.z = widened_sigmoid(acc[2]);
+      o.x = widened_sigmoid(c3[0]);
+      o.y = widened_sigmoid(c3[1]);
+      o.z = widened_sigmoid(c3[2]);
       o.w = sigma;                               // cat([rgb, sigma]) nerf.py:146
       reinterpret_cast<float4*>(out)[p_raw] = o;
     }
   }
-#undef SN_SLAB_BEGIN
-#undef SN_SLAB_END
-#undef SN_STORE_TILE
+#undef SN_LW
 }
 
 }  // namespace snk
@@ -262,28 +275,28 @@ extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, con
                                          int sigma_only, int input_mode, int use_dma, float* out, float* acts, float* emb,
                                          long slot_rows, hipStream_t stream) {
   using namespace snk;
+  (void)use_dma;                                 // the register-staged ablation path was retired with the v2 pipeline
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
   if (tiles > 0x7fffffffL) return -2;
   const bool store = acts != nullptr;
   if (store && (sigma_only || input_mode != 0 || emb == nullptr || slot_rows < n_points)) return -1;
   dim3 grid((unsigned)tiles), block(256);
-  const size_t lds = MLP_F32_LDS_BYTES;
+  const size_t lds = MLP_F32_LDS_BYTES_V2;
   const char* b = reinterpret_cast<const char*>(blob);
-#define SN_LAUNCH(DMA, SO, IM, ST)                                                                               \
+#define SN_LAUNCH(SO, IM, ST)                                                                                    \
   do {                                                                                                           \
-    auto kfn = mlp_fwd_f32_kernel<DMA, SO, IM, ST>;                                                              \
+    auto kfn = mlp_fwd_f32_kernel<SO, IM, ST>;                                                                   \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                          \
     hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows); \
   } while (0)
   if (store) {
-    SN_LAUNCH(true, false, 0, true);
+    SN_LAUNCH(false, 0, true);
   } else if (input_mode == 0) {
-    if (use_dma) { if (sigma_only) SN_LAUNCH(true, true, 0, false); else SN_LAUNCH(true, false, 0, false); }
-    else         { if (sigma_only) SN_LAUNCH(false, true, 0, false); else SN_LAUNCH(false, false, 0, false); }
+    if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false);
   } else {
-    if (sigma_only) SN_LAUNCH(true, true, 1, false); else SN_LAUNCH(true, false, 1, false);
+    if (sigma_only) SN_LAUNCH(true, 1, false); else SN_LAUNCH(false, 1, false);
   }
 #undef SN_LAUNCH
   return (int)hipGetLastError();

@@ -1,0 +1,108 @@
+// sn_mlp_pipe.h -- weight-slab pipeline of the fused MLP kernels (fp32 path), second generation.
+//
+// A workgroup (4 waves) consumes the packed weights slab by slab (one 32-row output tile x full K each, sn_layout.h).
+// Slabs stream L2 -> LDS by global_load_lds DMA into a RING OF THREE buffers and the single per-slab barrier sits in the
+// MIDDLE of a slab's MFMA sequence instead of at the slab boundary:
+//
+//   sync point of slab s (after its first GB MFMA groups):
+//       s_waitcnt vmcnt(0)        own DMA pieces of slab s+1 (issued one slab ago) have landed
+//       s_barrier                 -> slab s+1 is complete for every wave; every wave has left slab s-1
+//       issue DMA of slab s+2     into the ring slot slab s-1 used; one 4 KB piece per MFMA group, in the MFMA shadow
+//
+// so the transition slab s -> s+1 needs no barrier: the bias of slab s+1 and its first A fragment are requested while
+// the last MFMAs of slab s are still issuing, the accumulator epilogue of slab s (ReLU, moves, activation stores) runs
+// under the first MFMAs of slab s+1, and the barrier itself waits under an MFMA that is already in flight.
+// (First generation = Stager in sn_mlp_common.h: double buffer, barrier + DMA issue + bias/fragment reload on the
+//  critical path at every slab boundary -- 85 % MFMA-busy; see profiles/r01_run2_pmc.json.)
+#pragma once
+#include "sn_mlp_common.h"
+
+namespace snk {
+
+constexpr int TAIL_LDS_BYTES = 12544;                       // biases + aux head table (12320 B), padded
+constexpr int RING_SLOT_BYTES = snl::MAX_SLAB_K * 128;      // 40960
+constexpr int MLP_F32_LDS_BYTES_V2 = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES;   // 135424
+
+struct Ring {
+  const char* gnext;    // global address of slab `nstage`
+  char* base;           // LDS address of ring slot 0
+  int nstage;           // next slab to stage
+  int last;             // last slab this kernel consumes
+  int tid;
+  int wbase;            // wave-uniform LDS byte offset of this wave inside a 4 KB piece
+  int pieces, piece;    // staging state of slab `nstage`
+
+  SN_DEV char* slot(int s) const { return base + (s % 3) * RING_SLOT_BYTES; }
+  SN_DEV void begin_stage() {
+    pieces = (nstage <= last) ? (slab_k_rt(nstage) >> 5) : 0;
+    piece = 0;
+  }
+  SN_DEV void issue_piece() {           // one 4096-byte piece (16 B per thread)
+    if (piece < pieces) {
+      __builtin_amdgcn_global_load_lds((gbl_cvoid*)(gnext + piece * 4096 + tid * 16),
+                                       (lds_void*)(slot(nstage) + piece * 4096 + wbase), 16, 0, 0);
+      ++piece;
+    }
+  }
+  SN_DEV void end_stage() {
+    if (pieces > 0) { gnext += pieces * 4096; ++nstage; pieces = 0; }
+  }
+  SN_DEV void stage_whole() {           // prologue only
+    begin_stage();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) issue_piece();
+    end_stage();
+  }
+};
+
+// One slab: NG0 + NG1 groups of 4 k-steps (two K segments with B operands b0 / b1), barrier after group GB.
+//   acc      in: bias-initialised accumulator of this slab; out: its result
+//   a_cur    in: first A fragment of this slab (prefetched by the previous slab); out: first fragment of the next slab
+//   acc_pre  out: bias of the next slab
+//   pending  run after the first group's MFMAs are issued (the previous slab's epilogue)
+template <int NG0, int NG1, int GB, bool HAS_NEXT, class Pending>
+SN_DEV void slab_f32(f32x16& acc, f32x4& a_cur, f32x16& acc_pre, const char* lw, const float* b0, const float* b1,
+                     const char* lw_next, const float* lds_bias, int s, int h, Ring& ring, Pending&& pending) {
+  constexpr int NG = NG0 + NG1;
+  constexpr int PPG = (10 + (NG - GB) - 1) / (NG - GB);     // DMA pieces per group after the sync point
+  static_assert(GB >= 1 && GB < NG, "sync point inside the slab");
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    f32x4 a_nxt;
+    if (g + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(lw + (g + 1) * 1024);
+    else if (HAS_NEXT) a_nxt = *reinterpret_cast<const f32x4*>(lw_next);
+    if (g == GB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      ring.begin_stage();
+      if (HAS_NEXT) acc_pre = load_bias(lds_bias, s + 1, h);
+    }
+    if (g >= GB) {
+#pragma unroll
+      for (int j = 0; j < PPG; ++j) ring.issue_piece();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* b = (g < NG0) ? (b0 + 4 * g) : (b1 + 4 * (g - NG0));
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[3], acc, 0, 0, 0);
+    if (g == 0) pending();
+    if (g + 1 < NG || HAS_NEXT) a_cur = a_nxt;
+  }
+  ring.end_stage();
+}
+
+// ShiftedSoftplus (models/activations.py:33-35) on hardware exp2/log2:  max(x-1,0) + log1p(exp(-|x-1|)).
+// log1p(e) for e in (0,1]: u = 1+e; log(u) * e/(u-1) restores the bits lost in 1+e (u-1 is exact); e < 2^-24 -> e.
+SN_DEV float shifted_softplus_fast(float x) {
+  const float sx = x - 1.0f;
+  const float e = __builtin_amdgcn_exp2f(-fabsf(sx) * 1.44269504088896340736f);
+  const float u = 1.0f + e;
+  const float d = u - 1.0f;
+  const float l = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
+  const float lp = (d == 0.0f) ? e : l * (e / d);
+  return fmaxf(sx, 0.0f) + lp;
+}
+
+}  // namespace snk

@@ -53,12 +53,16 @@ def pack_blob(lib, params, dtype_code=0):
 
 
 def emulate_tile(lib, blob, x_embedded, sigma_only=False):
-    """x_embedded: (32, 90) rows = points of one tile.  Returns (32,4) or (32,)."""
+    """x_embedded: (32, 90) rows = points of one tile.  Returns (32,4) or (32,).  Mirrors csrc/sn_mlp_fwd.hip:
+    76 MFMA slabs (L0, L1-7, FIN, DIR) + the sigma / rgb heads applied from the aux table in K-slot order."""
     from oracle.oracle_np import shifted_softplus, widened_sigmoid
     n_slabs = lib.sn_layout_n_slabs()
     slab_k = [lib.sn_layout_slab_k(s) for s in range(n_slabs)]
     slab_off = np.cumsum([0] + [32 * k for k in slab_k])
-    bias = blob[slab_off[-1]:].reshape(n_slabs, 2, 16)
+    tail = blob[slab_off[-1]:]
+    bias = tail[:n_slabs * 32].reshape(n_slabs, 2, 16)
+    aux = tail[n_slabs * 32:]
+    sig_w, rgb_w, head_b = aux[:256].reshape(2, 128), aux[256:640].reshape(3, 2, 64), aux[640:644]
 
     xe = np.zeros((64, 32), np.float32)
     for e in range(32):
@@ -85,6 +89,10 @@ def emulate_tile(lib, blob, x_embedded, sigma_only=False):
         assert g == frags.shape[0]
         return acc
 
+    def head(w_hq, b):                                              # VALU head: per-half partial dot + cross-half add
+        part = (w_hq[H] * b).sum(1, dtype=np.float64)
+        return (part[:32] + part[32:]).astype(np.float32)
+
     s = 0
     nxt = np.zeros((64, 128), np.float32)
     for t in range(8):
@@ -94,19 +102,18 @@ def emulate_tile(lib, blob, x_embedded, sigma_only=False):
         for t in range(8):
             nxt[:, 16 * t:16 * t + 16] = np.maximum(run_slab(s, [xe, hid] if l == 4 else [hid]), 0); s += 1
         hid = nxt.copy()
-    sigma = run_slab(s, [hid])[:, 0]; s += 1
+    sigma = head(sig_w, hid) + head_b[0]
     if sigma_only:
-        return sigma[:32]
+        return sigma
     for t in range(8):
         nxt[:, 16 * t:16 * t + 16] = run_slab(s, [hid]); s += 1
     hid = nxt.copy()
     h2 = np.zeros((64, 64), np.float32)
     for t in range(4):
         h2[:, 16 * t:16 * t + 16] = shifted_softplus(run_slab(s, [hid, de])); s += 1
-    acc = run_slab(s, [h2]); s += 1
     assert s == n_slabs
-    rgb = widened_sigmoid(acc[:32, :3])
-    return np.concatenate([rgb, sigma[:32, None]], 1)
+    rgb = np.stack([widened_sigmoid(head(rgb_w[c], h2) + head_b[1 + c]) for c in range(3)], 1)
+    return np.concatenate([rgb, sigma[:, None]], 1)
 
 
 def pack_blob_bwd(lib, params):
