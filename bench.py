@@ -104,6 +104,17 @@ def main():
         flop_fine = FLOP_PER_POINT * n_rays * (NS + NI)
         achieved = flop_fine / (ms_fine * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        # HBM bytes of the same launch from the rocprofv3 PMC passes of this command (FETCH_SIZE x2 gfx950 correction +
+        # WRITE_SIZE, tools/summarize_prof.py); PMC cannot be sampled from inside the process, so the committed summary
+        # is quoted when it matches this workload, else null.
+        traffic, traffic_note = None, "no PMC summary for this workload"
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+            if tj.get("points") == n_rays * (NS + NI) and args.dtype == "fp32":
+                traffic = tj["hbm_bytes"]
+                traffic_note = "bytes/launch from %s (algorithmic %d)" % (tj["source"], tj["algorithmic_bytes"])
+        except Exception:
+            pass
         res = {
             "metric": "rendered rays/sec (64+%d samples), lego %dx%d" % (NI, W, H),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -114,12 +125,37 @@ def main():
                                    % (W, H, n_rays, NI),
                        "rays_per_step_per_gpu": n_rays, "points_per_ray": NS + NS + NI, "parallelism": "rays sharded x%d, no collective" % world},
             "roofline": {"bound": "mfma", "kernel": "mlp_fwd_%s_kernel (fine pass, %d points/launch)" % ("f32" if args.dtype == "fp32" else "bf16", n_rays * (NS + NI)),
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "flop_per_launch": flop_fine, "avg_launch_ms": ms_fine,
                          "coarse_launch_ms": ms_coarse,
                          "mlp_share_of_step": (ms_fine + ms_coarse) / (dt / args.steps * 1e3)},
             "roofline_rays_per_s_per_gpu": peak * 1e12 / (FLOP_PER_POINT * (NS + NS + NI)),
         }
+        if world == 1 and args.dtype == "fp32":
+            # secondary figure: one optimisation-shaped step (fwd+bwd of render_rays, 4096 rays, perturb=1, noise_std=1)
+            try:
+                for m in models:
+                    m.train()
+                tr = rays[:: n_rays // 4096][:4096].contiguous()
+                tgt = torch.rand((4096, 3), device=dev)
+
+                def tstep():
+                    for m in models:
+                        m.zero_grad(set_to_none=True)
+                    r = rendering.render_rays(models, emb, tr, NS, False, 1.0, 1.0, NI, 32768, True)
+                    (((r["rgb_fine"] - tgt) ** 2).mean() + ((r["rgb_coarse"] - tgt) ** 2).mean()).backward()
+                tstep(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    tstep()
+                torch.cuda.synchronize()
+                tdt = (time.perf_counter() - t1) / 3
+                tflop = 3489024 * 4096 * (NS + NS + NI) / tdt / 1e12
+                res["train_step"] = {"rays": 4096, "ms": tdt * 1e3, "rays_per_s": 4096 / tdt, "achieved_tflops": tflop,
+                                     "frac_of_fp32_mfma_peak": tflop / peak}
+            except Exception as e:                      # noqa: BLE001
+                res["train_step"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             ncpu = os.cpu_count() or 1
             sample = rays_np[:: max(1, n_rays // args.cpu_rays)][:args.cpu_rays]

@@ -62,15 +62,17 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   const int wave = tid >> 6;
   const int j = lane & 31;
   const int h = lane >> 5;
-  const long p_raw = ((long)blockIdx.x * 4 + wave) * 32 + j;
-  const bool valid = p_raw < P;
-  const long p = valid ? p_raw : P - 1;
+  const long n_tiles = (P + 127) / 128;
+  const long my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;     // persistent: tiles b, b+grid, ...
 
   Ring ring;
+  ring.blob = blob;
   ring.gnext = blob;
   ring.base = smem + TAIL_LDS_BYTES;
-  ring.nstage = 0;
-  ring.last = SIGMA_ONLY ? (snl::SLAB_FIN - 1) : (snl::N_SLABS - 1);
+  ring.n_used = SIGMA_ONLY ? snl::SLAB_FIN : snl::N_SLABS;
+  ring.stage_id = 0;
+  ring.stage_slot = 0;
+  ring.remaining = my_tiles * ring.n_used;
   ring.tid = tid;
   ring.wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
   ring.pieces = 0; ring.piece = 0;
@@ -81,8 +83,20 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     float4* lb = reinterpret_cast<float4*>(lds_bias);
     for (int i = tid; i < snl::TAIL_FLOATS / 4; i += 256) lb[i] = gb[i];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                               // slabs 0,1 + bias/aux table visible
 
-  float xe[32], de[16];
+  int cslot = 0;                                 // ring slot of the slab being consumed
+  f32x4 a_cur = *reinterpret_cast<const f32x4*>(ring.slot(0) + lane * 16);
+  f32x16 acc = load_bias(lds_bias, 0, h);
+  const int n_used = ring.n_used;
+
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const long p_raw = (tile * 4 + wave) * 32 + j;
+  const bool valid = p_raw < P;
+  const long p = valid ? p_raw : P - 1;
+
+  float xe[32];
   if (INPUT_MODE == 0) {
     const long ray = p / S;
     const float* rp = in0 + ray * 8;
@@ -93,7 +107,6 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     const float y = __fadd_rn(oy, __fmul_rn(dy, zz));
     const float z = __fadd_rn(oz, __fmul_rn(dz, zz));
     embed_xyz(x, y, z, h, xe);
-    if (!SIGMA_ONLY) embed_dir(dx, dy, dz, h, de);
   } else {
     const float* row = in0 + p * (long)S;        // S = leading dimension here
 #pragma unroll
@@ -101,14 +114,6 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
       const int c = h ? c1 : c0;
       xe[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
-    }
-    if (!SIGMA_ONLY) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
-        const int c = h ? c1 : c0;
-        de[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
-      }
     }
   }
   if (STORE && valid) {
@@ -119,20 +124,11 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       const int c = h ? c1 : c0;
       if (c >= 0) er[c] = xe[e];
     }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
-      const int c = h ? c1 : c0;
-      if (c >= 0) er[64 + c] = de[e];
-    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                               // slabs 0,1 + bias/aux table visible
 
-  int s = 0;                                     // slab being consumed
+  int s = 0;                                     // slab id being consumed
   float hid[128], nxt[128];
-  f32x16 acc = load_bias(lds_bias, 0, h), acc_pre, pacc;
-  f32x4 a_cur = *reinterpret_cast<const f32x4*>(ring.slot(0) + lane * 16);
+  f32x16 pacc, acc_pre;
 
   // activation tile store (accumulator layout -> row-major [slot_rows][256]): 4 x 16 B per lane per 32-feature tile
   auto store_tile = [&](int slot, int t, const float* v) {
@@ -149,17 +145,23 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   // epilogue of a ReLU tile: nxt[16t..] = max(acc,0) (+ training store)
   auto relu_tile = [&](int slot, int t, const f32x16& a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) nxt[16 * t + r] = fmaxf(a[r], 0.0f);
+    for (int r = 0; r < 16; ++r) {
+      float v = fmaxf(a[r], 0.0f);
+      asm volatile("" : "+v"(v));                // pin: keeps the epilogue where it is written (register pressure)
+      nxt[16 * t + r] = v;
+    }
     store_tile(slot, t, nxt + 16 * t);
   };
-#define SN_LW(si) (ring.slot(si) + lane * 16)
+#define SN_LW_CUR (ring.slot(cslot) + lane * 16)
+#define SN_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
+#define SN_ADVANCE() do { pacc = acc; acc = acc_pre; ++s; cslot = (cslot == 2) ? 0 : cslot + 1; } while (0)
 
   // ---- layer 0: xyz_encoding_1  (nerf.py:68)
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    slab_f32<8, 0, 2, true>(acc, a_cur, acc_pre, SN_LW(s), xe, xe, SN_LW(s + 1), lds_bias, s, h, ring,
+    slab_f32<8, 0, 2, true>(acc, a_cur, acc_pre, SN_LW_CUR, xe, xe, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
                             [&] { if (t > 0) relu_tile(0, t - 1, pacc); });
-    pacc = acc; acc = acc_pre; ++s;
+    SN_ADVANCE();
   }
   relu_tile(0, 7, pacc);
 #pragma unroll
@@ -171,16 +173,16 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     if (l == 4) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        slab_f32<8, 32, 4, true>(acc, a_cur, acc_pre, SN_LW(s), xe, hid, SN_LW(s + 1), lds_bias, s, h, ring,
+        slab_f32<8, 32, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, xe, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
                                  [&] { if (t > 0) relu_tile(l, t - 1, pacc); });
-        pacc = acc; acc = acc_pre; ++s;
+        SN_ADVANCE();
       }
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW(s), hid, hid, SN_LW(s + 1), lds_bias, s, h, ring,
+        slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
                                  [&] { if (t > 0) relu_tile(l, t - 1, pacc); });
-        pacc = acc; acc = acc_pre; ++s;
+        SN_ADVANCE();
       }
     }
     relu_tile(l, 7, pacc);
@@ -205,26 +207,53 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   }
   if (SIGMA_ONLY) {
     if (valid && h == 0) out[p_raw] = sigma;
-    return;
+    continue;
   }
 
   // ---- xyz_encoding_final (nerf.py:140), no activation
   auto copy_tile = [&](int slot, int t, const f32x16& a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) nxt[16 * t + r] = a[r];
+    for (int r = 0; r < 16; ++r) {
+      float v = a[r];
+      asm volatile("" : "+v"(v));
+      nxt[16 * t + r] = v;
+    }
     store_tile(slot, t, nxt + 16 * t);
   };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW(s), hid, hid, SN_LW(s + 1), lds_bias, s, h, ring,
+    slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
                              [&] { if (t > 0) copy_tile(8, t - 1, pacc); });
-    pacc = acc; acc = acc_pre; ++s;
+    SN_ADVANCE();
   }
   copy_tile(8, 7, pacc);
 #pragma unroll
   for (int i = 0; i < 128; ++i) hid[i] = nxt[i];
 
-  // ---- dir_encoding + ShiftedSoftplus (nerf.py:142-143)
+  // ---- dir_encoding + ShiftedSoftplus (nerf.py:142-143).  The 32-slot direction embedding is built here, not in the
+  // prologue, so that it does not occupy 16 registers through the trunk.
+  float de[16];
+  if (INPUT_MODE == 0) {
+    const float* rp = in0 + (p / S) * 8;
+    embed_dir(rp[3], rp[4], rp[5], h, de);
+  } else {
+    const float* row = in0 + p * (long)S;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
+      const int c = h ? c1 : c0;
+      de[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
+    }
+  }
+  if (STORE && valid) {
+    float* er = emb + p_raw * 128;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
+      const int c = h ? c1 : c0;
+      if (c >= 0) er[64 + c] = de[e];
+    }
+  }
   float h2[64];
   auto ssp_tile = [&](int t, const f32x16& a) {
 #pragma unroll
@@ -233,9 +262,9 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   };
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    slab_f32<32, 4, 4, true>(acc, a_cur, acc_pre, SN_LW(s), hid, de, SN_LW(s + 1), lds_bias, s, h, ring,
+    slab_f32<32, 4, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, de, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
                              [&] { if (t > 0) ssp_tile(t - 1, pacc); });
-    pacc = acc; acc = acc_pre; ++s;
+    SN_ADVANCE();
   }
   ssp_tile(3, pacc);
 
@@ -265,7 +294,11 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       reinterpret_cast<float4*>(out)[p_raw] = o;
     }
   }
-#undef SN_LW
+  }  // persistent tile loop
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing may still be landing in LDS when the workgroup retires
+#undef SN_LW_CUR
+#undef SN_LW_NEXT
+#undef SN_ADVANCE
 }
 
 }  // namespace snk
@@ -278,10 +311,12 @@ extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, con
   (void)use_dma;                                 // the register-staged ablation path was retired with the v2 pipeline
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
-  if (tiles > 0x7fffffffL) return -2;
   const bool store = acts != nullptr;
   if (store && (sigma_only || input_mode != 0 || emb == nullptr || slot_rows < n_points)) return -1;
-  dim3 grid((unsigned)tiles), block(256);
+  // persistent launch: one workgroup per CU (the 135 KB LDS ring admits exactly one), each walks tiles b, b+grid, ...
+  int dev = 0, n_cu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
   const size_t lds = MLP_F32_LDS_BYTES_V2;
   const char* b = reinterpret_cast<const char*>(blob);
 #define SN_LAUNCH(SO, IM, ST)                                                                                    \

@@ -9,7 +9,9 @@
 //       s_barrier                 -> slab s+1 is complete for every wave; every wave has left slab s-1
 //       issue DMA of slab s+2     into the ring slot slab s-1 used; one 4 KB piece per MFMA group, in the MFMA shadow
 //
-// so the transition slab s -> s+1 needs no barrier: the bias of slab s+1 and its first A fragment are requested while
+// The kernels are PERSISTENT (one workgroup per CU walks its point tiles): the weight stream simply wraps around from the
+// last slab of a tile to slab 0 of the next, so the ring never drains and there is no per-tile launch / prologue bubble.
+// The transition slab s -> s+1 needs no barrier: the bias of slab s+1 and its first A fragment are requested while
 // the last MFMAs of slab s are still issuing, the accumulator epilogue of slab s (ReLU, moves, activation stores) runs
 // under the first MFMAs of slab s+1, and the barrier itself waits under an MFMA that is already in flight.
 // (First generation = Stager in sn_mlp_common.h: double buffer, barrier + DMA issue + bias/fragment reload on the
@@ -24,28 +26,37 @@ constexpr int RING_SLOT_BYTES = snl::MAX_SLAB_K * 128;      // 40960
 constexpr int MLP_F32_LDS_BYTES_V2 = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES;   // 135424
 
 struct Ring {
-  const char* gnext;    // global address of slab `nstage`
+  const char* blob;     // packed weights (slab 0)
+  const char* gnext;    // global address of the next slab to stage
   char* base;           // LDS address of ring slot 0
-  int nstage;           // next slab to stage
-  int last;             // last slab this kernel consumes
+  int n_used;           // slabs per point tile consumed by this kernel (76, or 64 for sigma_only)
+  int stage_id;         // id (0..n_used-1) of the next slab to stage
+  int stage_slot;       // ring slot (0..2) it goes to
+  long remaining;       // slabs still to stage over the whole life of this (persistent) workgroup
   int tid;
   int wbase;            // wave-uniform LDS byte offset of this wave inside a 4 KB piece
-  int pieces, piece;    // staging state of slab `nstage`
+  int pieces, piece;    // staging state of the slab being staged
 
-  SN_DEV char* slot(int s) const { return base + (s % 3) * RING_SLOT_BYTES; }
+  SN_DEV char* slot(int k) const { return base + k * RING_SLOT_BYTES; }
   SN_DEV void begin_stage() {
-    pieces = (nstage <= last) ? (slab_k_rt(nstage) >> 5) : 0;
+    pieces = (remaining > 0) ? (slab_k_rt(stage_id) >> 5) : 0;
     piece = 0;
   }
   SN_DEV void issue_piece() {           // one 4096-byte piece (16 B per thread)
     if (piece < pieces) {
       __builtin_amdgcn_global_load_lds((gbl_cvoid*)(gnext + piece * 4096 + tid * 16),
-                                       (lds_void*)(slot(nstage) + piece * 4096 + wbase), 16, 0, 0);
+                                       (lds_void*)(slot(stage_slot) + piece * 4096 + wbase), 16, 0, 0);
       ++piece;
     }
   }
   SN_DEV void end_stage() {
-    if (pieces > 0) { gnext += pieces * 4096; ++nstage; pieces = 0; }
+    if (pieces > 0) {
+      gnext += pieces * 4096;
+      --remaining;
+      stage_slot = (stage_slot == 2) ? 0 : stage_slot + 1;
+      if (++stage_id == n_used) { stage_id = 0; gnext = blob; }    // next point tile: the weight stream wraps around
+      pieces = 0;
+    }
   }
   SN_DEV void stage_whole() {           // prologue only
     begin_stage();
@@ -56,13 +67,16 @@ struct Ring {
 };
 
 // One slab: NG0 + NG1 groups of 4 k-steps (two K segments with B operands b0 / b1), barrier after group GB.
-//   acc      in: bias-initialised accumulator of this slab; out: its result
+//   acc      in: bias-initialised accumulator of this slab; out: its result (bias + W.x)
 //   a_cur    in: first A fragment of this slab (prefetched by the previous slab); out: first fragment of the next slab
-//   acc_pre  out: bias of the next slab
+//   acc_pre  out: bias of slab s_next (requested right after the sync point, consumed by the next slab)
 //   pending  run after the first group's MFMAs are issued (the previous slab's epilogue)
+// One dependent accumulator chain: measured on MI355X (tools/ubench/mfma_chain.hip) a dependent v_mfma_f32_32x32x2 chain
+// with a ds_read_b128 + s_waitcnt every 4 MFMAs and a barrier every 32 sustains 152 TF from one wave per SIMD, the same as
+// two interleaved chains -- so no second accumulator is spent.
 template <int NG0, int NG1, int GB, bool HAS_NEXT, class Pending>
 SN_DEV void slab_f32(f32x16& acc, f32x4& a_cur, f32x16& acc_pre, const char* lw, const float* b0, const float* b1,
-                     const char* lw_next, const float* lds_bias, int s, int h, Ring& ring, Pending&& pending) {
+                     const char* lw_next, const float* lds_bias, int s_next, int h, Ring& ring, Pending&& pending) {
   constexpr int NG = NG0 + NG1;
   constexpr int PPG = (10 + (NG - GB) - 1) / (NG - GB);     // DMA pieces per group after the sync point
   static_assert(GB >= 1 && GB < NG, "sync point inside the slab");
@@ -75,7 +89,7 @@ SN_DEV void slab_f32(f32x16& acc, f32x4& a_cur, f32x16& acc_pre, const char* lw,
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       ring.begin_stage();
-      if (HAS_NEXT) acc_pre = load_bias(lds_bias, s + 1, h);
+      if (HAS_NEXT) acc_pre = load_bias(lds_bias, s_next, h);
     }
     if (g >= GB) {
 #pragma unroll
