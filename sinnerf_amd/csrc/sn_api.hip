@@ -10,6 +10,8 @@ int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* i
 int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
+int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                               int sigma_only, int input_mode, float* out, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
                                  const float* g_depth, const float* g_w, float* g_raw, hipStream_t stream);
@@ -118,6 +120,9 @@ int sn_sample_coarse(const float* rays, long n_rays, int n_samples, int use_disp
 int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                    int sigma_only, int flags, float* out, void* stream) {
   if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  if (dtype == SN_DTYPE_BF16)
+    return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out,
+                                      (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
                                    (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
@@ -156,6 +161,8 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
                             int flags, float* out, void* stream) {
   if (!blob || !x || !out || n_rows < 0) return SN_E_BADARG;
   if (ld < (sigma_only ? 63 : 90)) return SN_E_BADSHAPE;
+  if (dtype == SN_DTYPE_BF16)
+    return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1,
                                    out, nullptr, nullptr, 0, (hipStream_t)stream);

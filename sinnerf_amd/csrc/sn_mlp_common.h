@@ -74,4 +74,32 @@ SN_DEV f32x16 load_bias(const float* lds_bias, int s, int h) {
   return acc;
 }
 
+// Slots this lane half computes for the first layer / skip layer (sn_layout.h: xyz_slot_col).
+SN_DEV void embed_xyz(float x, float y, float z, int h, float* xe) {
+  const Rev2 px = to_revolutions(x), py = to_revolutions(y), pz = to_revolutions(z);
+  const float hs = h ? 32.0f : 1.0f;            // bands 5..9 on the upper lane half
+#pragma unroll
+  for (int p = 0; p < 15; ++p) {
+    const Rev2 pc = (p % 3 == 0) ? px : (p % 3 == 1) ? py : pz;
+    const float scale = hs * (float)(1 << (p / 3));
+    sincos_rev(pc, scale, xe[2 * p], xe[2 * p + 1]);
+  }
+  xe[30] = h ? z : x;
+  xe[31] = h ? 0.0f : y;
+}
+SN_DEV void embed_dir(float x, float y, float z, int h, float* de) {
+  const Rev2 px = to_revolutions(x), py = to_revolutions(y), pz = to_revolutions(z);
+  const float hs = h ? 4.0f : 1.0f;             // bands 2,3 on the upper lane half
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    const Rev2 pc = (p % 3 == 0) ? px : (p % 3 == 1) ? py : pz;
+    const float scale = hs * (float)(1 << (p / 3));
+    sincos_rev(pc, scale, de[2 * p], de[2 * p + 1]);
+  }
+  de[12] = h ? z : x;
+  de[13] = h ? 0.0f : y;
+  de[14] = 0.0f;
+  de[15] = 0.0f;
+}
+
 }  // namespace snk

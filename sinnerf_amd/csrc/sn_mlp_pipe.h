@@ -25,7 +25,8 @@ constexpr int TAIL_LDS_BYTES = 12544;                       // biases + aux head
 constexpr int RING_SLOT_BYTES = snl::MAX_SLAB_K * 128;      // 40960
 constexpr int MLP_F32_LDS_BYTES_V2 = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES;   // 135424
 
-struct Ring {
+template <int BYTES_PER_K, int SLOT_BYTES>
+struct RingT {
   const char* blob;     // packed weights (slab 0)
   const char* gnext;    // global address of the next slab to stage
   char* base;           // LDS address of ring slot 0
@@ -35,23 +36,26 @@ struct Ring {
   long remaining;       // slabs still to stage over the whole life of this (persistent) workgroup
   int tid;
   int wbase;            // wave-uniform LDS byte offset of this wave inside a 4 KB piece
-  int pieces, piece;    // staging state of the slab being staged
+  int pieces, piece;    // staging state of the slab being staged (pieces of 4096 B, the last one may be partial)
+  int slab_bytes;
 
-  SN_DEV char* slot(int k) const { return base + k * RING_SLOT_BYTES; }
+  SN_DEV char* slot(int k) const { return base + k * SLOT_BYTES; }
   SN_DEV void begin_stage() {
-    pieces = (remaining > 0) ? (slab_k_rt(stage_id) >> 5) : 0;
+    slab_bytes = slab_k_rt(stage_id) * BYTES_PER_K;
+    pieces = (remaining > 0) ? ((slab_bytes + 4095) >> 12) : 0;
     piece = 0;
   }
   SN_DEV void issue_piece() {           // one 4096-byte piece (16 B per thread)
     if (piece < pieces) {
-      __builtin_amdgcn_global_load_lds((gbl_cvoid*)(gnext + piece * 4096 + tid * 16),
-                                       (lds_void*)(slot(stage_slot) + piece * 4096 + wbase), 16, 0, 0);
+      if ((BYTES_PER_K * 32) % 4096 == 0 || piece * 4096 + wbase < slab_bytes)     // wave-uniform (1 KB per wave)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(gnext + piece * 4096 + tid * 16),
+                                         (lds_void*)(slot(stage_slot) + piece * 4096 + wbase), 16, 0, 0);
       ++piece;
     }
   }
   SN_DEV void end_stage() {
     if (pieces > 0) {
-      gnext += pieces * 4096;
+      gnext += slab_bytes;
       --remaining;
       stage_slot = (stage_slot == 2) ? 0 : stage_slot + 1;
       if (++stage_id == n_used) { stage_id = 0; gnext = blob; }    // next point tile: the weight stream wraps around
@@ -65,6 +69,7 @@ struct Ring {
     end_stage();
   }
 };
+typedef RingT<128, RING_SLOT_BYTES> Ring;          // fp32 weights: 128 B per K per 32-row tile
 
 // One slab: NG0 + NG1 groups of 4 k-steps (two K segments with B operands b0 / b1), barrier after group GB.
 //   acc      in: bias-initialised accumulator of this slab; out: its result (bias + W.x)
