@@ -118,9 +118,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   auto relu_tile = [&](int slot, int t, const f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = fmaxf(a[r], 0.0f);
-      asm volatile("" : "+v"(v));                // pin: keeps the epilogue where it is written (register pressure)
-      nxt[16 * t + r] = v;
+      nxt[16 * t + r] = relu1(a[r]);           // one v_max_f32; the asm also pins the epilogue where it is written
     }
     store_tile(slot, t, nxt + 16 * t);
   };

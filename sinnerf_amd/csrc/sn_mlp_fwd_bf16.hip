@@ -32,18 +32,24 @@ SN_DEV bf16x8 pack8(const float* v) {
 }
 
 // One slab: NK0 + NK1 k-steps (two K segments, B operands b0 / b1 laid out [k-step][PT]), barrier after k-step GB.
-template <int NK0, int NK1, int GB, class Pending>
-SN_DEV void slab_bf16(f32x16 (&acc)[PT], bf16x8& a_cur, f32x16& acc_pre, const char* lw, const bf16x8* b0,
+//   af       4-entry ring of A fragments, prefetch distance 3 k-steps (a bf16 k-step is only 2 x 32 MFMA cycles, one step
+//            of lookahead does not cover the LDS latency).  Invariant at entry: fragments of k-steps 0,1,2 of this slab
+//            sit in af[(PHASE+0..2) & 3]; at exit the same holds for the next slab with PHASE' = (PHASE + NK) & 3
+//            (NK % 4 == 0 everywhere except the four dir_encoding slabs, whose phases 0,2,0,2 are still static).
+template <int NK0, int NK1, int GB, int PHASE, class Pending>
+SN_DEV void slab_bf16(f32x16 (&acc)[PT], bf16x8 (&af)[4], f32x16& acc_pre, const char* lw, const bf16x8* b0,
                       const bf16x8* b1, const char* lw_next, const float* lds_bias, int s_next, int h, RingB& ring,
                       Pending&& pending) {
   constexpr int NK = NK0 + NK1;
   constexpr int PPG = (5 + (NK - GB) - 1) / (NK - GB);      // <= 5 pieces of 4 KB per slab (K = 320)
-  static_assert(GB >= 1 && GB < NK, "sync point inside the slab");
+  static_assert(GB >= 1 && GB < NK && NK >= 4, "sync point inside the slab");
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
-    bf16x8 a_nxt;
-    if (ks + 1 < NK) a_nxt = *reinterpret_cast<const bf16x8*>(lw + (ks + 1) * 1024);
-    else a_nxt = *reinterpret_cast<const bf16x8*>(lw_next);
+    {
+      const int kn = ks + 3;
+      af[(PHASE + kn) & 3] = (kn < NK) ? *reinterpret_cast<const bf16x8*>(lw + kn * 1024)
+                                       : *reinterpret_cast<const bf16x8*>(lw_next + (kn - NK) * 1024);
+    }
     if (ks == GB) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -56,10 +62,10 @@ SN_DEV void slab_bf16(f32x16 (&acc)[PT], bf16x8& a_cur, f32x16& acc_pre, const c
     }
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8* b = (ks < NK0) ? (b0 + ks * PT) : (b1 + (ks - NK0) * PT);
+    const bf16x8 a_cur = af[(PHASE + ks) & 3];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur, b[pt], acc[pt], 0, 0, 0);
     if (ks == 0) pending();
-    a_cur = a_nxt;
   }
   ring.end_stage();
 }
@@ -103,7 +109,9 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   __syncthreads();
 
   int cslot = 0;
-  bf16x8 a_cur = *reinterpret_cast<const bf16x8*>(ring.slot(0) + lane * 16);
+  bf16x8 af[4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ring.slot(0) + lane * 16 + i * 1024);
   f32x16 acc_pre = load_bias(lds_bias, 0, h);
   const int n_used = ring.n_used;
 
@@ -152,7 +160,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       for (int pt = 0; pt < PT; ++pt) {
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(pacc[pt][r], 0.0f);
+        for (int r = 0; r < 16; ++r) v[r] = relu1(pacc[pt][r]);
         if (with_sigma) {
           const f32x4* ws = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t);
 #pragma unroll
@@ -180,7 +188,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     // ---- layer 0
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      slab_bf16<4, 0, 1>(acc, a_cur, acc_pre, SNB_LW_CUR, xe, xe, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
+      slab_bf16<4, 0, 1, 0>(acc, af, acc_pre, SNB_LW_CUR, xe, xe, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
                          [&] { if (t > 0) relu_tile(t - 1, false); });
       SNB_ADVANCE();
     }
@@ -195,14 +203,14 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       if (l == 4) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          slab_bf16<4, 16, 2>(acc, a_cur, acc_pre, SNB_LW_CUR, xe, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
+          slab_bf16<4, 16, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, xe, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
                               [&] { if (t > 0) relu_tile(t - 1, false); });
           SNB_ADVANCE();
         }
       } else {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          slab_bf16<16, 0, 2>(acc, a_cur, acc_pre, SNB_LW_CUR, hid, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
+          slab_bf16<16, 0, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, hid, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
                               [&] { if (t > 0) relu_tile(t - 1, ws); });
           SNB_ADVANCE();
         }
@@ -235,7 +243,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     };
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      slab_bf16<16, 0, 2>(acc, a_cur, acc_pre, SNB_LW_CUR, hid, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
+      slab_bf16<16, 0, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, hid, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
                           [&] { if (t > 0) copy_tile(t - 1); });
       SNB_ADVANCE();
     }
@@ -286,12 +294,15 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         }
       }
     };
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      slab_bf16<16, 2, 2>(acc, a_cur, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
-                          [&] { if (t > 0) ssp_tile(t - 1); });
-      SNB_ADVANCE();
-    }
+    // 18 k-steps per slab: the fragment-ring phase alternates 0,2,0,2 (static)
+    slab_bf16<16, 2, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring, [&] {});
+    SNB_ADVANCE();
+    slab_bf16<16, 2, 2, 2>(acc, af, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring, [&] { ssp_tile(0); });
+    SNB_ADVANCE();
+    slab_bf16<16, 2, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring, [&] { ssp_tile(1); });
+    SNB_ADVANCE();
+    slab_bf16<16, 2, 2, 2>(acc, af, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring, [&] { ssp_tile(2); });
+    SNB_ADVANCE();
     ssp_tile(3);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {

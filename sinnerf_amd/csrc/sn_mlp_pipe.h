@@ -38,18 +38,22 @@ struct RingT {
   int wbase;            // wave-uniform LDS byte offset of this wave inside a 4 KB piece
   int pieces, piece;    // staging state of the slab being staged (pieces of 4096 B, the last one may be partial)
   int slab_bytes;
+  const char* gp;       // per-lane global source of the next piece
+  char* lp;             // wave-uniform LDS destination of the next piece
 
   SN_DEV char* slot(int k) const { return base + k * SLOT_BYTES; }
   SN_DEV void begin_stage() {
     slab_bytes = slab_k_rt(stage_id) * BYTES_PER_K;
     pieces = (remaining > 0) ? ((slab_bytes + 4095) >> 12) : 0;
     piece = 0;
+    gp = gnext + tid * 16;
+    lp = slot(stage_slot) + wbase;
   }
   SN_DEV void issue_piece() {           // one 4096-byte piece (16 B per thread)
     if (piece < pieces) {
       if ((BYTES_PER_K * 32) % 4096 == 0 || piece * 4096 + wbase < slab_bytes)     // wave-uniform (1 KB per wave)
-        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(gnext + piece * 4096 + tid * 16),
-                                         (lds_void*)(slot(stage_slot) + piece * 4096 + wbase), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)gp, (lds_void*)lp, 16, 0, 0);
+      gp += 4096; lp += 4096;
       ++piece;
     }
   }
@@ -110,6 +114,14 @@ SN_DEV void slab_f32(f32x16& acc, f32x4& a_cur, f32x16& acc_pre, const char* lw,
     if (g + 1 < NG || HAS_NEXT) a_cur = a_nxt;
   }
   ring.end_stage();
+}
+
+// ReLU as ONE v_max_f32 (fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max first: 2 VALU per value, and
+// the epilogues of the bf16 path are VALU-issue-bound).
+SN_DEV float relu1(float x) {
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
 }
 
 // ShiftedSoftplus (models/activations.py:33-35) on hardware exp2/log2:  max(x-1,0) + log1p(exp(-|x-1|)).
