@@ -56,7 +56,7 @@ SN_DEV void slab_bf16(f32x16 (&acc)[PT], bf16x8 (&af)[4], f32x16& acc_pre, const
       ring.begin_stage();
       acc_pre = load_bias(lds_bias, s_next, h);
     }
-    if (ks >= GB) {
+    if (ks >= GB && ks < GB + (5 + PPG - 1) / PPG) {          // <= 5 pieces per slab: no dead issue sites after them
 #pragma unroll
       for (int j = 0; j < PPG; ++j) ring.issue_piece();
     }

@@ -100,7 +100,7 @@ SN_DEV void slab_f32(f32x16& acc, f32x4& a_cur, f32x16& acc_pre, const char* lw,
       ring.begin_stage();
       if (HAS_NEXT) acc_pre = load_bias(lds_bias, s_next, h);
     }
-    if (g >= GB) {
+    if (g >= GB && g < GB + (10 + PPG - 1) / PPG) {           // <= 10 pieces per slab: no dead issue sites after them
 #pragma unroll
       for (int j = 0; j < PPG; ++j) ring.issue_piece();
     }
