@@ -29,7 +29,7 @@ for f in ("pmc1", "pmc2", "pmc3"):
         per[key][r["Counter_Name"]] = float(r["Counter_Value"])
 disp = []
 for (f, d), v in sorted(per.items()):
-    v = dict(v, pass_=f, dispatch=d, points=v["grid"] // 256 * 128)
+    v = dict(v, pass_=f, dispatch=d)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles are summed over 1024 SIMDs
         cyc = v["GRBM_GUI_ACTIVE"] / 8.0
@@ -41,14 +41,18 @@ out["dispatches"] = disp
 # HBM traffic of the dominant launch (largest grid): FETCH_SIZE / WRITE_SIZE are in KiB.  The gfx950 2x correction of
 # MI355X_MICROARCH.md applies to wide (16 B/lane) coalesced reads; this kernel's reads are 4 B/lane z_vals + L2-resident
 # weights, so the raw FETCH_SIZE is reported and the corrected value given alongside.
-big = max((v["grid"] for v in disp), default=0)
-f = [v for v in disp if v["grid"] == big and "FETCH_SIZE" in v]
-w = [v for v in disp if v["grid"] == big and "WRITE_SIZE" in v]
+# the kernels are persistent (grid = #CUs): the fine pass of the frame render is the longest dispatch of each pass
+POINTS = int(sys.argv[2]) if len(sys.argv) > 2 else 160000 * 128
+f = sorted([v for v in disp if "FETCH_SIZE" in v], key=lambda v: -v["dur_ms"])
+w = sorted([v for v in disp if "WRITE_SIZE" in v], key=lambda v: -v["dur_ms"])
+m = sorted([v for v in disp if "mfma_busy_frac" in v], key=lambda v: -v["dur_ms"])
+if m:
+    out["fine_pass_sq"] = {k: m[0][k] for k in ("dur_ms", "clock_ghz", "mfma_busy_frac", "wave_parked_frac(SQ_WAIT_ANY/SQ_WAVE_CYCLES)", "vgpr", "agpr")}
 if f and w:
     fetch, write = f[0]["FETCH_SIZE"] * 1024, w[0]["WRITE_SIZE"] * 1024
-    out["traffic"] = {"kernel": "mlp_fwd_f32_kernel fine pass", "points": f[0]["points"], "fetch_bytes": fetch,
+    out["traffic"] = {"kernel": "mlp_fwd_f32_kernel fine pass", "points": POINTS, "fetch_bytes": fetch,
                       "fetch_bytes_2x_corrected": 2 * fetch, "write_bytes": write, "hbm_bytes": 2 * fetch + write,
-                      "algorithmic_bytes": f[0]["points"] * 20}
+                      "algorithmic_bytes": POINTS * 20}
 json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 if "traffic" in out:
     json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json"), open("profiles/pmc_traffic.json", "w"), indent=1)
