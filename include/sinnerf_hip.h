@@ -130,6 +130,20 @@ int sn_sample_pdf(const float* z_vals, const float* weights, const float* u, lon
 int sn_sample_pdf_bins(const float* bins, const float* weights, const float* u, long n_rays, int n_bins,
                        int n_importance, float* samples, void* stream);
 
+/* ==== "next" rows: the steps immediately before / after the hot path ========================== */
+
+/* ---- datasets/ray_utils.py:86-133 (get_ray_directions + get_rays) + the [o, d, near, far] packing of the datasets
+ * (e.g. blender_ray_patch_1image_rot3d.py:201-211; strided patches :487-498): rays generated on the GPU.
+ * c2w: 12 floats (3x4 row-major, DEVICE).  Pixel (x0 + ix*stride_x, y0 + iy*stride_y), ix < patch_w, iy < patch_h,
+ * written row-major over (iy, ix) into rays (patch_w*patch_h, 8).  Full frame = (0, 0, 1, 1, W, H).             */
+int sn_generate_rays(const float* c2w, int H, int W, float focal, float near, float far, int x0, int y0, int stride_x,
+                     int stride_y, int patch_w, int patch_h, float* rays, void* stream);
+
+/* ---- utils/__init__.py:19-21 (torch.optim.Adam, eps=1e-8) over one flat fp32 buffer (the all-reduce buffer).
+ * step = 1-based iteration count (bias correction).                                                             */
+int sn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,7 +162,7 @@ def main():
     print("done ->", OUT)
 
 
-if __name__ == "__main__" and "--grads" not in sys.argv:
+if __name__ == "__main__" and "--grads" not in sys.argv and "--rays" not in sys.argv:
     main()
 
 
@@ -217,3 +217,36 @@ def main_grads():
 
 if __name__ == "__main__" and "--grads" in sys.argv:
     main_grads()
+
+
+def main_rays():
+    """datasets/ray_utils.py get_ray_directions / get_rays, run unmodified.  Its only missing import is
+    kornia.create_meshgrid (not installed): a stub with kornia's documented semantics -- (1, H, W, 2) pixel grid,
+    [..., 0] = x in [0, W-1], [..., 1] = y in [0, H-1] -- is injected for the import."""
+    import importlib.util
+    import types
+    stub = types.ModuleType("kornia")
+
+    def create_meshgrid(height, width, normalized_coordinates=True, **kw):
+        assert not normalized_coordinates
+        xs, ys = torch.linspace(0, width - 1, width), torch.linspace(0, height - 1, height)
+        return torch.stack(torch.meshgrid([xs, ys], indexing="ij"), -1).permute(1, 0, 2).unsqueeze(0)
+    stub.create_meshgrid = create_meshgrid
+    sys.modules["kornia"] = stub
+    spec = importlib.util.spec_from_file_location("ref_ray_utils", os.path.join(REF, "datasets", "ray_utils.py"))
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    H, W, focal, near, far = 21, 34, 41.7, 2.0, 6.0
+    r = np.random.RandomState(3)
+    q, _ = np.linalg.qr(r.standard_normal((3, 3)))
+    c2w = np.concatenate([q, r.uniform(-4, 4, (3, 1))], 1).astype(np.float32)
+    directions = ru.get_ray_directions(H, W, focal)
+    rays_o, rays_d = ru.get_rays(directions, torch.from_numpy(c2w))
+    rays = torch.cat([rays_o, rays_d, near * torch.ones_like(rays_o[:, :1]), far * torch.ones_like(rays_o[:, :1])], 1)
+    np.savez_compressed(os.path.join(OUT, "rays.npz"), H=np.asarray(H), W=np.asarray(W), focal=np.asarray(focal),
+                        near=np.asarray(near), far=np.asarray(far), c2w=c2w, rays=rays.numpy())
+    print("rays", rays.shape)
+
+
+if __name__ == "__main__" and "--rays" in sys.argv:
+    main_rays()

@@ -383,6 +383,18 @@ def render_rays_backward(models, rays, upstream, N_samples=64, use_disp=False, p
     return out
 
 
+def get_rays(H, W, focal, c2w, near, far):
+    """``datasets/ray_utils.py:86-133`` (get_ray_directions + get_rays, directions NOT normalised) followed by the
+    datasets' ``[rays_o, rays_d, near, far]`` packing (``blender_ray_patch_1image_rot3d.py:201-211``).  (H*W, 8) fp32."""
+    c2w = np.asarray(c2w, F)
+    j, i = np.meshgrid(np.arange(H, dtype=F), np.arange(W, dtype=F), indexing="ij")
+    d = np.stack([((i - F(W / 2)) / F(focal)).astype(F), (-((j - F(H / 2)) / F(focal))).astype(F), -np.ones_like(i)], -1)
+    rays_d = (d.reshape(-1, 3) @ c2w[:, :3].T).astype(F)                      # :109
+    rays_o = np.broadcast_to(c2w[:, 3], rays_d.shape)                          # :112
+    ones = np.ones((H * W, 1), F)
+    return np.concatenate([rays_o, rays_d, F(near) * ones, F(far) * ones], 1).astype(F)
+
+
 # ------------------------------------------------------------------ synthetic inputs
 _KEYS = ([f"xyz_encoding_{i+1}.0" for i in range(8)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"])
 _SHAPES = {"xyz_encoding_1.0": (256, 63), "xyz_encoding_5.0": (256, 319), "xyz_encoding_final": (256, 256),

@@ -38,6 +38,8 @@ SIGNATURES = {
     "sn_mlp_forward_train": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, c_fp, c_fp, c_fp, _long, c_vp]),
     "sn_mlp_backward_chain": (_int, [c_vp, _int, c_fp, c_fp, c_fp, _long, _long, c_fp, c_fp, c_vp]),
     "sn_dw_gemm": (_int, [c_vp, _int, c_vp]),
+    "sn_generate_rays": (_int, [c_fp, _int, _int, _float, _float, _float, _int, _int, _int, _int, _int, _int, c_fp, c_vp]),
+    "sn_adam_step": (_int, [c_fp, c_fp, c_fp, c_fp, _long, _float, _float, _float, _float, _float, _int, c_vp]),
     "sn_composite_backward": (_int, [c_fp, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_fp, c_vp]),
     "sn_mlp_forward_embedded": (_int, [c_vp, _int, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
     "sn_composite_forward": (_int, [c_fp, _int, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_vp]),

@@ -10,6 +10,10 @@ int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* i
 int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
+int sn_generate_rays_launch(const float* c2w, int H, int W, float focal, float near, float far, int x0, int y0, int sx,
+                            int sy, int pw, int ph, float* rays, hipStream_t stream);
+int sn_adam_step_launch(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                        float wd, int step, hipStream_t stream);
 int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                int sigma_only, int input_mode, float* out, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
@@ -142,6 +146,22 @@ int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, co
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
                                           (hipStream_t)stream);
+}
+
+int sn_generate_rays(const float* c2w, int H, int W, float focal, float near, float far, int x0, int y0, int stride_x,
+                     int stride_y, int patch_w, int patch_h, float* rays, void* stream) {
+  if (!c2w || !rays || H < 1 || W < 1 || stride_x < 1 || stride_y < 1 || patch_w < 0 || patch_h < 0) return SN_E_BADARG;
+  if (x0 < 0 || y0 < 0 || (patch_w > 0 && x0 + (patch_w - 1) * stride_x >= W) || (patch_h > 0 && y0 + (patch_h - 1) * stride_y >= H))
+    return SN_E_BADSHAPE;
+  return sn_generate_rays_launch(c2w, H, W, focal, near, far, x0, y0, stride_x, stride_y, patch_w, patch_h, rays,
+                                 (hipStream_t)stream);
+}
+
+int sn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return SN_E_BADARG;
+  return sn_adam_step_launch(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
+                             (hipStream_t)stream);
 }
 
 int sn_dw_gemm(const void* tasks, int n_tasks, void* stream) {

@@ -67,11 +67,25 @@ def _composite(raw, has_rgb, z_vals, rays, noise, noise_std, white_back):
     return rgb, depth, weights
 
 
+def _empty_result(dev, N_samples, N_importance, test_time):
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    sf = N_samples + N_importance
+    res = {"opacity_coarse": e(0, N_samples)}
+    if not test_time:
+        res.update(rgb_coarse=e(0, 3), depth_coarse=e(0))
+    elif N_importance == 0:
+        raise NameError("name 'rgb_coarse' is not defined (rendering.py:331)")
+    res.update(rgb_fine=e(0, 3), depth_fine=e(0), opacity_fine=e(0, sf))
+    return res
+
+
 def _forward_core(models, rays, N_samples, use_disp, perturb, noise_std, N_importance, white_back, test_time,
                   flags=0, keep=None):
     """No-grad forward of the whole path.  ``keep`` (dict) receives the intermediates the backward needs."""
     dev = rays.device
     n = rays.shape[0]
+    if n == 0:                                                           # empty batch: the reference returns empty tensors
+        return _empty_result(dev, N_samples, N_importance, test_time)
     stream = _lib.stream_ptr()
     perturb_rand = None
     if perturb > 0:                                                      # rendering.py:281
@@ -145,7 +159,7 @@ def render_rays(models,
     rays = rays.contiguous().float()
     needs_grad = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
     with torch.cuda.device(rays.device):
-        if needs_grad:
+        if needs_grad and rays.shape[0] > 0:
             from .autograd import render_rays_autograd
             return render_rays_autograd(models, rays, N_samples, use_disp, perturb, noise_std, N_importance,
                                         white_back, test_time, detach_coarse)

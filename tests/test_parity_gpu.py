@@ -301,3 +301,43 @@ def test_bf16_render_psnr_parity():
     assert np.isfinite(got).all()
     assert abs(O.psnr(got, gt) - O.psnr(ref, gt)) <= 0.05, (O.psnr(got, gt), O.psnr(ref, gt))
     assert O.psnr(got, ref) > 55.0, O.psnr(got, ref)
+
+
+# ------------------------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("n,S,NI", [(1, 64, 64), (3, 64, 128), (5, 3, 1), (2, 512, 0), (129, 17, 33)])
+def test_ragged_and_extreme_shapes_vs_oracle(n, S, NI):
+    """1 ray, sizes that are no multiple of the 32-point / 64-lane tiles, the smallest legal sample_pdf (S=3 -> one pdf
+    bin), the largest samples-per-ray the compositor supports (512 = 8 per lane)."""
+    import sinnerf_amd
+    mc, pc = make_model(0, True)
+    mf, pf = make_model(1, True)
+    rays_np = O.lego_rays(400, 400, seed=1)[:: 160000 // n][:n]
+    r = np.random.RandomState(n + S)
+    rng = {"perturb": r.uniform(0, 1, (n, S)).astype(np.float32), "noise_coarse": r.standard_normal((n, S)).astype(np.float32)}
+    if NI:
+        rng.update(u=r.uniform(0, 1, (n, NI)).astype(np.float32), noise_fine=r.standard_normal((n, S + NI)).astype(np.float32))
+    meta = dict(N_samples=S, N_importance=NI, perturb=1.0, noise_std=0.5)
+    ref = O.render_rays([pc, pf], rays_np, S, False, 1.0, 0.5, NI, 32768, True, False, rng=rng)
+    with torch.no_grad(), injected_rng(rng_order(meta, rng, n)) as left:
+        res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays_np).to(dev()), S, False, 1.0, 0.5, NI, 32768, True)
+        assert not left
+    # tiny S makes the fine depths extremely sensitive to the cdf's last bit (one wide bin): looser opacity bar there
+    check_render(to_np(res), ref, tag=f"n{n}_S{S}_NI{NI}", opa=1e-4 if S >= 17 else 5e-3, rel=1e-3 if S >= 17 else 5e-3)
+
+
+def test_empty_batch_and_unsupported_sizes():
+    import sinnerf_amd
+    from sinnerf_amd._lib import SinnerfHipError
+    mc, _ = make_model(0, True)
+    mf, _ = make_model(1, True)
+    with torch.no_grad():
+        res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.zeros((0, 8), device=dev()), 64, False, 0, 0, 64, 32768, True)
+    assert res["rgb_fine"].shape == (0, 3) and res["opacity_fine"].shape == (0, 128) and res["depth_coarse"].shape == (0,)
+    with pytest.raises(SinnerfHipError):            # > 8 samples per lane: compositor refuses loudly
+        with torch.no_grad():
+            sinnerf_amd.render_rays([mc, mf], embeddings(), torch.rand((4, 8), device=dev()) + 1, 600, False, 0, 0, 0, 32768, True)
+    with pytest.raises(NotImplementedError):
+        sinnerf_amd.NeRF(D=4, W=128, use_new_activation=True)
+    with pytest.raises(NotImplementedError):
+        sinnerf_amd.render_rays([mc, mf], [sinnerf_amd.Embedding(3, 6), sinnerf_amd.Embedding(3, 4)],
+                                torch.rand((4, 8), device=dev()), 64)
