@@ -102,25 +102,23 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   float hid[128], nxt[128];
   f32x16 pacc, acc_pre;
 
-  // activation tile store (accumulator layout -> row-major [slot_rows][256]): 4 x 16 B per lane per 32-feature tile
-  auto store_tile = [&](int slot, int t, const float* v) {
+  // Epilogue slices: slice q (0..3) finalises accumulator registers 4q..4q+3 of an output tile = features 32t+8q+4h+(0..3),
+  // i.e. exactly one 16-byte store of the row-major activation matrix in the training variant.
+  auto store_slice = [&](int slot, int t, int q, const float* v) {
     if (STORE && valid) {
-      float* dst = acts + ((long)slot * slot_rows + p_raw) * 256 + 32 * t + 4 * h;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        float4 o;
-        o.x = v[4 * q4 + 0]; o.y = v[4 * q4 + 1]; o.z = v[4 * q4 + 2]; o.w = v[4 * q4 + 3];
-        *reinterpret_cast<float4*>(dst + 8 * q4) = o;
-      }
+      float4 o;
+      o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+      *reinterpret_cast<float4*>(acts + ((long)slot * slot_rows + p_raw) * 256 + 32 * t + 4 * h + 8 * q) = o;
     }
   };
-  // epilogue of a ReLU tile: nxt[16t..] = max(acc,0) (+ training store)
-  auto relu_tile = [&](int slot, int t, const f32x16& a) {
+  auto relu_slice = [&](int slot, int t, int q, const f32x16& a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      nxt[16 * t + r] = relu1(a[r]);           // one v_max_f32; the asm also pins the epilogue where it is written
-    }
-    store_tile(slot, t, nxt + 16 * t);
+    for (int r = 4 * q; r < 4 * q + 4; ++r) nxt[16 * t + r] = relu1(a[r]);   // one v_max_f32; the asm also pins it here
+    store_slice(slot, t, q, nxt + 16 * t + 4 * q);
+  };
+  auto relu_tile = [&](int slot, int t, const f32x16& a) {                    // un-overlapped form (last tile of a layer)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) relu_slice(slot, t, q, a);
   };
 #define SN_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SN_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
@@ -130,7 +128,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     slab_f32<8, 0, 2, true>(acc, a_cur, acc_pre, SN_LW_CUR, xe, xe, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                            [&] { if (t > 0) relu_tile(0, t - 1, pacc); });
+                            [&](int q) { if (t > 0) relu_slice(0, t - 1, q, pacc); });
     SN_ADVANCE();
   }
   relu_tile(0, 7, pacc);
@@ -144,14 +142,14 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         slab_f32<8, 32, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, xe, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                                 [&] { if (t > 0) relu_tile(l, t - 1, pacc); });
+                                 [&](int q) { if (t > 0) relu_slice(l, t - 1, q, pacc); });
         SN_ADVANCE();
       }
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                                 [&] { if (t > 0) relu_tile(l, t - 1, pacc); });
+                                 [&](int q) { if (t > 0) relu_slice(l, t - 1, q, pacc); });
         SN_ADVANCE();
       }
     }
@@ -181,19 +179,23 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   }
 
   // ---- xyz_encoding_final (nerf.py:140), no activation
-  auto copy_tile = [&](int slot, int t, const f32x16& a) {
+  auto copy_slice = [&](int slot, int t, int q, const f32x16& a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 4 * q; r < 4 * q + 4; ++r) {
       float v = a[r];
       asm volatile("" : "+v"(v));
       nxt[16 * t + r] = v;
     }
-    store_tile(slot, t, nxt + 16 * t);
+    store_slice(slot, t, q, nxt + 16 * t + 4 * q);
+  };
+  auto copy_tile = [&](int slot, int t, const f32x16& a) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) copy_slice(slot, t, q, a);
   };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                             [&] { if (t > 0) copy_tile(8, t - 1, pacc); });
+                             [&](int q) { if (t > 0) copy_slice(8, t - 1, q, pacc); });
     SN_ADVANCE();
   }
   copy_tile(8, 7, pacc);
@@ -225,15 +227,19 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     }
   }
   float h2[64];
+  auto ssp_slice = [&](int t, int q, const f32x16& a) {
+#pragma unroll
+    for (int r = 4 * q; r < 4 * q + 4; ++r) h2[16 * t + r] = shifted_softplus_fast(a[r]);
+    store_slice(9, t, q, h2 + 16 * t + 4 * q);
+  };
   auto ssp_tile = [&](int t, const f32x16& a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h2[16 * t + r] = shifted_softplus_fast(a[r]);
-    store_tile(9, t, h2 + 16 * t);
+    for (int q = 0; q < 4; ++q) ssp_slice(t, q, a);
   };
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     slab_f32<32, 4, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, de, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                             [&] { if (t > 0) ssp_tile(t - 1, pacc); });
+                             [&](int q) { if (t > 0) ssp_slice(t - 1, q, pacc); });
     SN_ADVANCE();
   }
   ssp_tile(3, pacc);

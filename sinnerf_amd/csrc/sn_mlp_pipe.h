@@ -83,34 +83,46 @@ typedef RingT<128, RING_SLOT_BYTES> Ring;          // fp32 weights: 128 B per K 
 // One dependent accumulator chain: measured on MI355X (tools/ubench/mfma_chain.hip) a dependent v_mfma_f32_32x32x2 chain
 // with a ds_read_b128 + s_waitcnt every 4 MFMAs and a barrier every 32 sustains 152 TF from one wave per SIMD, the same as
 // two interleaved chains -- so no second accumulator is spent.
+// Issue discipline (measured with an MFMA-duplication experiment: every extra v_mfma costs exactly 64.2 cycles, and a
+// FIXED ~1170 cycles per slab were lost on top): the wave issues in order, so a gap between two MFMAs hides at most the 64
+// cycles the previous MFMA executes.  All non-MFMA work of a group therefore must not sit in ONE gap: it is dealt out over
+// the four gaps of the group, each pinned with sched_barrier --
+//     MFMA0 | A-fragment prefetch | MFMA1 | one DMA piece | MFMA2 | one slice of the previous slab's epilogue | MFMA3
+// pending(i), i = 0..3: slice i (4 accumulator registers) of the previous slab's epilogue, run in groups 0..3.
 template <int NG0, int NG1, int GB, bool HAS_NEXT, class Pending>
 SN_DEV void slab_f32(f32x16& acc, f32x4& a_cur, f32x16& acc_pre, const char* lw, const float* b0, const float* b1,
                      const char* lw_next, const float* lds_bias, int s_next, int h, Ring& ring, Pending&& pending) {
   constexpr int NG = NG0 + NG1;
   constexpr int PPG = (10 + (NG - GB) - 1) / (NG - GB);     // DMA pieces per group after the sync point
-  static_assert(GB >= 1 && GB < NG, "sync point inside the slab");
+  static_assert(GB >= 1 && GB < NG && NG >= 4, "sync point inside the slab");
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    f32x4 a_nxt;
-    if (g + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(lw + (g + 1) * 1024);
-    else if (HAS_NEXT) a_nxt = *reinterpret_cast<const f32x4*>(lw_next);
-    if (g == GB) {
+    const float* b = (g < NG0) ? (b0 + 4 * g) : (b1 + 4 * (g - NG0));
+    if (g == GB) {                               // sync point (one longer gap per slab)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       ring.begin_stage();
       if (HAS_NEXT) acc_pre = load_bias(lds_bias, s_next, h);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (g >= GB && g < GB + (10 + PPG - 1) / PPG) {           // <= 10 pieces per slab: no dead issue sites after them
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[0], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 a_nxt;                                 // gap 1: fragment of the next group (next slab at the end)
+    if (g + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(lw + (g + 1) * 1024);
+    else if (HAS_NEXT) a_nxt = *reinterpret_cast<const f32x4*>(lw_next);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[1], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g >= GB && g < GB + (10 + PPG - 1) / PPG) {          // gap 2: weight DMA
 #pragma unroll
       for (int j = 0; j < PPG; ++j) ring.issue_piece();
     }
     __builtin_amdgcn_sched_barrier(0);
-    const float* b = (g < NG0) ? (b0 + 4 * g) : (b1 + 4 * (g - NG0));
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[2], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g < 4) pending(g);                       // gap 3: epilogue slice of the previous slab
+    __builtin_amdgcn_sched_barrier(0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[3], acc, 0, 0, 0);
-    if (g == 0) pending();
     if (g + 1 < NG || HAS_NEXT) a_cur = a_nxt;
   }
   ring.end_stage();
