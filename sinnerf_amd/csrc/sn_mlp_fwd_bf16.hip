@@ -23,6 +23,27 @@ constexpr int RING_SLOT_BYTES_BF16 = snl::MAX_SLAB_K * 64;  // 20480
 constexpr int MLP_BF16_LDS_BYTES = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES_BF16;   // 73984
 typedef RingT<64, RING_SLOT_BYTES_BF16> RingB;
 
+// The layer being WRITTEN lives in the accumulator half of the register file (explicit v_accvgpr_write, "a" constraint)
+// so that the layer being READ -- the MFMA B operands -- can stay in architectural VGPRs: hipcc otherwise parks half of
+// the 256 activation registers in AGPRs as spill slots and pays 4 v_accvgpr_read per MFMA (measured: VALU-issue-bound).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+SN_DEV uint32_t pack2(float a, float b) {
+  bf16x2 v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;            // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(uint32_t, v);
+}
+SN_DEV uint32_t to_agpr(uint32_t x) {
+  uint32_t a;
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
+  return a;
+}
+SN_DEV uint32_t from_agpr(uint32_t a) {
+  uint32_t x;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
+  return x;
+}
+
 SN_DEV bf16x8 pack8(const float* v) {
   bf16x8 o;
 #pragma unroll
@@ -146,7 +167,8 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     }
 
     int s = 0;
-    bf16x8 hid[16 * PT], nxt[16 * PT];                       // [k-step][PT]: 256 features of PT point tiles
+    bf16x8 hid[16 * PT];                                     // [k-step][PT]: layer being read (VGPR tuples)
+    uint32_t nxt[16 * PT * 4];                               // layer being written: dwords (2 bf16), AGPR-resident
     f32x16 acc[PT], pacc[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = acc_pre;
@@ -172,8 +194,18 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             sg[pt] = __builtin_fmaf(w[3], v[4 * q + 3], sg[pt]);
           }
         }
-        nxt[(2 * t) * PT + pt] = pack8(v);
-        nxt[(2 * t + 1) * PT + pt] = pack8(v + 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)                          // dword q of the tile = accumulator registers 2q, 2q+1
+          nxt[((2 * t + (q >> 2)) * PT + pt) * 4 + (q & 3)] = to_agpr(pack2(v[2 * q], v[2 * q + 1]));
+      }
+    };
+    auto promote = [&]() {                                   // layer boundary: written layer -> read layer (AGPR -> VGPR)
+#pragma unroll
+      for (int i = 0; i < 16 * PT; ++i) {
+        u32x4_t q;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) q[jj] = from_agpr(nxt[i * 4 + jj]);
+        hid[i] = __builtin_bit_cast(bf16x8, q);
       }
     };
 #define SNB_LW_CUR (ring.slot(cslot) + lane * 16)
@@ -193,8 +225,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       SNB_ADVANCE();
     }
     relu_tile(7, false);
-#pragma unroll
-    for (int i = 0; i < 16 * PT; ++i) hid[i] = nxt[i];
+    promote();
 
     // ---- layers 1..7 (skip concat at layer 4); layer 7's epilogues also feed the sigma head
 #pragma unroll 1
@@ -216,8 +247,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         }
       }
       relu_tile(7, ws);
-#pragma unroll
-      for (int i = 0; i < 16 * PT; ++i) hid[i] = nxt[i];
+      promote();
     }
 
     float sigma[PT];
@@ -237,8 +267,9 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = pacc[pt][r];
-        nxt[(2 * t) * PT + pt] = pack8(v);
-        nxt[(2 * t + 1) * PT + pt] = pack8(v + 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          nxt[((2 * t + (q >> 2)) * PT + pt) * 4 + (q & 3)] = to_agpr(pack2(v[2 * q], v[2 * q + 1]));
       }
     };
 #pragma unroll
@@ -248,8 +279,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       SNB_ADVANCE();
     }
     copy_tile(7);
-#pragma unroll
-    for (int i = 0; i < 16 * PT; ++i) hid[i] = nxt[i];
+    promote();
 
     // ---- dir_encoding + ShiftedSoftplus; the rgb head is accumulated from the fp32 softplus outputs
     bf16x8 de[2 * PT];
