@@ -44,7 +44,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   ring.n_used = SIGMA_ONLY ? snl::SLAB_FIN : snl::N_SLABS;
   ring.stage_id = 0;
   ring.stage_slot = 0;
-  ring.remaining = my_tiles * ring.n_used;
+  ring.remaining = my_tiles * ring.n_used;      // (only the prologue staging checks it)
   ring.tid = tid;
   ring.wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
   ring.pieces = 0; ring.piece = 0;
@@ -59,7 +59,9 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   __syncthreads();                               // slabs 0,1 + bias/aux table visible
 
   int cslot = 0;                                 // ring slot of the slab being consumed
-  f32x4 a_cur = *reinterpret_cast<const f32x4*>(ring.slot(0) + lane * 16);
+  f32x4 af[2];
+  af[0] = *reinterpret_cast<const f32x4*>(ring.slot(0) + lane * 16);
+  af[1] = *reinterpret_cast<const f32x4*>(ring.slot(0) + lane * 16 + 1024);
   f32x16 acc = load_bias(lds_bias, 0, h);
   const int n_used = ring.n_used;
 
@@ -124,12 +126,20 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 #define SN_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
 #define SN_ADVANCE() do { pacc = acc; acc = acc_pre; ++s; cslot = (cslot == 2) ? 0 : cslot + 1; } while (0)
 
+  // NP argument of each slab = 4 KB pieces of the slab staged at its sync point = the slab TWO ahead in the stream:
+  // K/32 -> 2 (xyz_encoding_1), 8 (256-wide), 10 (skip), 9 (dir_encoding).
+#define SN_SLAB(NG0_, NG1_, GB_, NP_, B0_, B1_, PEND_)                                                               \
+  do {                                                                                                              \
+    slab_f32<NG0_, NG1_, GB_, NP_>(acc, af, acc_pre, SN_LW_CUR, B0_, B1_, SN_LW_NEXT, lds_bias,                      \
+                                   (s + 1 == n_used ? 0 : s + 1), h, ring, PEND_);                                   \
+    SN_ADVANCE();                                                                                                   \
+  } while (0)
+
   // ---- layer 0: xyz_encoding_1  (nerf.py:68)
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    slab_f32<8, 0, 2, true>(acc, a_cur, acc_pre, SN_LW_CUR, xe, xe, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                            [&](int q) { if (t > 0) relu_slice(0, t - 1, q, pacc); });
-    SN_ADVANCE();
+    auto pend = [&](int q) { if (t > 0) relu_slice(0, t - 1, q, pacc); };
+    if (t < 6) SN_SLAB(8, 0, 2, 2, xe, xe, pend); else SN_SLAB(8, 0, 2, 8, xe, xe, pend);
   }
   relu_tile(0, 7, pacc);
 #pragma unroll
@@ -141,16 +151,22 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     if (l == 4) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        slab_f32<8, 32, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, xe, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                                 [&](int q) { if (t > 0) relu_slice(l, t - 1, q, pacc); });
-        SN_ADVANCE();
+        auto pend = [&](int q) { if (t > 0) relu_slice(l, t - 1, q, pacc); };
+        if (t < 6) SN_SLAB(8, 32, 4, 10, xe, hid, pend); else SN_SLAB(8, 32, 4, 8, xe, hid, pend);
       }
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                                 [&](int q) { if (t > 0) relu_slice(l, t - 1, q, pacc); });
-        SN_ADVANCE();
+        auto pend = [&](int q) { if (t > 0) relu_slice(l, t - 1, q, pacc); };
+        if (t < 6) {
+          SN_SLAB(32, 0, 4, 8, hid, hid, pend);
+        } else if (l == 3) {                      // the slab two ahead belongs to the skip layer
+          SN_SLAB(32, 0, 4, 10, hid, hid, pend);
+        } else if (SIGMA_ONLY && l == 7) {        // ... or to xyz_encoding_1 of the next tile
+          SN_SLAB(32, 0, 4, 2, hid, hid, pend);
+        } else {
+          SN_SLAB(32, 0, 4, 8, hid, hid, pend);
+        }
       }
     }
     relu_tile(l, 7, pacc);
@@ -194,9 +210,8 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   };
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    slab_f32<32, 0, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, hid, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                             [&](int q) { if (t > 0) copy_slice(8, t - 1, q, pacc); });
-    SN_ADVANCE();
+    auto pend = [&](int q) { if (t > 0) copy_slice(8, t - 1, q, pacc); };
+    if (t < 6) SN_SLAB(32, 0, 4, 8, hid, hid, pend); else SN_SLAB(32, 0, 4, 9, hid, hid, pend);    // tiles 6,7 stage dir_encoding
   }
   copy_tile(8, 7, pacc);
 #pragma unroll
@@ -238,9 +253,8 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   };
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    slab_f32<32, 4, 4, true>(acc, a_cur, acc_pre, SN_LW_CUR, hid, de, SN_LW_NEXT, lds_bias, (s + 1 == n_used ? 0 : s + 1), h, ring,
-                             [&](int q) { if (t > 0) ssp_slice(t - 1, q, pacc); });
-    SN_ADVANCE();
+    auto pend = [&](int q) { if (t > 0) ssp_slice(t - 1, q, pacc); };
+    if (t < 2) SN_SLAB(32, 4, 4, 9, hid, de, pend); else SN_SLAB(32, 4, 4, 2, hid, de, pend);       // tiles 2,3 stage the next tile's layer 0
   }
   ssp_tile(3, pacc);
 
@@ -275,6 +289,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 #undef SN_LW_CUR
 #undef SN_LW_NEXT
 #undef SN_ADVANCE
+#undef SN_SLAB
 }
 
 }  // namespace snk

@@ -57,6 +57,23 @@ struct RingT {
       ++piece;
     }
   }
+  // compile-time piece count: no per-piece compare/branch.  begin_static()/piece_static()/end_static<NP>() stage slab
+  // `stage_id` unconditionally (a workgroup's last tiles over-stage the first slabs of a tile nobody consumes: harmless,
+  // drained before exit).
+  SN_DEV void begin_static() {
+    gp = gnext + tid * 16;
+    lp = slot(stage_slot) + wbase;
+  }
+  SN_DEV void piece_static() {
+    __builtin_amdgcn_global_load_lds((gbl_cvoid*)gp, (lds_void*)lp, 16, 0, 0);
+    gp += 4096; lp += 4096;
+  }
+  template <int NP>
+  SN_DEV void end_static() {
+    gnext += NP * 4096;
+    stage_slot = (stage_slot == 2) ? 0 : stage_slot + 1;
+    if (++stage_id == n_used) { stage_id = 0; gnext = blob; }
+  }
   SN_DEV void end_stage() {
     if (pieces > 0) {
       gnext += slab_bytes;
@@ -89,43 +106,69 @@ typedef RingT<128, RING_SLOT_BYTES> Ring;          // fp32 weights: 128 B per K 
 // the four gaps of the group, each pinned with sched_barrier --
 //     MFMA0 | A-fragment prefetch | MFMA1 | one DMA piece | MFMA2 | one slice of the previous slab's epilogue | MFMA3
 // pending(i), i = 0..3: slice i (4 accumulator registers) of the previous slab's epilogue, run in groups 0..3.
-template <int NG0, int NG1, int GB, bool HAS_NEXT, class Pending>
-SN_DEV void slab_f32(f32x16& acc, f32x4& a_cur, f32x16& acc_pre, const char* lw, const float* b0, const float* b1,
+// NP = number of 4 KB pieces of the slab staged at this slab's sync point (the slab two ahead): compile-time, so a DMA
+// piece is m0 + address bump + global_load_lds with no compare/branch.
+template <int NG0, int NG1, int GB, int NP, class Pending>
+SN_DEV void slab_f32(f32x16& acc, f32x4 (&af)[2], f32x16& acc_pre, const char* lw, const float* b0, const float* b1,
                      const char* lw_next, const float* lds_bias, int s_next, int h, Ring& ring, Pending&& pending) {
   constexpr int NG = NG0 + NG1;
-  constexpr int PPG = (10 + (NG - GB) - 1) / (NG - GB);     // DMA pieces per group after the sync point
-  static_assert(GB >= 1 && GB < NG && NG >= 4, "sync point inside the slab");
+  constexpr int PPG = (NP + (NG - GB) - 1) / (NG - GB);      // DMA pieces per group after the sync point
+  static_assert(GB >= 2 && GB % 2 == 0 && GB < NG && NG % 2 == 0, "sync point inside the slab; fragments come in pairs");
+  // af[0], af[1] = A fragments of groups g, g+1 for even g: both are requested together two groups ahead (one s_waitcnt
+  // per TWO groups instead of one per group).  Invariant at entry / exit: af = fragments of groups 0, 1 of the slab.
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const float* b = (g < NG0) ? (b0 + 4 * g) : (b1 + 4 * (g - NG0));
     if (g == GB) {                               // sync point (one longer gap per slab)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      ring.begin_stage();
-      if (HAS_NEXT) acc_pre = load_bias(lds_bias, s_next, h);
+      ring.begin_static();
+      acc_pre = load_bias(lds_bias, s_next, h);
       __builtin_amdgcn_sched_barrier(0);
     }
+    const f32x4 a_cur = af[g & 1];
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[0], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 a_nxt;                                 // gap 1: fragment of the next group (next slab at the end)
-    if (g + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(lw + (g + 1) * 1024);
-    else if (HAS_NEXT) a_nxt = *reinterpret_cast<const f32x4*>(lw_next);
-    __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[1], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g >= GB && g < GB + (10 + PPG - 1) / PPG) {          // gap 2: weight DMA
+    if (g & 1) {                                 // gap 1 of odd groups: both fragments of the next pair of groups
+      const int gn = g + 1;
+      f32x4 n0, n1;
+      if (gn < NG) {
+        n0 = *reinterpret_cast<const f32x4*>(lw + gn * 1024);
+        n1 = *reinterpret_cast<const f32x4*>(lw + (gn + 1) * 1024);
+      } else {
+        n0 = *reinterpret_cast<const f32x4*>(lw_next);
+        n1 = *reinterpret_cast<const f32x4*>(lw_next + 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[1], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g >= GB) {
 #pragma unroll
-      for (int j = 0; j < PPG; ++j) ring.issue_piece();
+        for (int j = 0; j < PPG; ++j) if ((g - GB) * PPG + j < NP) ring.piece_static();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[2], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g < 4) pending(g);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[3], acc, 0, 0, 0);
+      af[0] = n0; af[1] = n1;
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[1], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g >= GB) {                             // gap 2: weight DMA
+#pragma unroll
+        for (int j = 0; j < PPG; ++j) if ((g - GB) * PPG + j < NP) ring.piece_static();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[2], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g < 4) pending(g);                     // gap 3: epilogue slice of the previous slab
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[3], acc, 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[2], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g < 4) pending(g);                       // gap 3: epilogue slice of the previous slab
-    __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[3], acc, 0, 0, 0);
-    if (g + 1 < NG || HAS_NEXT) a_cur = a_nxt;
   }
-  ring.end_stage();
+  ring.template end_static<NP>();
 }
 
 // ReLU as ONE v_max_f32 (fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max first: 2 VALU per value, and
