@@ -12,83 +12,162 @@
 //   outputs of dir_encoding -- so the 128-wide dir activation is never materialised at all;
 // * weights stream as bf16 slabs (K*64 bytes, a quarter of the fp32 LDS traffic per point), biases stay fp32.
 //
-// Persistent workgroups, 3-slot weight ring with a mid-slab barrier: sn_mlp_pipe.h.
+// REGISTER PLAN.  At bf16 rate an MFMA is 32 cycles and the instruction mix, not the matrix pipe, decides the speed
+// (rocprofv3 SQ_INSTS_*: the first version of this kernel issued 9.6 non-MFMA instructions per MFMA, 6 VALU per
+// activation value: hipcc keeps every builtin-MFMA accumulator in AGPRs -- v_accvgpr_read before each VALU use,
+// v_accvgpr_mov for each accumulator hand-over -- and shuffles 4-register B tuples between the two register files).
+// So the MFMAs are inline asm and the accumulation-register half of the file is managed BY HAND:
+//     a[0:127], a[128:255]   two activation sets.  A layer reads its B operands from one set (MFMA reads B from AGPRs
+//                            at no cost) while its epilogues v_accvgpr_write the next layer's into the other; the roles
+//                            swap every layer, nothing is ever copied.  The AGPR numbers are immediates in the asm
+//                            text, the compiler never sees these registers (it is told a255 is clobbered so the kernel
+//                            is sized for all 256; tools/check_agpr.py verifies it allocated none itself).
+//     VGPRs                  two accumulator sets (C/D) used alternately by consecutive slabs -- the epilogue reads them
+//                            with plain VALU instructions, the bias of slab s+1 is ds_read straight into the set slab
+//                            s-1 just vacated --, the A-fragment ring, the xyz / dir embeddings (B operands of layer
+//                            0, the skip layer and dir_encoding).
+// ReLU of a hidden layer is done AFTER the conversion on the packed pair (v_pk_max_i16 with 0: a negative bf16 is a
+// negative int16), one instruction per two values; only layer 8, whose fp32 ReLU output feeds the sigma head, uses v_max.
+// => 1.5 VALU instructions per activation value (cvt_pk, pk_max, accvgpr_write per pair).
+// The compiler does not know the asm is an MFMA, so the MFMA -> VALU-read hazard is kept by construction: an accumulator
+// set is read (a) by the deferred epilogue, which sits behind two MFMAs of the NEXT slab (64 cycles) and is pinned there
+// by sched_barrier, or (b) at a layer end behind an explicit s_nop run.
+//
+// Persistent workgroups, 3-slot weight ring with a mid-slab barrier, compile-time DMA piece counts: sn_mlp_pipe.h.
 #include "sn_mlp_pipe.h"
+#include <type_traits>
 
 namespace snk {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
 constexpr int PT = 2;                                       // point tiles per wave
 constexpr int RING_SLOT_BYTES_BF16 = snl::MAX_SLAB_K * 64;  // 20480
 constexpr int MLP_BF16_LDS_BYTES = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES_BF16;   // 73984
 typedef RingT<64, RING_SLOT_BYTES_BF16> RingB;
 
-// The layer being WRITTEN lives in the accumulator half of the register file (explicit v_accvgpr_write, "a" constraint)
-// so that the layer being READ -- the MFMA B operands -- can stay in architectural VGPRs: hipcc otherwise parks half of
-// the 256 activation registers in AGPRs as spill slots and pays 4 v_accvgpr_read per MFMA (measured: VALU-issue-bound).
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-SN_DEV uint32_t pack2(float a, float b) {
-  bf16x2 v;
-  v[0] = (__bf16)a; v[1] = (__bf16)b;            // v_cvt_pk_bf16_f32 (RNE)
-  return __builtin_bit_cast(uint32_t, v);
+SN_DEV uint32_t pack2(float a, float b) {        // {bf16(a), bf16(b)}, RNE (asm: hipcc converts the halves separately + v_perm)
+  uint32_t d;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
 }
-SN_DEV uint32_t to_agpr(uint32_t x) {
-  uint32_t a;
-  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
-  return a;
+SN_DEV uint32_t relu_pk(uint32_t x) {            // ReLU on a packed bf16 pair: v_pk_max_i16 x, 0
+  const i16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, x), z));
 }
-SN_DEV uint32_t from_agpr(uint32_t a) {
-  uint32_t x;
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
-  return x;
-}
-
-SN_DEV bf16x8 pack8(const float* v) {
-  bf16x8 o;
+SN_DEV u32x4 pack8(const float* v) {
+  u32x4 o;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
-  asm volatile("" : "+v"(o));                    // pin: convert here, not lazily at the consumer (register pressure)
+  for (int i = 0; i < 4; ++i) o[i] = pack2(v[2 * i], v[2 * i + 1]);
   return o;
 }
+// Epilogue blocks: four fp32 accumulator values -> two packed dwords of the hand-managed AGPR file, a[reg], a[reg+1]
+// (`reg` must fold to a constant, it is printed into the asm text).  One asm per block: dependent instructions are one
+// slot apart (the compiler pads every VALU <-> inline-asm dependence with an s_nop for the dst_sel forwarding hazard
+// it has to assume), and as volatile asm they keep their program order relative to the MFMA asm -- which is what keeps
+// the MFMA-result hazard distance.
+SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3) {          // hidden layer: pack, ReLU on the pairs
+  uint32_t t0, t1;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+               "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\t"
+               "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
+               : "=&v"(t0), "=&v"(t1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
+}
+SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3) {          // no activation
+  uint32_t t0, t1;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+               "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
+               : "=&v"(t0), "=&v"(t1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
+}
+SN_DEV void epi_relu_f32(int reg, float x0, float x1, float x2, float x3, float (&v)[4]) {   // fp32 ReLU, kept for the head
+  uint32_t t0, t1;
+  asm volatile("v_max_f32 %2, 0, %6\n\tv_max_f32 %3, 0, %7\n\tv_max_f32 %4, 0, %8\n\tv_max_f32 %5, 0, %9\n\t"
+               "v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+               "v_accvgpr_write_b32 a[%10], %0\n\tv_accvgpr_write_b32 a[%11], %1"
+               : "=&v"(t0), "=&v"(t1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
+}
+// D = A.B + D, D and A in VGPRs; B = a[reg : reg+3] ...
+// FIRST = first MFMA of a slab on this accumulator: its C operand was just written by VALU moves / its B operands by the
+// previous layer's v_accvgpr_write, and a VALU write -> MFMA read needs 2 wait states the compiler cannot insert for asm.
+template <bool FIRST>
+SN_DEV void mma_a(f32x16& acc, const u32x4& a, int reg) {
+  if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
+}
+// ... or B in VGPRs
+template <bool FIRST>
+SN_DEV void mma_v(f32x16& acc, const u32x4& a, const u32x4& b) {
+  if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// MFMA (8 passes) -> VALU read of its result: the wait states the compiler would insert for a builtin MFMA
+SN_DEV void mfma_result_fence() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }
+constexpr int act_reg(int set, int kstep, int pt) { return set * 128 + (kstep * PT + pt) * 4; }
 
-// One slab: NK0 + NK1 k-steps (two K segments, B operands b0 / b1 laid out [k-step][PT]), barrier after k-step GB.
-//   af       4-entry ring of A fragments, prefetch distance 3 k-steps (a bf16 k-step is only 2 x 32 MFMA cycles, one step
-//            of lookahead does not cover the LDS latency).  Invariant at entry: fragments of k-steps 0,1,2 of this slab
-//            sit in af[(PHASE+0..2) & 3]; at exit the same holds for the next slab with PHASE' = (PHASE + NK) & 3
-//            (NK % 4 == 0 everywhere except the four dir_encoding slabs, whose phases 0,2,0,2 are still static).
-template <int NK0, int NK1, int GB, int PHASE, class Pending>
-SN_DEV void slab_bf16(f32x16 (&acc)[PT], bf16x8 (&af)[4], f32x16& acc_pre, const char* lw, const bf16x8* b0,
-                      const bf16x8* b1, const char* lw_next, const float* lds_bias, int s_next, int h, RingB& ring,
-                      Pending&& pending) {
+// One slab: NK0 + NK1 k-steps (two K segments), barrier after k-step GB.
+//   SET0/SET1  B operands of the segment: AGPR activation set 0/1, or -1 = the VGPR array bv ([k-step][PT])
+//   acc        accumulator set of this slab, bias-initialised on entry
+//   accn       the other set: holds the previous slab's result until pending() has consumed it (after k-step 0), then
+//              receives the bias of slab s_next at the sync point
+//   af         4-entry ring of A fragments, prefetch distance 3 k-steps (a bf16 k-step is only 2 x 32 MFMA cycles, one
+//              step of lookahead does not cover the LDS latency).  Invariant at entry: fragments of k-steps 0,1,2 of this
+//              slab sit in af[(PHASE+0..2) & 3]; at exit the same holds for the next slab with PHASE' = (PHASE + NK) & 3
+//              (NK % 4 == 0 everywhere except the four dir_encoding slabs, whose phases 0,2,0,2 are still static).
+//   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead): compile-time -> no DMA branches
+//              (a K = 288 slab ends in a half piece that only waves 0,1 carry).
+template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, class Pending>
+SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], const char* lw, const u32x4* bv,
+                      const char* lw_next, const float* lds_bias, int s_next, int h, RingB& ring, Pending&& pending) {
   constexpr int NK = NK0 + NK1;
-  constexpr int PPG = (5 + (NK - GB) - 1) / (NK - GB);      // <= 5 pieces of 4 KB per slab (K = 320)
-  static_assert(GB >= 1 && GB < NK && NK >= 4, "sync point inside the slab");
+  constexpr int NP = (NBYTES + 4095) / 4096;
+  constexpr int PPK = (NP + (NK - GB) - 1) / (NK - GB);      // DMA pieces per k-step after the sync point (1; 2 in layer 0)
+  static_assert(GB >= 1 && GB < NK && NK >= 4 && GB + 3 <= NK, "sync point inside the slab, not after the first next-slab fragment read");
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
-    {
-      const int kn = ks + 3;
-      af[(PHASE + kn) & 3] = (kn < NK) ? *reinterpret_cast<const bf16x8*>(lw + kn * 1024)
-                                       : *reinterpret_cast<const bf16x8*>(lw_next + (kn - NK) * 1024);
-    }
     if (ks == GB) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      ring.begin_stage();
-      acc_pre = load_bias(lds_bias, s_next, h);
-    }
-    if (ks >= GB && ks < GB + (5 + PPG - 1) / PPG) {          // <= 5 pieces per slab: no dead issue sites after them
+      ring.begin_static();
 #pragma unroll
-      for (int j = 0; j < PPG; ++j) ring.issue_piece();
+      for (int pt = 0; pt < PT; ++pt) accn[pt] = load_bias(lds_bias, s_next, h);
+    }
+    {   // AFTER the sync point: in layer 0 (NK = 4, GB = 1) the fragment of k-step 1+3 already belongs to the NEXT slab,
+        // which is only guaranteed to have landed once this slab's barrier has been passed
+      const int kn = ks + 3;
+      af[(PHASE + kn) & 3] = (kn < NK) ? *reinterpret_cast<const u32x4*>(lw + kn * 1024)
+                                       : *reinterpret_cast<const u32x4*>(lw_next + (kn - NK) * 1024);
+    }
+    if (ks >= GB) {
+#pragma unroll
+      for (int i = 0; i < PPK; ++i) {
+        const int piece = (ks - GB) * PPK + i;
+        if (piece < NP) {
+          if ((piece + 1) * 4096 <= NBYTES || ring.wbase < NBYTES - piece * 4096) ring.piece_static();   // wave-uniform
+          else ring.skip_static();
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    const bf16x8* b = (ks < NK0) ? (b0 + ks * PT) : (b1 + (ks - NK0) * PT);
-    const bf16x8 a_cur = af[(PHASE + ks) & 3];
+    const u32x4 a_cur = af[(PHASE + ks) & 3];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur, b[pt], acc[pt], 0, 0, 0);
-    if (ks == 0) pending();
+    for (int pt = 0; pt < PT; ++pt) {
+      if (ks == 0) {
+        if (SET0 < 0) mma_v<true>(acc[pt], a_cur, bv[pt]); else mma_a<true>(acc[pt], a_cur, act_reg(SET0, 0, pt));
+      } else if (ks < NK0) {
+        if (SET0 < 0) mma_v<false>(acc[pt], a_cur, bv[ks * PT + pt]); else mma_a<false>(acc[pt], a_cur, act_reg(SET0, ks, pt));
+      } else {
+        if (SET1 < 0) mma_v<false>(acc[pt], a_cur, bv[(ks - NK0) * PT + pt]);
+        else mma_a<false>(acc[pt], a_cur, act_reg(SET1, ks - NK0, pt));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks == 0) {
+      pending();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  ring.end_stage();
+  ring.template end_static_bytes<NBYTES>();
 }
 
 template <bool SIGMA_ONLY, int INPUT_MODE>
@@ -98,6 +177,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_bias = reinterpret_cast<float*>(smem);
   const float* lds_aux = lds_bias + snl::BIAS_FLOATS;
+  asm volatile("" ::: "a0", "a255");             // size the kernel for the whole hand-managed AGPR file
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -115,7 +195,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   ring.n_used = SIGMA_ONLY ? snl::SLAB_FIN : snl::N_SLABS;
   ring.stage_id = 0;
   ring.stage_slot = 0;
-  ring.remaining = my_tiles * ring.n_used;
+  ring.remaining = my_tiles * ring.n_used;       // (only the prologue staging checks it)
   ring.tid = tid;
   ring.wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
   ring.pieces = 0; ring.piece = 0; ring.slab_bytes = 0;
@@ -130,16 +210,18 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   __syncthreads();
 
   int cslot = 0;
-  bf16x8 af[4];
+  u32x4 af[4];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ring.slot(0) + lane * 16 + i * 1024);
-  f32x16 acc_pre = load_bias(lds_bias, 0, h);
+  for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const u32x4*>(ring.slot(0) + lane * 16 + i * 1024);
+  f32x16 acc0[PT], acc1[PT];                                 // the two accumulator sets (VGPRs)
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) acc0[pt] = load_bias(lds_bias, 0, h);
   const int n_used = ring.n_used;
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     long p_raw[PT], p[PT];
     bool valid[PT];
-    bf16x8 xe[4 * PT];                                       // [k-step][PT]
+    u32x4 xe[4 * PT];                                        // [k-step][PT]
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       p_raw[pt] = ((tile * 4 + wave) * PT + pt) * 32 + j;
@@ -155,99 +237,117 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         embed_xyz(x, y, z, h, f);
       } else {
         const float* row = in0 + p[pt] * (long)S;
+        int hh = h;
+        asm volatile("" : "+v"(hh));             // keep the 32 column selects inside the tile loop (else hoisted: +32 VGPRs)
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
           const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
-          const int c = h ? c1 : c0;
+          const int c = hh ? c1 : c0;
           f[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
         }
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) xe[ks * PT + pt] = pack8(f + 8 * ks);
+      for (int ks = 0; ks < 4; ++ks) {
+        xe[ks * PT + pt] = pack8(f + 8 * ks);
+        asm volatile("" : "+v"(xe[ks * PT + pt]));           // convert here (32 fp32 temporaries per point tile die)
+      }
+      __builtin_amdgcn_sched_barrier(0);                     // ... and do not interleave the two point tiles
     }
 
     int s = 0;
-    bf16x8 hid[16 * PT];                                     // [k-step][PT]: layer being read (VGPR tuples)
-    uint32_t nxt[16 * PT * 4];                               // layer being written: dwords (2 bf16), AGPR-resident
-    f32x16 acc[PT], pacc[PT];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = acc_pre;
     float sg[PT];                                            // sigma head partial (fp32, this lane half)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) sg[pt] = 0.0f;
 
-    // epilogue of output tile t of a ReLU layer: relu, (optionally) sigma partial, pack to the two k-steps 2t, 2t+1
-    auto relu_tile = [&](int t, bool with_sigma) {
+    // Epilogues of output tile t (results r) writing activation set W: dword q of the tile = accumulator registers
+    // 2q, 2q+1 -> k-steps 2t, 2t+1 of the next layer (dwords q, q+1 for even q are adjacent registers).
+    auto relu_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
+      constexpr int W = decltype(wset)::value;
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        float v[16];
+      for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = relu1(pacc[pt][r]);
-        if (with_sigma) {
-          const f32x4* ws = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t);
+        for (int q = 0; q < 8; q += 2)
+          epi_relu(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]);
+    };
+    // layer 8: fp32 ReLU first, its output also feeds the sigma head (nerf.py:136)
+    auto relu_sigma_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
+      constexpr int W = decltype(wset)::value;
+      const f32x4* ws = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 w = ws[q];
-            sg[pt] = __builtin_fmaf(w[0], v[4 * q + 0], sg[pt]);
-            sg[pt] = __builtin_fmaf(w[1], v[4 * q + 1], sg[pt]);
-            sg[pt] = __builtin_fmaf(w[2], v[4 * q + 2], sg[pt]);
-            sg[pt] = __builtin_fmaf(w[3], v[4 * q + 3], sg[pt]);
-          }
+      for (int q = 0; q < 8; q += 2) {
+        const f32x4 w = ws[q >> 1];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          float v[4];
+          epi_relu_f32(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v);
+          sg[pt] = __builtin_fmaf(w[0], v[0], sg[pt]);
+          sg[pt] = __builtin_fmaf(w[1], v[1], sg[pt]);
+          sg[pt] = __builtin_fmaf(w[2], v[2], sg[pt]);
+          sg[pt] = __builtin_fmaf(w[3], v[3], sg[pt]);
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)                          // dword q of the tile = accumulator registers 2q, 2q+1
-          nxt[((2 * t + (q >> 2)) * PT + pt) * 4 + (q & 3)] = to_agpr(pack2(v[2 * q], v[2 * q + 1]));
       }
     };
-    auto promote = [&]() {                                   // layer boundary: written layer -> read layer (AGPR -> VGPR)
+    auto copy_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {     // xyz_encoding_final
+      constexpr int W = decltype(wset)::value;
 #pragma unroll
-      for (int i = 0; i < 16 * PT; ++i) {
-        u32x4_t q;
+      for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) q[jj] = from_agpr(nxt[i * 4 + jj]);
-        hid[i] = __builtin_bit_cast(bf16x8, q);
-      }
+        for (int q = 0; q < 8; q += 2)
+          epi_copy(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]);
     };
 #define SNB_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SNB_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
 #define SNB_SNEXT (s + 1 == n_used ? 0 : s + 1)
-#define SNB_ADVANCE()                                                    \
-  do {                                                                   \
-    _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) { pacc[pt] = acc[pt]; acc[pt] = acc_pre; } \
-    ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                           \
+#define SNB_ADVANCE() do { ++s; cslot = (cslot == 2) ? 0 : cslot + 1; } while (0)
+#define SNB_W(W_) std::integral_constant<int, W_>{}
+    // slab of output tile T_ (compile-time: selects the accumulator set); EPI_ = the previous tile's epilogue into set W_
+#define SNB_SLAB(T_, NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, BV_, EPI_, W_)                                           \
+  do {                                                                                                             \
+    if (((T_) & 1) == 0)                                                                                           \
+      slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(acc0, acc1, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
+                                                     SNB_SNEXT, h, ring,                                           \
+                                                     [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNB_W(W_), (T_) - 1, acc1); }); \
+    else                                                                                                           \
+      slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(acc1, acc0, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
+                                                     SNB_SNEXT, h, ring, [&]() __attribute__((always_inline)) { EPI_(SNB_W(W_), (T_) - 1, acc0); });\
+    SNB_ADVANCE();                                                                                                 \
   } while (0)
+    // the 8 output tiles of a layer, T_ literal (it ends up in asm immediates); tiles 6,7 stage the NEXT layer's slabs
+#define SNB_LAYER(NK0_, NK1_, S0_, S1_, GB_, NBA_, NBB_, BV_, EPI_, W_)   \
+  do {                                                                    \
+    SNB_SLAB(0, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, BV_, EPI_, W_);       \
+    SNB_SLAB(1, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, BV_, EPI_, W_);       \
+    SNB_SLAB(2, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, BV_, EPI_, W_);       \
+    SNB_SLAB(3, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, BV_, EPI_, W_);       \
+    SNB_SLAB(4, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, BV_, EPI_, W_);       \
+    SNB_SLAB(5, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, BV_, EPI_, W_);       \
+    SNB_SLAB(6, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, BV_, EPI_, W_);       \
+    SNB_SLAB(7, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, BV_, EPI_, W_);       \
+    mfma_result_fence();                                                  \
+    EPI_(SNB_W(W_), 7, acc1);                                             \
+  } while (0)
+    // bytes of the slab kinds (K * 64): the NB_ argument is the slab TWO ahead in the stream
+    constexpr int B_L0 = 64 * 64, B_H = 256 * 64, B_SKIP = 320 * 64, B_DIR = 288 * 64;
 
-    // ---- layer 0
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      slab_bf16<4, 0, 1, 0>(acc, af, acc_pre, SNB_LW_CUR, xe, xe, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
-                         [&] { if (t > 0) relu_tile(t - 1, false); });
-      SNB_ADVANCE();
-    }
-    relu_tile(7, false);
-    promote();
+    // ---- layer 0: reads the xyz embedding (VGPRs), writes set 0
+    SNB_LAYER(4, 0, -1, -1, 1, B_L0, B_H, xe, relu_tile, 0);
 
-    // ---- layers 1..7 (skip concat at layer 4); layer 7's epilogues also feed the sigma head
+    // ---- layers 1..7: odd layers read set 0 and write set 1, even layers the reverse; skip concat at layer 4;
+    //      layer 7's epilogues also feed the sigma head
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
-      const bool ws = (l == 7);
       if (l == 4) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          slab_bf16<4, 16, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, xe, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
-                              [&] { if (t > 0) relu_tile(t - 1, false); });
-          SNB_ADVANCE();
-        }
+        SNB_LAYER(4, 16, -1, 1, 2, B_SKIP, B_H, xe, relu_tile, 0);
+      } else if (l == 7) {
+        if (SIGMA_ONLY) SNB_LAYER(16, 0, 0, 0, 2, B_H, B_L0, xe, relu_sigma_tile, 1);     // next point tile's layer 0
+        else SNB_LAYER(16, 0, 0, 0, 2, B_H, B_H, xe, relu_sigma_tile, 1);
+      } else if (l == 3) {
+        SNB_LAYER(16, 0, 0, 0, 2, B_H, B_SKIP, xe, relu_tile, 1);
+      } else if (l & 1) {
+        SNB_LAYER(16, 0, 0, 0, 2, B_H, B_H, xe, relu_tile, 1);
       } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          slab_bf16<16, 0, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, hid, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
-                              [&] { if (t > 0) relu_tile(t - 1, ws); });
-          SNB_ADVANCE();
-        }
+        SNB_LAYER(16, 0, 1, 1, 2, B_H, B_H, xe, relu_tile, 0);
       }
-      relu_tile(7, ws);
-      promote();
     }
 
     float sigma[PT];
@@ -260,29 +360,12 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       continue;
     }
 
-    // ---- xyz_encoding_final (no activation)
-    auto copy_tile = [&](int t) {
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = pacc[pt][r];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          nxt[((2 * t + (q >> 2)) * PT + pt) * 4 + (q & 3)] = to_agpr(pack2(v[2 * q], v[2 * q + 1]));
-      }
-    };
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      slab_bf16<16, 0, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, hid, hid, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring,
-                          [&] { if (t > 0) copy_tile(t - 1); });
-      SNB_ADVANCE();
-    }
-    copy_tile(7);
-    promote();
+    // ---- xyz_encoding_final (no activation): reads set 1, writes set 0
+    SNB_LAYER(16, 0, 1, 1, 2, B_H, B_DIR, xe, copy_tile, 0);
 
-    // ---- dir_encoding + ShiftedSoftplus; the rgb head is accumulated from the fp32 softplus outputs
-    bf16x8 de[2 * PT];
+    // ---- dir_encoding + ShiftedSoftplus: reads set 0 and the dir embedding (VGPRs); the rgb head is accumulated from
+    //      the fp32 softplus outputs
+    u32x4 de[2 * PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       float f[16];
@@ -291,49 +374,59 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         embed_dir(rp[3], rp[4], rp[5], h, f);
       } else {
         const float* row = in0 + p[pt] * (long)S;
+        int hh = h;
+        asm volatile("" : "+v"(hh));
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
-          const int c = h ? c1 : c0;
+          const int c = hh ? c1 : c0;
           f[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
         }
       }
       de[0 * PT + pt] = pack8(f);
       de[1 * PT + pt] = pack8(f + 8);
+      asm volatile("" : "+v"(de[0 * PT + pt]), "+v"(de[1 * PT + pt]));
+      __builtin_amdgcn_sched_barrier(0);
     }
     float c3[PT][3];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) c3[pt][0] = c3[pt][1] = c3[pt][2] = 0.0f;
-    auto ssp_tile = [&](int t) {
+    // ShiftedSoftplus (activations.py:33-35) = max(x-1,0) + log1p(exp(-|x-1|)) on hardware exp2/log2.  log(1+e) is taken
+    // directly: its absolute error (2^-24, the bits 1+e drops) is far below the bf16 rounding of the layer's inputs, so
+    // the relative-accuracy correction of the fp32 kernel is not spent here.  Four values at a time (register pressure).
+    auto ssp_tile = [&](auto, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        float v[16];
+      for (int q = 0; q < 4; ++q) {
+        f32x4 w[3];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = shifted_softplus_fast(pacc[pt][r]);
+        for (int c = 0; c < 3; ++c)
+          w[c] = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_RGBW + c * 128 + h * 64 + 16 * t + 4 * q);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f32x4* wr = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_RGBW + c * 128 + h * 64 + 16 * t);
+        for (int pt = 0; pt < PT; ++pt) {
+          float x[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 w = wr[q];
-            c3[pt][c] = __builtin_fmaf(w[0], v[4 * q + 0], c3[pt][c]);
-            c3[pt][c] = __builtin_fmaf(w[1], v[4 * q + 1], c3[pt][c]);
-            c3[pt][c] = __builtin_fmaf(w[2], v[4 * q + 2], c3[pt][c]);
-            c3[pt][c] = __builtin_fmaf(w[3], v[4 * q + 3], c3[pt][c]);
+          for (int i = 0; i < 4; ++i) x[i] = r[pt][4 * q + i];
+          // the chunk's inputs and the running sums pass through one volatile asm: chunks execute strictly in order
+          asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(c3[pt][0]), "+v"(c3[pt][1]), "+v"(c3[pt][2]));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float sx = x[i] - 1.0f;
+            const float e = __builtin_amdgcn_exp2f(-fabsf(sx) * 1.44269504088896340736f);
+            const float v = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), 0.69314718055994530942f, fmaxf(sx, 0.0f));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) c3[pt][c] = __builtin_fmaf(w[c][i], v, c3[pt][c]);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    // 18 k-steps per slab: the fragment-ring phase alternates 0,2,0,2 (static)
-    slab_bf16<16, 2, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring, [&] {});
-    SNB_ADVANCE();
-    slab_bf16<16, 2, 2, 2>(acc, af, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring, [&] { ssp_tile(0); });
-    SNB_ADVANCE();
-    slab_bf16<16, 2, 2, 0>(acc, af, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring, [&] { ssp_tile(1); });
-    SNB_ADVANCE();
-    slab_bf16<16, 2, 2, 2>(acc, af, acc_pre, SNB_LW_CUR, hid, de, SNB_LW_NEXT, lds_bias, SNB_SNEXT, h, ring, [&] { ssp_tile(2); });
-    SNB_ADVANCE();
-    ssp_tile(3);
+    // 18 k-steps per slab: the fragment-ring phase alternates 0,2,0,2 (static); tiles 2,3 stage the next point tile
+    SNB_SLAB(0, 16, 2, 0, -1, 2, 0, B_DIR, de, ssp_tile, 0);
+    SNB_SLAB(1, 16, 2, 0, -1, 2, 2, B_DIR, de, ssp_tile, 0);
+    SNB_SLAB(2, 16, 2, 0, -1, 2, 0, B_L0, de, ssp_tile, 0);
+    SNB_SLAB(3, 16, 2, 0, -1, 2, 2, B_L0, de, ssp_tile, 0);
+    mfma_result_fence();
+    ssp_tile(SNB_W(0), 3, acc1);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       float o3[3];
@@ -350,6 +443,9 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #undef SNB_LW_NEXT
 #undef SNB_SNEXT
 #undef SNB_ADVANCE
+#undef SNB_SLAB
+#undef SNB_LAYER
+#undef SNB_W
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

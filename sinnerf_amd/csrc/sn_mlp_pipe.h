@@ -68,6 +68,13 @@ struct RingT {
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)gp, (lds_void*)lp, 16, 0, 0);
     gp += 4096; lp += 4096;
   }
+  SN_DEV void skip_static() { gp += 4096; lp += 4096; }      // a trailing partial piece this wave has no share of
+  template <int NBYTES>
+  SN_DEV void end_static_bytes() {
+    gnext += NBYTES;
+    stage_slot = (stage_slot == 2) ? 0 : stage_slot + 1;
+    if (++stage_id == n_used) { stage_id = 0; gnext = blob; }
+  }
   template <int NP>
   SN_DEV void end_static() {
     gnext += NP * 4096;

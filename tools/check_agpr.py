@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Build check for sn_mlp_fwd_bf16.hip (run by sinnerf_amd/csrc/Makefile on the hipcc -S output).
+
+The kernel manages the AGPR file by hand and emits its MFMAs as inline asm, so three things the compiler normally
+guarantees are checked on the generated code instead:
+  1. the compiler allocated no AGPR itself (every AGPR reference sits inside ASMSTART/ASMEND) and spilled nothing;
+  2. no VALU instruction writes a register an MFMA reads within the next 2 wait states (VALU write -> MFMA read hazard);
+  3. no VALU instruction reads an MFMA result before two further MFMAs (or 12 other instructions) have issued
+     (MFMA write -> VALU read hazard, 11 wait states for an 8-pass MFMA).
+usage: check_agpr.py file.s"""
+import re, sys
+
+def vregs(tok):
+    out = set()
+    for m in re.finditer(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]', tok):
+        if m.group(1): out.add(('v', int(m.group(1))))
+        else: out |= {('v', r) for r in range(int(m.group(2)), int(m.group(3)) + 1)}
+    for m in re.finditer(r'\ba(\d+)\b|\ba\[(\w+)(?::(\w+))?\]', tok):
+        if m.group(1): out.add(('a', int(m.group(1))))
+        else:
+            lo = int(m.group(2), 0); hi = int(m.group(3), 0) if m.group(3) else lo
+            out |= {('a', r) for r in range(lo, hi + 1)}
+    return out
+
+kern = None; ina = False; ins = []; bad_agpr = []; spills = 0
+for ln, l in enumerate(open(sys.argv[1]), 1):
+    m = re.match(r'^(_Z\S*mlp_fwd_bf16\S*):', l)
+    if m: kern = m.group(1); continue
+    if kern is None: continue
+    if re.match(r'^\s*s_endpgm', l): kern = None; continue
+    if 'ASMSTART' in l: ina = True; continue
+    if 'ASMEND' in l: ina = False; continue
+    t = l.strip().split(';')[0].strip()
+    if not t or t[0] == '.' or t.endswith(':'): continue
+    if 'scratch_' in t: spills += 1
+    m = re.match(r'^([a-z_0-9]+)\s*(.*)$', t)
+    op, args = m.groups()
+    parts = [a.strip() for a in args.split(',')] if args else []
+    if not ina and any(k == 'a' for k, _ in vregs(args)): bad_agpr.append((ln, t))
+    is_valu = op.startswith('v_') and not op.startswith('v_mfma')
+    if op.startswith(('v_', 'ds_read', 'global_load_dword', 'scratch_load')) and not op.startswith(('v_cmp', 'v_readfirstlane')):
+        dst = vregs(parts[0]) if parts else set(); src = set().union(*[vregs(p) for p in parts[1:]]) if len(parts) > 1 else set()
+        if op.startswith(('v_fmac', 'v_pk_fma', 'v_mfma')): src |= dst if not op.startswith('v_mfma') else set()
+    else:
+        dst = set(); src = set().union(*[vregs(p) for p in parts]) if parts else set()
+    ins.append((ln, op, dst, src, is_valu, t))
+
+haz1 = []; haz2 = []
+for i, (ln, op, dst, src, is_valu, t) in enumerate(ins):
+    if not op.startswith('v_mfma'): continue
+    # leading s_nop N inside the same asm statement shows up as the previous instruction
+    ws = 0; j = i - 1
+    while j >= 0 and ws < 2:
+        pop = ins[j][1]
+        if pop == 's_nop': ws += int(ins[j][5].split()[1], 0) + 1
+        else:
+            if ins[j][4] and (ins[j][2] & src): haz1.append((ln, ins[j][5], t))
+            ws += 8 if pop.startswith('v_mfma') else 1
+        j -= 1
+    nm = 0; other = 0; j = i + 1
+    while j < len(ins) and nm < 2 and other < 12:
+        if ins[j][1].startswith('v_mfma'): nm += 1
+        else:
+            if ins[j][4] and (ins[j][3] & dst): haz2.append((ln, t, ins[j][5]))
+            other += (int(ins[j][5].split()[1], 0) + 1) if ins[j][1] == 's_nop' else 1
+        j += 1
+
+print(f"compiler-allocated AGPR references: {len(bad_agpr)}; scratch instructions: {spills}; "
+      f"VALU->MFMA read hazards: {len(haz1)}; MFMA->VALU read hazards: {len(haz2)}")
+for b in bad_agpr[:5]: print("  agpr  line %d: %s" % b)
+for b in haz1[:5]: print("  haz1  line %d: %s  ->  %s" % b)
+for b in haz2[:5]: print("  haz2  line %d: %s  ->  %s" % b)
+sys.exit(1 if bad_agpr or spills or haz1 or haz2 else 0)
