@@ -144,6 +144,22 @@ int sn_generate_rays(const float* c2w, int H, int W, float focal, float near, fl
 int sn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* ---- losses on the rendered rays, forward + gradients in two launches: MSELoss (losses.py:12-22: nn.MSELoss 'mean' of
+ * rgb_coarse and rgb_fine against the targets), SL1Loss (models/sinnerf.py:32-42: nn.SmoothL1Loss 'mean', beta 1, of
+ * depth_coarse and depth_fine -- call sites :310-319) and psnr (metrics.py:5-15).
+ *   rgb_* (n,3), depth_* (n), rgb_gt (n,3), depth_gt (n): DEVICE fp32; any prediction and either target may be NULL
+ *   (its terms are then 0 and its gradient is not written).
+ *   mask_mode 0: every depth element counts (useMask=False); 1: depth_gt > 0 (mask=None, useMask=True); 2: mask (n) uint8.
+ *   out[8] = mse_coarse, mse_fine, sl1_coarse, sl1_fine, total = w_rgb (mse_c + mse_f) + w_depth (sl1_c + sl1_f),
+ *            psnr_coarse, psnr_fine, number of depth elements counted.
+ *   g_*: gradients of `total` w.r.t. the matching prediction (NULL = not wanted).
+ *   workspace: sn_render_loss_workspace_bytes() bytes of DEVICE scratch (per-block partial sums; deterministic order). */
+long sn_render_loss_workspace_bytes(void);
+int sn_render_loss(const float* rgb_coarse, const float* rgb_fine, const float* depth_coarse, const float* depth_fine,
+                   const float* rgb_gt, const float* depth_gt, const unsigned char* mask, int mask_mode, long n,
+                   float w_rgb, float w_depth, float* g_rgb_coarse, float* g_rgb_fine, float* g_depth_coarse,
+                   float* g_depth_fine, void* workspace, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,7 +162,7 @@ def main():
     print("done ->", OUT)
 
 
-if __name__ == "__main__" and "--grads" not in sys.argv and "--rays" not in sys.argv:
+if __name__ == "__main__" and "--grads" not in sys.argv and "--rays" not in sys.argv and "--loss" not in sys.argv:
     main()
 
 
@@ -250,3 +250,65 @@ def main_rays():
 
 if __name__ == "__main__" and "--rays" in sys.argv:
     main_rays()
+
+
+def main_loss():
+    """losses.py MSELoss, models/sinnerf.py SL1Loss and metrics.py psnr, run unmodified: the modules' unrelated imports
+    that are not installed (torchvision, kornia, piq) are stubbed, and SL1Loss -- whose module imports pytorch_lightning
+    & co -- is compiled from its own class node in the reference file (ast), not re-typed."""
+    import ast
+    import importlib.util
+    import types
+    for name, attrs in (("torchvision", {"models": None}), ("kornia", {}), ("kornia.losses", {"ssim_loss": None, "ssim": None}),
+                        ("piq", {})):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    sys.modules["kornia"].losses = sys.modules["kornia.losses"]
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, path))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    ref_losses, ref_metrics = load("losses.py", "ref_losses"), load("metrics.py", "ref_metrics")
+    tree = ast.parse(open(os.path.join(REF, "models", "sinnerf.py")).read())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "SL1Loss")
+    ns = {"nn": torch.nn, "torch": torch}
+    exec(compile(ast.Module([node], []), "models/sinnerf.py", "exec"), ns)
+    SL1Loss = ns["SL1Loss"]
+
+    r = np.random.RandomState(11)
+    n = 777
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).requires_grad_(True)
+    rgb_gt = r.uniform(0, 1, (n, 3)).astype(np.float32)
+    depth_gt = r.uniform(-1.0, 6.0, n).astype(np.float32)            # some <= 0: exercised by useMask=True
+    depth_gt[::13] = 0.0
+    res = {"rgb_coarse": t(rgb_gt + r.normal(0, 0.2, (n, 3))), "rgb_fine": t(rgb_gt + r.normal(0, 0.05, (n, 3))),
+           "depth_coarse": t(depth_gt + r.normal(0, 1.5, n)), "depth_fine": t(depth_gt + r.normal(0, 0.6, n))}
+    mask = r.uniform(0, 1, n) < 0.4
+    out = {"rgb_gt": rgb_gt, "depth_gt": depth_gt, "mask": mask, **{k: v.detach().numpy() for k, v in res.items()}}
+    mse, s1 = ref_losses.MSELoss(), SL1Loss()
+    w_depth = 0.37
+    for tag, kw in (("nomask", dict(useMask=False)), ("gt0", dict(useMask=True)), ("mask", dict(mask=torch.from_numpy(mask)))):
+        for v in res.values():
+            v.grad = None
+        l2 = mse(res, torch.from_numpy(rgb_gt))["tot"]
+        sl_f = s1(res["depth_fine"], torch.from_numpy(depth_gt), **kw)
+        sl_c = s1(res["depth_coarse"], torch.from_numpy(depth_gt), **kw)
+        total = l2 + w_depth * (sl_f + sl_c)                          # models/sinnerf.py:310-319 shape of the sum
+        total.backward()
+        out.update({f"{tag}_l2": l2.detach().numpy(), f"{tag}_sl1_fine": sl_f.detach().numpy(),
+                    f"{tag}_sl1_coarse": sl_c.detach().numpy(), f"{tag}_total": total.detach().numpy(),
+                    **{f"{tag}_g_{k}": v.grad.numpy().copy() for k, v in res.items()}})
+    out["psnr_fine"] = ref_metrics.psnr(res["rgb_fine"].detach(), torch.from_numpy(rgb_gt)).numpy()
+    out["psnr_coarse"] = ref_metrics.psnr(res["rgb_coarse"].detach(), torch.from_numpy(rgb_gt)).numpy()
+    out["mse_fine"] = ref_metrics.mse(res["rgb_fine"].detach(), torch.from_numpy(rgb_gt)).numpy()
+    out["w_depth"] = np.asarray(w_depth, np.float32)
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+    print("loss", {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
+
+
+if __name__ == "__main__" and "--loss" in sys.argv:
+    main_loss()

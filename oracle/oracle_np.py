@@ -270,6 +270,51 @@ def psnr(a, b):
 
 
 # ------------------------------------------------------------ backward (autograd restated)
+# ---- losses on the rendered rays (the step after the path) -----------------------------------------------------------
+def mse_loss(pred, gt):
+    """nn.MSELoss(reduction='mean') (losses.py:15,18-20); metrics.py:5-11 `mse`.  Accumulated in double."""
+    d = (pred.astype(np.float32) - gt.astype(np.float32)).astype(np.float32)
+    return np.float32(np.mean((d * d).astype(np.float64)))
+
+
+def smooth_l1_loss(pred, gt, mask=None):
+    """nn.SmoothL1Loss(reduction='mean'), beta = 1, over pred[mask], gt[mask] (models/sinnerf.py:36-42)."""
+    d = np.abs(pred.astype(np.float32) - gt.astype(np.float32)).astype(np.float32)
+    v = np.where(d < 1, np.float32(0.5) * d * d, d - np.float32(0.5)).astype(np.float32)
+    if mask is not None:
+        v = v[mask]
+    return np.float32(np.mean(v.astype(np.float64)))
+
+
+def render_loss(results, rgbs, depths=None, w_rgb=1.0, w_depth=1.0, mask=None, use_mask=False):
+    """MSELoss (losses.py:12-22) + w_depth * SL1 of depth_fine and depth_coarse (models/sinnerf.py:310-319) and the
+    gradients of the total w.r.t. the rendered tensors.  Returns (stats dict, grads dict)."""
+    st, gr = {}, {}
+    total = np.float64(0)
+    n3 = rgbs.size if rgbs is not None else 0
+    for k in ("coarse", "fine"):
+        key = "rgb_" + k
+        if rgbs is not None and key in results:
+            st["mse_" + k] = mse_loss(results[key], rgbs)
+            gr[key] = (np.float32(w_rgb * 2.0 / n3) * (results[key] - rgbs)).astype(np.float32)
+            total += w_rgb * st["mse_" + k]
+            st["psnr_" + k] = np.float32(-10.0 * np.log10(st["mse_" + k]))
+    if depths is not None:
+        m = mask if mask is not None else ((depths > 0) if use_mask else np.ones(depths.shape, bool))
+        cnt = int(m.sum())
+        st["n_depth"] = cnt
+        for k in ("coarse", "fine"):
+            key = "depth_" + k
+            if key in results:
+                st["sl1_" + k] = smooth_l1_loss(results[key], depths, m)
+                d = (results[key] - depths).astype(np.float32)
+                g = np.where(np.abs(d) < 1, d, np.sign(d)).astype(np.float32) * np.float32(w_depth / cnt)
+                gr[key] = np.where(m, g, np.float32(0)).astype(np.float32)
+                total += w_depth * st["sl1_" + k]
+    st["total"] = np.float32(total)
+    return st, gr
+
+
 def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None):
     """Parameter gradients of ``nerf_forward`` (non sigma_only) for upstream ``g_out`` (B,4) -- what torch autograd
     derives from ``models/nerf.py:122-148`` + ``models/activations.py`` (Linear: gW = g^T x, gb = sum g, gx = g W;

@@ -40,6 +40,9 @@ SIGNATURES = {
     "sn_dw_gemm": (_int, [c_vp, _int, c_vp]),
     "sn_generate_rays": (_int, [c_fp, _int, _int, _float, _float, _float, _int, _int, _int, _int, _int, _int, c_fp, c_vp]),
     "sn_adam_step": (_int, [c_fp, c_fp, c_fp, c_fp, _long, _float, _float, _float, _float, _float, _int, c_vp]),
+    "sn_render_loss_workspace_bytes": (_long, []),
+    "sn_render_loss": (_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_vp, _int, _long, _float, _float, c_fp, c_fp, c_fp, c_fp,
+                              c_vp, c_fp, c_vp]),
     "sn_composite_backward": (_int, [c_fp, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_fp, c_vp]),
     "sn_mlp_forward_embedded": (_int, [c_vp, _int, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
     "sn_composite_forward": (_int, [c_fp, _int, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_vp]),

@@ -14,6 +14,11 @@ int sn_generate_rays_launch(const float* c2w, int H, int W, float focal, float n
                             int sy, int pw, int ph, float* rays, hipStream_t stream);
 int sn_adam_step_launch(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                         float wd, int step, hipStream_t stream);
+long sn_render_loss_workspace_bytes_impl();
+int sn_render_loss_launch(const float* rgb_c, const float* rgb_f, const float* depth_c, const float* depth_f,
+                          const float* rgb_gt, const float* depth_gt, const unsigned char* mask, int mask_mode, long n,
+                          float w_rgb, float w_depth, float* g_rgb_c, float* g_rgb_f, float* g_depth_c, float* g_depth_f,
+                          void* workspace, float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                int sigma_only, int input_mode, float* out, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
@@ -162,6 +167,21 @@ int sn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
   if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return SN_E_BADARG;
   return sn_adam_step_launch(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
                              (hipStream_t)stream);
+}
+
+long sn_render_loss_workspace_bytes(void) { return sn_render_loss_workspace_bytes_impl(); }
+
+int sn_render_loss(const float* rgb_coarse, const float* rgb_fine, const float* depth_coarse, const float* depth_fine,
+                   const float* rgb_gt, const float* depth_gt, const unsigned char* mask, int mask_mode, long n,
+                   float w_rgb, float w_depth, float* g_rgb_coarse, float* g_rgb_fine, float* g_depth_coarse,
+                   float* g_depth_fine, void* workspace, float* out, void* stream) {
+  if (!workspace || !out || n < 1 || mask_mode < 0 || mask_mode > 2) return SN_E_BADARG;
+  if ((mask_mode == 2 && !mask) || (mask_mode != 0 && !depth_gt)) return SN_E_BADARG;
+  if ((rgb_coarse || rgb_fine) && !rgb_gt) return SN_E_BADARG;
+  if ((depth_coarse || depth_fine) && !depth_gt) return SN_E_BADARG;
+  return sn_render_loss_launch(rgb_coarse, rgb_fine, depth_coarse, depth_fine, rgb_gt, depth_gt, mask, mask_mode, n,
+                               w_rgb, w_depth, g_rgb_coarse, g_rgb_fine, g_depth_coarse, g_depth_fine, workspace, out,
+                               (hipStream_t)stream);
 }
 
 int sn_dw_gemm(const void* tasks, int n_tasks, void* stream) {

@@ -21,6 +21,7 @@ from torch import nn
 
 from .nerf import Embedding, NeRF
 from .parallel import FlatGradBuffer, broadcast_parameters
+from .losses import psnr, render_loss      # noqa: F401  (psnr re-exported: metrics.py:14-15)
 from .rendering import render_rays
 
 DEFAULT_HPARAMS = dict(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=1.0, chunk=32 * 1024,
@@ -28,9 +29,6 @@ DEFAULT_HPARAMS = dict(N_samples=64, N_importance=64, use_disp=False, perturb=1.
                        compute_dtype="fp32")
 
 
-def psnr(image_pred, image_gt):
-    """``metrics.py:5-15``."""
-    return -10.0 * torch.log10(torch.mean((image_pred - image_gt) ** 2))
 
 
 class SinNeRFSystem(nn.Module):
@@ -71,29 +69,27 @@ class SinNeRFSystem(nn.Module):
         scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=hp.decay_step, gamma=hp.decay_gamma)
         return [self.optimizer], [scheduler]
 
-    # ---- losses.py:12-22 (MSE coarse + fine) + SmoothL1 depth (sinnerf.py:32-42, 310-319) ------------------------
-    def loss(self, results, rgbs, depths=None):
-        loss = torch.mean((results["rgb_coarse"] - rgbs) ** 2)
-        if "rgb_fine" in results:
-            loss = loss + torch.mean((results["rgb_fine"] - rgbs) ** 2)
-        if depths is not None and self.hparams.depth_weight > 0:
-            loss = loss + self.hparams.depth_weight * torch.nn.functional.smooth_l1_loss(results["depth_fine"], depths)
-        return loss
+    # ---- losses.py:12-22 (MSE coarse + fine) + SL1Loss of depth_fine and depth_coarse (sinnerf.py:32-42, 310-319):
+    #      value, gradients and PSNR from the fused sn_render_loss kernel pair (sinnerf_amd/losses.py)
+    def loss(self, results, rgbs, depths=None, with_stats=False):
+        use_depth = depths is not None and self.hparams.depth_weight > 0
+        total, stats = render_loss(results, rgbs, depths if use_depth else None, w_depth=self.hparams.depth_weight)
+        return (total, stats) if with_stats else total
 
     def training_step(self, batch, batch_idx=0, optimizer_idx=0):
         rays, rgbs = batch["rays"], batch["rgbs"]
         rays, rgbs = rays.reshape(-1, 8), rgbs.reshape(-1, 3)
         results = self(rays)
-        loss = self.loss(results, rgbs, batch.get("depths"))
-        with torch.no_grad():
-            p = psnr(results["rgb_fine"], rgbs)
+        loss, stats = self.loss(results, rgbs, batch.get("depths"), with_stats=True)
+        p = stats["psnr_fine"] if "rgb_fine" in results else stats["psnr_coarse"]
         return {"loss": loss, "progress_bar": {"train_psnr": p}, "log": {"train/loss": loss.detach(), "train/psnr": p}}
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx=0):
         rays, rgbs = batch["rays"].reshape(-1, 8), batch["rgbs"].reshape(-1, 3)
         results = self(rays)
-        return {"val_loss": self.loss(results, rgbs), "val_psnr": psnr(results["rgb_fine"], rgbs)}
+        loss, stats = self.loss(results, rgbs, with_stats=True)
+        return {"val_loss": loss, "val_psnr": stats["psnr_fine"] if "rgb_fine" in results else stats["psnr_coarse"]}
 
     def validation_epoch_end(self, outputs):
         mean_psnr = torch.stack([x["val_psnr"] for x in outputs]).mean()

@@ -90,3 +90,83 @@ def test_flat_adam_matches_torch_adam():
         ra = sinnerf_amd.render_rays(a, emb, rays, 64, False, 0, 0, 64, 32768, True)["rgb_fine"]
         rb = sinnerf_amd.render_rays(b, emb, rays, 64, False, 0, 0, 64, 32768, True)["rgb_fine"]
     assert torch.allclose(ra, rb, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------- losses on the rendered rays
+LOSS_MODES = (("nomask", dict(use_mask=False)), ("gt0", dict(use_mask=True)), ("mask", dict(mask="mask")))
+
+
+def test_oracle_render_loss_golden():
+    """oracle MSELoss / SL1Loss / psnr restatement against the reference's own classes (tests/golden/loss.npz, made by
+    oracle/gen_golden.py --loss from losses.py:12-22, models/sinnerf.py:32-42, metrics.py:5-15)."""
+    z = np.load(f"{GOLDEN}/loss.npz")
+    res = {k: z[k] for k in ("rgb_coarse", "rgb_fine", "depth_coarse", "depth_fine")}
+    for tag, kw in LOSS_MODES:
+        kw = {k: (z["mask"] if isinstance(v, str) else v) for k, v in kw.items()}
+        st, gr = O.render_loss(res, z["rgb_gt"], z["depth_gt"], w_depth=float(z["w_depth"]), **kw)
+        assert abs(st["mse_coarse"] + st["mse_fine"] - z[f"{tag}_l2"]) <= 1e-6 * z[f"{tag}_l2"]
+        for k in ("fine", "coarse"):
+            assert abs(st["sl1_" + k] - z[f"{tag}_sl1_{k}"]) <= 1e-6 * z[f"{tag}_sl1_{k}"], (tag, k)
+        assert abs(st["total"] - z[f"{tag}_total"]) <= 1e-6 * z[f"{tag}_total"]
+        for k in res:
+            assert np.abs(gr[k] - z[f"{tag}_g_{k}"]).max() <= 1e-6 * np.abs(z[f"{tag}_g_{k}"]).max(), (tag, k)
+    st, _ = O.render_loss(res, z["rgb_gt"])
+    assert abs(st["psnr_fine"] - z["psnr_fine"]) <= 1e-4 and abs(st["psnr_coarse"] - z["psnr_coarse"]) <= 1e-4
+    assert abs(st["mse_fine"] - z["mse_fine"]) <= 1e-6 * z["mse_fine"]
+
+
+@pytest.mark.gpu
+def test_render_loss_gpu_golden_and_autograd():
+    """sn_render_loss through the reference-shaped objects (MSELoss, SL1Loss, psnr) and the fused render_loss: values and
+    gradients against the golden fixture; tolerance 2e-6 relative (fp32 values, double accumulation)."""
+    from sinnerf_amd.losses import MSELoss, SL1Loss, psnr, render_loss
+    z = np.load(f"{GOLDEN}/loss.npz")
+    dev = torch.device("cuda:0")
+    gt_rgb, gt_d = torch.from_numpy(z["rgb_gt"]).to(dev), torch.from_numpy(z["depth_gt"]).to(dev)
+    w_depth = float(z["w_depth"])
+    for tag, kw in LOSS_MODES:
+        res = {k: torch.from_numpy(z[k]).to(dev).requires_grad_(True) for k in ("rgb_coarse", "rgb_fine", "depth_coarse", "depth_fine")}
+        rkw = dict(useMask=kw.get("use_mask", False), mask=torch.from_numpy(z["mask"]).to(dev) if "mask" in kw else None)
+        total, st = render_loss(res, gt_rgb, gt_d, w_depth=w_depth, **rkw)
+        total.backward()
+        assert abs(total.item() - z[f"{tag}_total"]) <= 2e-6 * z[f"{tag}_total"], tag
+        assert abs(st["mse_coarse"].item() + st["mse_fine"].item() - z[f"{tag}_l2"]) <= 2e-6 * z[f"{tag}_l2"]
+        for k in ("fine", "coarse"):
+            assert abs(st["sl1_" + k].item() - z[f"{tag}_sl1_{k}"]) <= 2e-6 * z[f"{tag}_sl1_{k}"], (tag, k)
+        for k, v in res.items():
+            ref = z[f"{tag}_g_{k}"]
+            assert np.abs(v.grad.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max(), (tag, k)
+        # the reference's separate objects, composed the way models/sinnerf.py:310-319 does
+        res2 = {k: torch.from_numpy(z[k]).to(dev).requires_grad_(True) for k in res}
+        skw = dict(useMask=kw.get("use_mask", False)) if "mask" not in kw else dict(mask=rkw["mask"])
+        tot2 = MSELoss()(res2, gt_rgb)["tot"] + w_depth * (SL1Loss()(res2["depth_fine"], gt_d, **skw)
+                                                          + SL1Loss()(res2["depth_coarse"], gt_d, **skw))
+        tot2.backward()
+        assert abs(tot2.item() - z[f"{tag}_total"]) <= 2e-6 * z[f"{tag}_total"]
+        for k, v in res2.items():
+            ref = z[f"{tag}_g_{k}"]
+            assert np.abs(v.grad.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max(), (tag, k)
+    assert abs(psnr(torch.from_numpy(z["rgb_fine"]).to(dev), gt_rgb).item() - z["psnr_fine"]) <= 1e-4
+    # only-coarse model (N_importance = 0): missing keys drop their terms (losses.py:19)
+    only_c = {"rgb_coarse": torch.from_numpy(z["rgb_coarse"]).to(dev)}
+    assert abs(MSELoss()(only_c, gt_rgb)["tot"].item() - O.mse_loss(z["rgb_coarse"], z["rgb_gt"])) <= 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 255, 160000])
+def test_render_loss_gpu_sizes_vs_oracle(n):
+    from sinnerf_amd.losses import render_loss
+    r = np.random.RandomState(n)
+    gt_rgb, gt_d = r.uniform(0, 1, (n, 3)).astype(np.float32), r.uniform(0.5, 6, n).astype(np.float32)
+    res = {"rgb_coarse": (gt_rgb + r.normal(0, 0.1, (n, 3))).astype(np.float32), "rgb_fine": (gt_rgb + r.normal(0, 0.03, (n, 3))).astype(np.float32),
+           "depth_coarse": (gt_d + r.normal(0, 2, n)).astype(np.float32), "depth_fine": (gt_d + r.normal(0, 0.5, n)).astype(np.float32)}
+    st, gr = O.render_loss(res, gt_rgb, gt_d, w_rgb=1.0, w_depth=0.1)
+    dev = torch.device("cuda:0")
+    tres = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in res.items()}
+    total, got = render_loss(tres, torch.from_numpy(gt_rgb).to(dev), torch.from_numpy(gt_d).to(dev), w_depth=0.1)
+    (3.0 * total).backward()
+    assert abs(total.item() - st["total"]) <= 2e-6 * st["total"]
+    for k in ("mse_coarse", "mse_fine", "sl1_coarse", "sl1_fine", "psnr_fine"):
+        assert abs(got[k].item() - st[k]) <= 2e-6 * abs(st[k]) + 1e-5 * (k == "psnr_fine"), k
+    for k, v in tres.items():
+        assert np.abs(v.grad.cpu().numpy() - 3.0 * gr[k]).max() <= 3e-6 * np.abs(3.0 * gr[k]).max(), k
