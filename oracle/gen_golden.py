@@ -162,7 +162,7 @@ def main():
     print("done ->", OUT)
 
 
-if __name__ == "__main__" and "--grads" not in sys.argv and "--rays" not in sys.argv and "--loss" not in sys.argv:
+if __name__ == "__main__" and "--grads" not in sys.argv and "--rays" not in sys.argv and "--loss" not in sys.argv and "--pfm" not in sys.argv:
     main()
 
 
@@ -312,3 +312,30 @@ def main_loss():
 
 if __name__ == "__main__" and "--loss" in sys.argv:
     main_loss()
+
+
+def main_pfm():
+    """datasets/depth_utils.py save_pfm / read_pfm run unmodified (numpy only): the bytes the reference writes."""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("ref_depth_utils", os.path.join(REF, "datasets", "depth_utils.py"))
+    du = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(du)
+    r = np.random.RandomState(5)
+    grey = r.uniform(0, 6, (7, 5)).astype(np.float32)
+    color = r.uniform(0, 1, (4, 6, 3)).astype(np.float32)
+    out = {"grey": grey, "color": color}
+    with tempfile.TemporaryDirectory() as d:
+        for name, img, scale in (("grey", grey, 1), ("color", color, 2.5)):
+            path = os.path.join(d, name + ".pfm")
+            du.save_pfm(path, img, scale)
+            out[name + "_bytes"] = np.frombuffer(open(path, "rb").read(), np.uint8)
+            back, sc = du.read_pfm(path)
+            out[name + "_read"] = np.ascontiguousarray(back)
+            out[name + "_scale"] = np.asarray(sc, np.float32)
+    np.savez_compressed(os.path.join(OUT, "pfm.npz"), **out)
+    print("pfm", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__" and "--pfm" in sys.argv:
+    main_pfm()

@@ -170,3 +170,79 @@ def test_render_loss_gpu_sizes_vs_oracle(n):
         assert abs(got[k].item() - st[k]) <= 2e-6 * abs(st[k]) + 1e-5 * (k == "psnr_fine"), k
     for k, v in tres.items():
         assert np.abs(v.grad.cpu().numpy() - 3.0 * gr[k]).max() <= 3e-6 * np.abs(3.0 * gr[k]).max(), k
+
+
+# ------------------------------------------------------------------------------------- eval-side formats / callers
+def test_pfm_bytes_match_reference(tmp_path):
+    """save_pfm writes byte-for-byte what datasets/depth_utils.py:46-74 writes (tests/golden/pfm.npz, gen_golden.py --pfm)
+    and read_pfm returns what :6-43 returns."""
+    from sinnerf_amd.evalio import read_pfm, save_pfm
+    z = np.load(f"{GOLDEN}/pfm.npz")
+    for name, scale in (("grey", 1), ("color", 2.5)):
+        path = os.path.join(tmp_path, name + ".pfm")
+        save_pfm(path, z[name], scale)
+        assert np.array_equal(np.frombuffer(open(path, "rb").read(), np.uint8), z[name + "_bytes"]), name
+        back, sc = read_pfm(path)
+        assert np.array_equal(back, z[name + "_read"]) and np.array_equal(back, z[name]) and sc == float(z[name + "_scale"])
+    with pytest.raises(Exception):
+        save_pfm(os.path.join(tmp_path, "x.pfm"), z["grey"].astype(np.float64))
+    open(os.path.join(tmp_path, "bad.pfm"), "wb").write(b"P6\n1 1\n255\n")
+    with pytest.raises(Exception):
+        read_pfm(os.path.join(tmp_path, "bad.pfm"))
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """to_uint8 = eval.py:182; the PNG is decoded back with a stdlib-only reader (zlib + filter 0)."""
+    import struct
+    import zlib
+    from sinnerf_amd.evalio import save_png, to_uint8
+    img = np.random.RandomState(0).uniform(-0.001, 1.001, (9, 13, 3)).astype(np.float32)
+    u8 = to_uint8(np.clip(img, 0, 1))
+    assert np.array_equal(u8, (np.clip(img, 0, 1) * 255).astype(np.uint8))
+    path = os.path.join(tmp_path, "a.png")
+    save_png(path, u8)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xFFFFFFFF
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        if tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert hdr == (13, 9, 8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(9, 1 + 13 * 3)
+    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(9, 13, 3), u8)
+
+
+@pytest.mark.gpu
+def test_render_frame_eval_driver_vs_oracle(tmp_path):
+    """eval.py:152-189 for one pose through render_frame: GPU ray generation + batched_inference; image / depth against the
+    oracle render of the same rays; files written in the reference's formats."""
+    import sinnerf_amd
+    from sinnerf_amd.evalio import read_pfm, render_frame, save_pfm, save_png, to_uint8
+    from tests.helpers import check_render
+    from tests.test_parity_gpu import embeddings, make_model
+    mc, pc = make_model(0, True)
+    mf, pf = make_model(1, True)
+    H, W = 20, 30
+    rays_np = O.lego_rays(H, W, seed=3)                                      # radius-4 pose looking at the origin
+    ref = O.render_rays([pc, pf], rays_np, 64, False, 0, 0, 64, 1 << 19, True, False)
+    res = sinnerf_amd.evalio.batched_inference([mc, mf], embeddings(), torch.from_numpy(rays_np).cuda(), 64, 64, False, 1024, True)
+    check_render({k: v.cpu().numpy() for k, v in res.items()}, ref, tag="batched_inference")
+    img = res["rgb_fine"].view(H, W, 3).cpu().numpy()
+    depth = np.nan_to_num(res["depth_fine"].view(H, W).cpu().numpy())
+    save_png(os.path.join(tmp_path, "000.png"), to_uint8(np.clip(img, 0, 1)))
+    save_pfm(os.path.join(tmp_path, "depth_000.pfm"), depth)
+    back, _ = read_pfm(os.path.join(tmp_path, "depth_000.pfm"))
+    assert np.array_equal(back, depth)
+    # render_frame = the same with rays generated on the GPU from (c2w, focal)
+    z = np.load(f"{GOLDEN}/rays.npz")
+    Hh, Ww = int(z["H"]), int(z["W"])
+    img2, depth2, res2 = render_frame([mc, mf], embeddings(), z["c2w"], Hh, Ww, float(z["focal"]), float(z["near"]), float(z["far"]))
+    ref2 = O.render_rays([pc, pf], z["rays"], 64, False, 0, 0, 64, 1 << 19, True, False)
+    assert img2.shape == (Hh, Ww, 3) and depth2.shape == (Hh, Ww)
+    assert np.abs(img2.reshape(-1, 3) - ref2["rgb_fine"]).max() <= 2e-3
