@@ -165,6 +165,26 @@ def main():
             res["cpu_baseline"] = {"value": sample.shape[0] / cdt, "unit": "rays/s", "cores": ncpu, "kind": "port",
                                    "sample": "%d rays of the same frame, numpy/OpenBLAS oracle (oracle/oracle_np.py), "
                                              "%.1f s" % (sample.shape[0], cdt)}
+        if world == 1 and not args.no_cpu_baseline:
+            # the same algorithm as stock PyTorch-ROCm eager ops on this GPU (oracle/torch_ref.py, fp32, no_grad): the
+            # "reference on the MI355X" figure SURVEY §8d asks for beside the CPU baseline.  Reported, never the target.
+            try:
+                from oracle import torch_ref as T
+                tp = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p in params]
+                er = rays[:: max(1, n_rays // 16384)][:16384].contiguous()
+                with torch.no_grad():
+                    T.render(tp, er[:1024], NS, NI, True)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(0, er.shape[0], 4096):
+                        T.render(tp, er[i:i + 4096], NS, NI, True)
+                    torch.cuda.synchronize()
+                edt = time.perf_counter() - t1
+                res["torch_eager_gpu_baseline"] = {"value": er.shape[0] / edt, "unit": "rays/s", "kind": "port",
+                                                   "sample": "%d rays of the same frame in chunks of 4096, stock torch fp32 ops on the same MI355X" % er.shape[0],
+                                                   "speedup_of_value": value / (er.shape[0] / edt)}
+            except Exception as e:                      # noqa: BLE001
+                res["torch_eager_gpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
