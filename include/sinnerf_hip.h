@@ -72,8 +72,9 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
                    int sigma_only, int flags, float* out, void* stream);
 
 /* ---- training forward: sn_mlp_forward + the activations autograd would keep alive --------------
- * slot_rows >= n_points = rows allocated per slot (callers round it up to a multiple of 16 and zero the pad rows so
- * that sn_dw_gemm can walk whole 16-point chunks).
+ * slot_rows = rows allocated per slot, >= n_points rounded up to a multiple of 128: the kernel stores whole 128-point
+ * tiles without a predicate (rows >= n_points receive finite copies of the last point; their gradients are zero, so
+ * sn_dw_gemm, which walks whole 16-point chunks, ignores them).
  * acts (10, slot_rows, 256): slots 0..7 = outputs of xyz_encoding_1..8 (post-ReLU), 8 = xyz_encoding_final,
  * 9 = dir_encoding output (128 wide, leading dimension 256).  emb (slot_rows, 128), ZERO-FILLED by the caller:
  * the kernel writes columns [0,63) = Embedding(xyz) and [64,91) = Embedding(dir) in the reference's column
@@ -85,7 +86,8 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
  * blob_bwd: transposed-weight blob (sn_build_pack_table_bwd).  out_raw / g_raw (n_points,4): forward output and its
  * gradient.  Writes g_acts (10, slot_rows, 256): slots 0..7 = dL/d(pre-activation) of xyz_encoding_1..8, 8 = of
  * xyz_encoding_final, 9 = of dir_encoding (128 wide); g_out (n_points,4) = dL/d(pre-activation) of rgb (3), sigma (1).
- * Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.   */
+ * slot_rows as for sn_mlp_forward_train (>= n_points rounded up to 128; rows >= n_points of slots' 256 columns are
+ * written as zeros, the caller zero-fills the rest of the pad rows).  Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.   */
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream);
 

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsinnerf_hip.so")
+# SINNERF_HIP_LIB: developer override used by tools/ to time experimental builds of the same ABI
+LIB_PATH = os.environ.get("SINNERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libsinnerf_hip.so")
 
 SN_DTYPE_F32 = 0
 SN_DTYPE_BF16 = 1

@@ -109,10 +109,8 @@ class _MLPFn(torch.autograd.Function):
         dev = rays.device
         code = dtype_code(model.compute_dtype)
         out = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
-        rows = -(-P // _KB) * _KB                      # sn_dw_gemm walks whole 16-point chunks: pad rows are zero
-        acts = torch.empty((10, rows, 256), dtype=torch.float32, device=dev)
-        if rows > P:
-            acts[:, P:].zero_()
+        rows = -(-P // 128) * 128                      # the training forward stores whole 128-point tiles (pad rows: finite
+        acts = torch.empty((10, rows, 256), dtype=torch.float32, device=dev)   # copies of the last point, zero gradient)
         emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
         _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                                  _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),

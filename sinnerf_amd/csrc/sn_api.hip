@@ -141,14 +141,17 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
                          float* out, float* acts, float* emb, long slot_rows, void* stream) {
   if (!blob || !rays || !z_vals || !out || !acts || !emb || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
-  return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, 0, 0, 1, out, acts, emb,
-                                   slot_rows, (hipStream_t)stream);
+  const long n_points = n_rays * (long)n_samples;
+  if (slot_rows < (n_points + 127) / 128 * 128) return SN_E_BADSHAPE;      // whole 128-point tiles are stored
+  return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, 1, out, acts, emb, slot_rows,
+                                   (hipStream_t)stream);
 }
 
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream) {
   if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
+  if (slot_rows < (n_points + 127) / 128 * 128) return SN_E_BADSHAPE;      // whole 128-point tiles are written
   return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
                                           (hipStream_t)stream);
 }
