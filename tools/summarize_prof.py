@@ -53,7 +53,37 @@ if f and w:
     out["traffic"] = {"kernel": "mlp_fwd_f32_kernel fine pass", "points": POINTS, "fetch_bytes": fetch,
                       "fetch_bytes_2x_corrected": 2 * fetch, "write_bytes": write, "hbm_bytes": 2 * fetch + write,
                       "algorithmic_bytes": POINTS * 20}
+# dynamic instruction mix of the fused MLP kernels (wave-level instruction counts summed over the launch)
+mix = {}
+for dt in ("fp32", "bf16"):
+    p = f"{src}/mix_{dt}_counter_collection.csv"
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(float)
+    for r in csv.DictReader(open(p)):
+        if "mlp_fwd" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+    if agg.get("SQ_INSTS_MFMA"):
+        other = agg["SQ_INSTS_VALU"] - agg["SQ_INSTS_MFMA"] + agg["SQ_INSTS_SALU"] + agg["SQ_INSTS_LDS"]
+        mix[dt] = dict(agg, non_mfma_valu_per_mfma=(agg["SQ_INSTS_VALU"] - agg["SQ_INSTS_MFMA"]) / agg["SQ_INSTS_MFMA"],
+                       salu_per_mfma=agg["SQ_INSTS_SALU"] / agg["SQ_INSTS_MFMA"], lds_per_mfma=agg["SQ_INSTS_LDS"] / agg["SQ_INSTS_MFMA"],
+                       other_per_mfma_excl_vmem=other / agg["SQ_INSTS_MFMA"])
+if mix:
+    out["instruction_mix"] = mix
+p = f"{src}/pmc1_bf16_counter_collection.csv"
+if os.path.exists(p):
+    b = collections.defaultdict(dict)
+    for r in csv.DictReader(open(p)):
+        if "mlp_fwd" in r["Kernel_Name"]:
+            k = int(r["Dispatch_Id"])
+            b[k]["dur_ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            b[k][r["Counter_Name"]] = float(r["Counter_Value"])
+    if b:
+        v = max(b.values(), key=lambda x: x["dur_ms"])
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        out["fine_pass_sq_bf16"] = {"dur_ms": v["dur_ms"], "clock_ghz": cyc / (v["dur_ms"] * 1e6),
+                                    "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc}
 json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 if "traffic" in out:
     json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json"), open("profiles/pmc_traffic.json", "w"), indent=1)
-print(json.dumps(out, indent=1)[:3500])
+print(json.dumps({k: v for k, v in out.items() if k != "dispatches"}, indent=1)[:5000])
