@@ -13,6 +13,7 @@
 // Per point tile: 290 x 32 MFMAs of 64 cycles (289.75 algorithmic: only the 63->64 input pad) -> MFMA-bound by
 // construction (fp32 roofline 157.3 TF).  The 1-row sigma and 3-row rgb heads run on the VALU from registers.
 #include "sn_mlp_pipe.h"
+#include <type_traits>
 
 namespace snk {
 
@@ -58,15 +59,22 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                               // slabs 0,1 + bias/aux table visible
 
+  asm volatile("" ::: "a0", "a255");             // size the kernel for the whole hand-managed AGPR file (sn_mlp_pipe.h)
   int cslot = 0;                                 // ring slot of the slab being consumed
   f32x4 af[2];
   af[0] = *reinterpret_cast<const f32x4*>(ring.slot(0) + lane * 16);
   af[1] = *reinterpret_cast<const f32x4*>(ring.slot(0) + lane * 16 + 1024);
-  f32x16 acc = load_bias(lds_bias, 0, h);
+  f32x16 acc0 = load_bias(lds_bias, 0, h), acc1;            // the two accumulator sets (VGPRs)
   const int n_used = ring.n_used;
+  // training forward: per-wave staging tile of the activation stores (sn_mlp_pipe.h XPOSE_*)
+  char* const xp = smem + MLP_F32_LDS_BYTES_V2 + wave * XPOSE_WAVE_BYTES;
+  const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;                       // this lane's register quads
+  const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;    // row lane>>3, 16-byte chunk lane&7
+  const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-  const long p_raw = (tile * 4 + wave) * 32 + j;
+  const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * 32;       // wave-uniform, in SGPRs
+  const long p_raw = p_wave + j;
   const bool valid = p_raw < P;
   const long p = valid ? p_raw : P - 1;
 
@@ -83,203 +91,209 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     embed_xyz(x, y, z, h, xe);
   } else {
     const float* row = in0 + p * (long)S;        // S = leading dimension here
+    int hh = h;
+    asm volatile("" : "+v"(hh));                 // keep the 32 column selects inside the tile loop (else hoisted: +32 VGPRs)
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
       const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
-      const int c = h ? c1 : c0;
+      const int c = hh ? c1 : c0;
       xe[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
     }
   }
-  if (STORE && valid) {
+  if (STORE) {                                   // rows are allocated for whole 128-point tiles: no predicate
     float* er = emb + p_raw * 128;               // caller zero-fills emb: pad columns 63, 91..127 stay 0
+    int hh = h;
+    asm volatile("" : "+v"(hh));                 // column selects stay inside the tile loop (hoisted they cost 32 VGPRs)
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
       const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
-      const int c = h ? c1 : c0;
+      const int c = hh ? c1 : c0;
       if (c >= 0) er[c] = xe[e];
     }
   }
 
   int s = 0;                                     // slab id being consumed
-  float hid[128], nxt[128];
-  f32x16 pacc, acc_pre;
+  float sg = 0.0f;                               // sigma head partial of this lane half (nerf.py:136), K-slot order
 
-  // Epilogue slices: slice q (0..3) finalises accumulator registers 4q..4q+3 of an output tile = features 32t+8q+4h+(0..3),
-  // i.e. exactly one 16-byte store of the row-major activation matrix in the training variant.
-  auto store_slice = [&](int slot, int t, int q, const float* v) {
-    if (STORE && valid) {
-      float4 o;
-      o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-      *reinterpret_cast<float4*>(acts + ((long)slot * slot_rows + p_raw) * 256 + 32 * t + 4 * h + 8 * q) = o;
+  // ---- epilogue slices.  Slice q (0..3) finalises accumulator registers 4q..4q+3 of output tile t (features
+  // 32t+8q+4h+(0..3)) and writes them as K-slots 16t+4q+(0..3) of activation set W.
+  // training forward: the slice's four values also go to the wave's staging tile; store_rows(i) later writes row group i
+  // (8 points x 128 B) of the staged 32-point x 32-feature tile to acts[slot][point][32t..32t+31], non-temporal (5 GB of
+  // write-once data must not evict the L2-resident weight blob).
+  auto stage = [&](int q, const float (&v)[4]) __attribute__((always_inline)) {
+    if (STORE) {
+      f32x4 o;
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+      *reinterpret_cast<f32x4*>(xp + xp_w + 32 * q) = o;
     }
   };
-  auto relu_slice = [&](int slot, int t, int q, const f32x16& a) {
-#pragma unroll
-    for (int r = 4 * q; r < 4 * q + 4; ++r) nxt[16 * t + r] = relu1(a[r]);   // one v_max_f32; the asm also pins it here
-    store_slice(slot, t, q, nxt + 16 * t + 4 * q);
+  auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) {
+    if (STORE) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
+      // wave-uniform 64-bit base (SALU) + one 32-bit per-lane offset, kept opaque: hipcc otherwise precomputes a 64-bit
+      // VGPR address per slot and runs out of registers
+      const char* base = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + p_wave + 8 * i) * 256 + 32 * t) * 4;
+      unsigned go = g_off;
+      asm volatile("" : "+v"(go));               // opaque per store: no hoisted per-slot address registers
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
+    }
   };
-  auto relu_tile = [&](int slot, int t, const f32x16& a) {                    // un-overlapped form (last tile of a layer)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) relu_slice(slot, t, q, a);
+  auto relu_slice = [&](auto wset, int slot, int t, int q, const f32x16& r) __attribute__((always_inline)) {
+    constexpr int W = decltype(wset)::value;
+    float v[4];
+    epi32_relu(W * 128 + 16 * t + 4 * q, r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3], v);
+    if (slot == 7) {                             // layer 8 feeds the sigma head: same accumulation order as a K-slot sweep
+      const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t + 4 * q);
+      sg = __builtin_fmaf(w[0], v[0], sg);
+      sg = __builtin_fmaf(w[1], v[1], sg);
+      sg = __builtin_fmaf(w[2], v[2], sg);
+      sg = __builtin_fmaf(w[3], v[3], sg);
+      asm volatile("" : "+v"(sg));
+    }
+    stage(q, v);
+  };
+  auto copy_slice = [&](auto wset, int slot, int t, int q, const f32x16& r) __attribute__((always_inline)) {   // xyz_encoding_final
+    constexpr int W = decltype(wset)::value;
+    epi32_copy(W * 128 + 16 * t + 4 * q, r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    const float v[4] = {r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+    stage(q, v);
   };
 #define SN_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SN_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
-#define SN_ADVANCE() do { pacc = acc; acc = acc_pre; ++s; cslot = (cslot == 2) ? 0 : cslot + 1; } while (0)
-
-  // NP argument of each slab = 4 KB pieces of the slab staged at its sync point = the slab TWO ahead in the stream:
-  // K/32 -> 2 (xyz_encoding_1), 8 (256-wide), 10 (skip), 9 (dir_encoding).
-#define SN_SLAB(NG0_, NG1_, GB_, NP_, B0_, B1_, PEND_)                                                               \
-  do {                                                                                                              \
-    slab_f32<NG0_, NG1_, GB_, NP_>(acc, af, acc_pre, SN_LW_CUR, B0_, B1_, SN_LW_NEXT, lds_bias,                      \
-                                   (s + 1 == n_used ? 0 : s + 1), h, ring, PEND_);                                   \
-    SN_ADVANCE();                                                                                                   \
+#define SN_W(W_) std::integral_constant<int, W_>{}
+  // slab of output tile T_ (literal: it ends up in asm immediates and selects the accumulator set) of layer slot SLOT_;
+  // EPI_ = the previous tile's epilogue into activation set W_.  NP_ = 4 KB pieces of the slab staged at its sync point =
+  // the slab TWO ahead in the stream: K/32 -> 2 (xyz_encoding_1), 8 (256-wide), 10 (skip), 9 (dir_encoding).
+#define SN_SLAB(T_, NG0_, NG1_, S0_, S1_, GB_, NP_, BV_, EPI_, W_, SLOT_)                                          \
+  do {                                                                                                             \
+    if (((T_) & 1) == 0)                                                                                           \
+      slab_f32a<NG0_, NG1_, S0_, S1_, GB_, NP_>(acc0, acc1, af, SN_LW_CUR, BV_, SN_LW_NEXT, lds_bias,              \
+          (s + 1 == n_used ? 0 : s + 1), h, ring,                                                                  \
+          [&](int q) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SN_W(W_), SLOT_, (T_) - 1, q, acc1); },   \
+          [&](int i) __attribute__((always_inline)) { if ((T_) > 0) store_rows(SLOT_, (T_) - 1, i); });            \
+    else                                                                                                           \
+      slab_f32a<NG0_, NG1_, S0_, S1_, GB_, NP_>(acc1, acc0, af, SN_LW_CUR, BV_, SN_LW_NEXT, lds_bias,              \
+          (s + 1 == n_used ? 0 : s + 1), h, ring,                                                                  \
+          [&](int q) __attribute__((always_inline)) { EPI_(SN_W(W_), SLOT_, (T_) - 1, q, acc0); },                 \
+          [&](int i) __attribute__((always_inline)) { store_rows(SLOT_, (T_) - 1, i); });                          \
+    ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
+  } while (0)
+  // the 8 output tiles of a layer; tiles 6,7 stage the NEXT layer's slabs (NPB_); the last tile's epilogue is not deferred
+#define SN_LAYER(NG0_, NG1_, S0_, S1_, GB_, NPA_, NPB_, BV_, EPI_, W_, SLOT_)   \
+  do {                                                                          \
+    SN_SLAB(0, NG0_, NG1_, S0_, S1_, GB_, NPA_, BV_, EPI_, W_, SLOT_);          \
+    SN_SLAB(1, NG0_, NG1_, S0_, S1_, GB_, NPA_, BV_, EPI_, W_, SLOT_);          \
+    SN_SLAB(2, NG0_, NG1_, S0_, S1_, GB_, NPA_, BV_, EPI_, W_, SLOT_);          \
+    SN_SLAB(3, NG0_, NG1_, S0_, S1_, GB_, NPA_, BV_, EPI_, W_, SLOT_);          \
+    SN_SLAB(4, NG0_, NG1_, S0_, S1_, GB_, NPA_, BV_, EPI_, W_, SLOT_);          \
+    SN_SLAB(5, NG0_, NG1_, S0_, S1_, GB_, NPA_, BV_, EPI_, W_, SLOT_);          \
+    SN_SLAB(6, NG0_, NG1_, S0_, S1_, GB_, NPB_, BV_, EPI_, W_, SLOT_);          \
+    SN_SLAB(7, NG0_, NG1_, S0_, S1_, GB_, NPB_, BV_, EPI_, W_, SLOT_);          \
+    mfma32_result_fence();                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) EPI_(SN_W(W_), SLOT_, 7, q_, acc1);   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) store_rows(SLOT_, 7, i_);  \
   } while (0)
 
-  // ---- layer 0: xyz_encoding_1  (nerf.py:68)
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    auto pend = [&](int q) { if (t > 0) relu_slice(0, t - 1, q, pacc); };
-    if (t < 6) SN_SLAB(8, 0, 2, 2, xe, xe, pend); else SN_SLAB(8, 0, 2, 8, xe, xe, pend);
-  }
-  relu_tile(0, 7, pacc);
-#pragma unroll
-  for (int i = 0; i < 128; ++i) hid[i] = nxt[i];
+  // ---- layer 0: xyz_encoding_1 (nerf.py:68): reads the xyz embedding (VGPRs), writes set 0
+  SN_LAYER(8, 0, -1, -1, 2, 2, 8, xe, relu_slice, 0, 0);
 
-  // ---- layers 1..7: xyz_encoding_2..8, skip concat at layer 4 (nerf.py:70,132-134)
+  // ---- layers 1..7: xyz_encoding_2..8, skip concat at layer 4 (nerf.py:70,132-134).  Odd layers read set 0 and write
+  //      set 1, even layers the reverse.
 #pragma unroll 1
   for (int l = 1; l < 8; ++l) {
     if (l == 4) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        auto pend = [&](int q) { if (t > 0) relu_slice(l, t - 1, q, pacc); };
-        if (t < 6) SN_SLAB(8, 32, 4, 10, xe, hid, pend); else SN_SLAB(8, 32, 4, 8, xe, hid, pend);
-      }
+      SN_LAYER(8, 32, -1, 1, 4, 10, 8, xe, relu_slice, 0, 4);
+    } else if (l == 7) {
+      if (SIGMA_ONLY) SN_LAYER(32, 0, 0, 0, 4, 8, 2, xe, relu_slice, 1, 7);     // tiles 6,7 stage the next point tile's layer 0
+      else SN_LAYER(32, 0, 0, 0, 4, 8, 8, xe, relu_slice, 1, 7);
+    } else if (l == 3) {
+      SN_LAYER(32, 0, 0, 0, 4, 8, 10, xe, relu_slice, 1, 3);                    // ... the skip layer's slabs
+    } else if (l == 1) {
+      SN_LAYER(32, 0, 0, 0, 4, 8, 8, xe, relu_slice, 1, 1);
+    } else if (l == 5) {
+      SN_LAYER(32, 0, 0, 0, 4, 8, 8, xe, relu_slice, 1, 5);
+    } else if (l == 2) {
+      SN_LAYER(32, 0, 1, 1, 4, 8, 8, xe, relu_slice, 0, 2);
     } else {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        auto pend = [&](int q) { if (t > 0) relu_slice(l, t - 1, q, pacc); };
-        if (t < 6) {
-          SN_SLAB(32, 0, 4, 8, hid, hid, pend);
-        } else if (l == 3) {                      // the slab two ahead belongs to the skip layer
-          SN_SLAB(32, 0, 4, 10, hid, hid, pend);
-        } else if (SIGMA_ONLY && l == 7) {        // ... or to xyz_encoding_1 of the next tile
-          SN_SLAB(32, 0, 4, 2, hid, hid, pend);
-        } else {
-          SN_SLAB(32, 0, 4, 8, hid, hid, pend);
-        }
-      }
+      SN_LAYER(32, 0, 1, 1, 4, 8, 8, xe, relu_slice, 0, 6);
     }
-    relu_tile(l, 7, pacc);
-#pragma unroll
-    for (int i = 0; i < 128; ++i) hid[i] = nxt[i];
   }
 
-  // ---- sigma head (nerf.py:136) on the VALU: this lane half's 128 K-slots, then one cross-half add
-  float sigma;
-  {
-    const f32x4* ws = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128);
-    float sg = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) {
-      const f32x4 w = ws[q];
-      sg = __builtin_fmaf(w[0], hid[4 * q + 0], sg);
-      sg = __builtin_fmaf(w[1], hid[4 * q + 1], sg);
-      sg = __builtin_fmaf(w[2], hid[4 * q + 2], sg);
-      sg = __builtin_fmaf(w[3], hid[4 * q + 3], sg);
-    }
-    sigma = sg + __shfl_xor(sg, 32, 64) + lds_aux[snl::AUX_HEADB];
-  }
+  // ---- sigma head (nerf.py:136): accumulated in layer 8's epilogues; one cross-half add
+  const float sigma = sg + __shfl_xor(sg, 32, 64) + lds_aux[snl::AUX_HEADB];
   if (SIGMA_ONLY) {
     if (valid && h == 0) out[p_raw] = sigma;
     continue;
   }
 
-  // ---- xyz_encoding_final (nerf.py:140), no activation
-  auto copy_slice = [&](int slot, int t, int q, const f32x16& a) {
-#pragma unroll
-    for (int r = 4 * q; r < 4 * q + 4; ++r) {
-      float v = a[r];
-      asm volatile("" : "+v"(v));
-      nxt[16 * t + r] = v;
-    }
-    store_slice(slot, t, q, nxt + 16 * t + 4 * q);
-  };
-  auto copy_tile = [&](int slot, int t, const f32x16& a) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) copy_slice(slot, t, q, a);
-  };
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    auto pend = [&](int q) { if (t > 0) copy_slice(8, t - 1, q, pacc); };
-    if (t < 6) SN_SLAB(32, 0, 4, 8, hid, hid, pend); else SN_SLAB(32, 0, 4, 9, hid, hid, pend);    // tiles 6,7 stage dir_encoding
-  }
-  copy_tile(8, 7, pacc);
-#pragma unroll
-  for (int i = 0; i < 128; ++i) hid[i] = nxt[i];
+  // ---- xyz_encoding_final (nerf.py:140), no activation: reads set 1, writes set 0
+  SN_LAYER(32, 0, 1, 1, 4, 8, 9, xe, copy_slice, 0, 8);
 
-  // ---- dir_encoding + ShiftedSoftplus (nerf.py:142-143).  The 32-slot direction embedding is built here, not in the
-  // prologue, so that it does not occupy 16 registers through the trunk.
+  // ---- dir_encoding + ShiftedSoftplus (nerf.py:142-143): reads set 0 and the dir embedding (VGPRs).  The 32-slot direction
+  // embedding is built here, not in the prologue, so that it does not occupy 16 registers through the trunk.
   float de[16];
   if (INPUT_MODE == 0) {
     const float* rp = in0 + (p / S) * 8;
     embed_dir(rp[3], rp[4], rp[5], h, de);
   } else {
     const float* row = in0 + p * (long)S;
+    int hh = h;
+    asm volatile("" : "+v"(hh));
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
-      const int c = h ? c1 : c0;
+      const int c = hh ? c1 : c0;
       de[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
     }
   }
-  if (STORE && valid) {
+  if (STORE) {
     float* er = emb + p_raw * 128;
+    int hh = h;
+    asm volatile("" : "+v"(hh));
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
-      const int c = h ? c1 : c0;
+      const int c = hh ? c1 : c0;
       if (c >= 0) er[64 + c] = de[e];
     }
   }
-  float h2[64];
-  auto ssp_slice = [&](int t, int q, const f32x16& a) {
+  // rgb head (nerf.py:144) accumulated from the softplus outputs while they are produced: 3 rows x this half's 64 K-slots
+  float c3[3] = {0.0f, 0.0f, 0.0f};
+  auto ssp_slice = [&](auto, int, int t, int q, const f32x16& r) __attribute__((always_inline)) {
+    float v[4];
 #pragma unroll
-    for (int r = 4 * q; r < 4 * q + 4; ++r) h2[16 * t + r] = shifted_softplus_fast(a[r]);
-    store_slice(9, t, q, h2 + 16 * t + 4 * q);
-  };
-  auto ssp_tile = [&](int t, const f32x16& a) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ssp_slice(t, q, a);
-  };
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    auto pend = [&](int q) { if (t > 0) ssp_slice(t - 1, q, pacc); };
-    if (t < 2) SN_SLAB(32, 4, 4, 9, hid, de, pend); else SN_SLAB(32, 4, 4, 2, hid, de, pend);       // tiles 2,3 stage the next tile's layer 0
-  }
-  ssp_tile(3, pacc);
-
-  // ---- rgb + WidenedSigmoid (nerf.py:144) on the VALU: 3 rows x this half's 64 K-slots, cross-half add
-  {
-    float c3[3];
+    for (int i = 0; i < 4; ++i) v[i] = shifted_softplus_fast(r[4 * q + i]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const f32x4* wr = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_RGBW + c * 128 + h * 64);
-      float a = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const f32x4 w = wr[q];
-        a = __builtin_fmaf(w[0], h2[4 * q + 0], a);
-        a = __builtin_fmaf(w[1], h2[4 * q + 1], a);
-        a = __builtin_fmaf(w[2], h2[4 * q + 2], a);
-        a = __builtin_fmaf(w[3], h2[4 * q + 3], a);
-      }
-      c3[c] = a + __shfl_xor(a, 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_RGBW + c * 128 + h * 64 + 16 * t + 4 * q);
+      c3[c] = __builtin_fmaf(w[0], v[0], c3[c]);
+      c3[c] = __builtin_fmaf(w[1], v[1], c3[c]);
+      c3[c] = __builtin_fmaf(w[2], v[2], c3[c]);
+      c3[c] = __builtin_fmaf(w[3], v[3], c3[c]);
     }
+    asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
+    stage(q, v);
+  };
+  SN_SLAB(0, 32, 4, 0, -1, 4, 9, de, ssp_slice, 0, 9);
+  SN_SLAB(1, 32, 4, 0, -1, 4, 9, de, ssp_slice, 0, 9);
+  SN_SLAB(2, 32, 4, 0, -1, 4, 2, de, ssp_slice, 0, 9);          // tiles 2,3 stage the next point tile's layer 0
+  SN_SLAB(3, 32, 4, 0, -1, 4, 2, de, ssp_slice, 0, 9);
+  mfma32_result_fence();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ssp_slice(SN_W(0), 9, 3, q, acc1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_rows(9, 3, i);
+
+  // ---- WidenedSigmoid (nerf.py:144) of the three cross-half sums
+  {
+    float o3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o3[c] = c3[c] + __shfl_xor(c3[c], 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c];
     if (valid && h == 0) {
       float4 o;
-      o.x = widened_sigmoid(c3[0]);
-      o.y = widened_sigmoid(c3[1]);
-      o.z = widened_sigmoid(c3[2]);
+      o.x = widened_sigmoid(o3[0]);
+      o.y = widened_sigmoid(o3[1]);
+      o.z = widened_sigmoid(o3[2]);
       o.w = sigma;                               // cat([rgb, sigma]) nerf.py:146
       reinterpret_cast<float4*>(out)[p_raw] = o;
     }
@@ -288,8 +302,9 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing may still be landing in LDS when the workgroup retires
 #undef SN_LW_CUR
 #undef SN_LW_NEXT
-#undef SN_ADVANCE
+#undef SN_W
 #undef SN_SLAB
+#undef SN_LAYER
 }
 
 }  // namespace snk
@@ -303,12 +318,12 @@ extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, con
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
   const bool store = acts != nullptr;
-  if (store && (sigma_only || input_mode != 0 || emb == nullptr || slot_rows < n_points)) return -1;
+  if (store && (sigma_only || input_mode != 0 || emb == nullptr || slot_rows < tiles * 128)) return -1;
   // persistent launch: one workgroup per CU (the 135 KB LDS ring admits exactly one), each walks tiles b, b+grid, ...
   int dev = 0, n_cu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
   dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
-  const size_t lds = MLP_F32_LDS_BYTES_V2;
+  const size_t lds = MLP_F32_LDS_BYTES_V2 + (store ? XPOSE_LDS_BYTES : 0);
   const char* b = reinterpret_cast<const char*>(blob);
 #define SN_LAUNCH(SO, IM, ST)                                                                                    \
   do {                                                                                                           \

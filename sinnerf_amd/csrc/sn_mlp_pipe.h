@@ -24,6 +24,12 @@ namespace snk {
 constexpr int TAIL_LDS_BYTES = 12544;                       // biases + aux head table (12320 B), padded
 constexpr int RING_SLOT_BYTES = snl::MAX_SLAB_K * 128;      // 40960
 constexpr int MLP_F32_LDS_BYTES_V2 = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES;   // 135424
+// Training forward: per-wave staging tile that turns the accumulator layout (lane = point, 4 consecutive features per
+// register quad -> a 16-byte access per lane with a 1 KB lane stride, 64 cache lines per store instruction) into row
+// accesses (8 lanes x 16 B = the 128 contiguous bytes one point owns in a 32-feature tile, 8 rows per instruction).
+constexpr int XPOSE_PITCH = 36;                              // floats per point row (32 + 4: conflict-free b128 both ways)
+constexpr int XPOSE_WAVE_BYTES = 32 * XPOSE_PITCH * 4;       // 4608
+constexpr int XPOSE_LDS_BYTES = 4 * XPOSE_WAVE_BYTES;        // 18432
 
 template <int BYTES_PER_K, int SLOT_BYTES>
 struct RingT {
@@ -99,46 +105,78 @@ struct RingT {
 };
 typedef RingT<128, RING_SLOT_BYTES> Ring;          // fp32 weights: 128 B per K per 32-row tile
 
-// One slab: NG0 + NG1 groups of 4 k-steps (two K segments with B operands b0 / b1), barrier after group GB.
-//   acc      in: bias-initialised accumulator of this slab; out: its result (bias + W.x)
-//   a_cur    in: first A fragment of this slab (prefetched by the previous slab); out: first fragment of the next slab
-//   acc_pre  out: bias of slab s_next (requested right after the sync point, consumed by the next slab)
-//   pending  run after the first group's MFMAs are issued (the previous slab's epilogue)
-// One dependent accumulator chain: measured on MI355X (tools/ubench/mfma_chain.hip) a dependent v_mfma_f32_32x32x2 chain
-// with a ds_read_b128 + s_waitcnt every 4 MFMAs and a barrier every 32 sustains 152 TF from one wave per SIMD, the same as
-// two interleaved chains -- so no second accumulator is spent.
-// Issue discipline (measured with an MFMA-duplication experiment: every extra v_mfma costs exactly 64.2 cycles, and a
-// FIXED ~1170 cycles per slab were lost on top): the wave issues in order, so a gap between two MFMAs hides at most the 64
-// cycles the previous MFMA executes.  All non-MFMA work of a group therefore must not sit in ONE gap: it is dealt out over
-// the four gaps of the group, each pinned with sched_barrier --
-//     MFMA0 | A-fragment prefetch | MFMA1 | one DMA piece | MFMA2 | one slice of the previous slab's epilogue | MFMA3
-// pending(i), i = 0..3: slice i (4 accumulator registers) of the previous slab's epilogue, run in groups 0..3.
-// NP = number of 4 KB pieces of the slab staged at this slab's sync point (the slab two ahead): compile-time, so a DMA
-// piece is m0 + address bump + global_load_lds with no compare/branch.
-template <int NG0, int NG1, int GB, int NP, class Pending>
-SN_DEV void slab_f32(f32x16& acc, f32x4 (&af)[2], f32x16& acc_pre, const char* lw, const float* b0, const float* b1,
-                     const char* lw_next, const float* lds_bias, int s_next, int h, Ring& ring, Pending&& pending) {
+// ---- fp32 slab, inline-asm MFMAs over a hand-managed AGPR file ------------------------------------------------------
+// hipcc keeps every builtin-MFMA accumulator in AGPRs: each VALU use of a result costs a v_accvgpr_read, each accumulator
+// hand-over a v_accvgpr_mov, and the 256 activation registers get shuffled between the two register files (v_accvgpr_write
+// + s_nop pairs) -- a third of the non-MFMA instructions of the builtin version of this kernel.  So, as in the bf16 kernel:
+//   accumulators (C/D)   architectural VGPRs, two sets used alternately by consecutive slabs (nothing is copied); the bias of
+//                        the next slab is ds_read straight into the set the previous slab vacated
+//   activations (B)      a[0:127] and a[128:255]: a layer reads its B operands from one set (MFMA reads B from AGPRs for
+//                        free) while its epilogues v_accvgpr_write the next layer's into the other; roles swap every layer.
+//                        AGPR numbers are immediates in the asm text, the compiler never sees these registers (it is told
+//                        a255 is clobbered so the kernel is sized for all 256; tools/check_agpr.py verifies the build)
+//   xyz / dir embeddings VGPRs (B operands of layer 0, the skip layer, dir_encoding)
+// One slab = NG0 + NG1 groups of 4 k-steps (two K segments), barrier after group GB.
+//   SET0/SET1  B operands of the segment: AGPR activation set 0/1 (register SET*128 + K-slot), or -1 = the VGPR array bv
+//   acc        accumulator set of this slab, bias-initialised on entry
+//   accn       the other set: the previous slab's result until pending(0..3) have consumed it (groups 0..3), then the
+//              bias of slab s_next (requested in group 4)
+//   af         A fragments of groups g, g+1 for even g: both are requested together two groups ahead (one s_waitcnt per
+//              TWO groups).  Invariant at entry / exit: af = fragments of groups 0, 1 of the slab.
+//   NP         4 KB pieces of the slab staged at this slab's sync point (the slab two ahead): compile-time, so a DMA piece
+//              is m0 + address bump + global_load_lds with no compare/branch
+// Issue discipline (measured: T = 64.2 N_mfma + 4.6 N_other, a single dependent accumulator chain hides nothing): the
+// non-MFMA work of a group is dealt over its four gaps --
+//     MFMA0 | A-fragment prefetch | MFMA1 | one DMA piece | MFMA2 | epilogue slice / activation-store step | MFMA3
+// pending(i), i = 0..3: slice i (4 accumulator registers) of the previous slab's epilogue, run in groups 0..3;
+// late(i), i = 0..3: the training forward's row-group store of that tile, run in groups 4..7.
+// The compiler does not know the asm is an MFMA: the MFMA -> VALU-read hazard (18 wait states for this 16-pass MFMA) is kept
+// by construction -- pending(0) sits behind three MFMAs of the NEXT slab, at a layer end an explicit s_nop run is used.
+// FIRST = first MFMA of a slab: its C operand may have just been written by compiler-inserted VALU copies (accumulator
+// hand-over at control-flow joins), and a VALU write -> MFMA read needs 2 wait states the compiler cannot insert for asm.
+template <bool FIRST>
+SN_DEV void mma32_a(f32x16& acc, float a, int reg) {       // D = A.B + D; D, A in VGPRs, B = a[reg]
+  if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, a[%2], %0" : "+v"(acc) : "v"(a), "n"(reg));
+  else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, a[%2], %0" : "+v"(acc) : "v"(a), "n"(reg));
+}
+template <bool FIRST>
+SN_DEV void mma32_v(f32x16& acc, float a, float b) {       // ... B in a VGPR
+  if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+SN_DEV void mfma32_result_fence() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }
+
+template <int NG0, int NG1, int SET0, int SET1, int GB, int NP, class Pending, class Late>
+SN_DEV void slab_f32a(f32x16& acc, f32x16& accn, f32x4 (&af)[2], const char* lw, const float* bv, const char* lw_next,
+                      const float* lds_bias, int s_next, int h, Ring& ring, Pending&& pending, Late&& late) {
   constexpr int NG = NG0 + NG1;
   constexpr int PPG = (NP + (NG - GB) - 1) / (NG - GB);      // DMA pieces per group after the sync point
-  static_assert(GB >= 2 && GB % 2 == 0 && GB < NG && NG % 2 == 0, "sync point inside the slab; fragments come in pairs");
-  // af[0], af[1] = A fragments of groups g, g+1 for even g: both are requested together two groups ahead (one s_waitcnt
-  // per TWO groups instead of one per group).  Invariant at entry / exit: af = fragments of groups 0, 1 of the slab.
+  static_assert(GB >= 2 && GB % 2 == 0 && GB <= 4 && NG >= 8 && NG % 2 == 0, "sync point inside the slab; fragments come in pairs");
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    const float* b = (g < NG0) ? (b0 + 4 * g) : (b1 + 4 * (g - NG0));
     if (g == GB) {                               // sync point (one longer gap per slab)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       ring.begin_static();
-      acc_pre = load_bias(lds_bias, s_next, h);
-      __builtin_amdgcn_sched_barrier(0);
     }
-    const f32x4 a_cur = af[g & 1];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[0], acc, 0, 0, 0);
+    if (g == 4) accn = load_bias(lds_bias, s_next, h);
     __builtin_amdgcn_sched_barrier(0);
+    const f32x4 a_cur = af[g & 1];
+    auto mma = [&](int kk) __attribute__((always_inline)) {
+      if (g == 0 && kk == 0) {
+        if (SET0 < 0) mma32_v<true>(acc, a_cur[0], bv[0]); else mma32_a<true>(acc, a_cur[0], SET0 * 128);
+      } else if (g < NG0) {
+        if (SET0 < 0) mma32_v<false>(acc, a_cur[kk], bv[4 * g + kk]); else mma32_a<false>(acc, a_cur[kk], SET0 * 128 + 4 * g + kk);
+      } else {
+        if (SET1 < 0) mma32_v<false>(acc, a_cur[kk], bv[4 * (g - NG0) + kk]);
+        else mma32_a<false>(acc, a_cur[kk], SET1 * 128 + 4 * (g - NG0) + kk);
+      }
+    };
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 n0, n1;
     if (g & 1) {                                 // gap 1 of odd groups: both fragments of the next pair of groups
       const int gn = g + 1;
-      f32x4 n0, n1;
       if (gn < NG) {
         n0 = *reinterpret_cast<const f32x4*>(lw + gn * 1024);
         n1 = *reinterpret_cast<const f32x4*>(lw + (gn + 1) * 1024);
@@ -147,35 +185,39 @@ SN_DEV void slab_f32(f32x16& acc, f32x4 (&af)[2], f32x16& acc_pre, const char* l
         n1 = *reinterpret_cast<const f32x4*>(lw_next + 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[1], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g >= GB) {
-#pragma unroll
-        for (int j = 0; j < PPG; ++j) if ((g - GB) * PPG + j < NP) ring.piece_static();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[2], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g < 4) pending(g);
-      __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[3], acc, 0, 0, 0);
-      af[0] = n0; af[1] = n1;
-    } else {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[1], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g >= GB) {                             // gap 2: weight DMA
-#pragma unroll
-        for (int j = 0; j < PPG; ++j) if ((g - GB) * PPG + j < NP) ring.piece_static();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[2], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g < 4) pending(g);                     // gap 3: epilogue slice of the previous slab
-      __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[3], acc, 0, 0, 0);
     }
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g >= GB) {                               // gap 2: weight DMA
+#pragma unroll
+      for (int i = 0; i < PPG; ++i) if ((g - GB) * PPG + i < NP) ring.piece_static();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mma(2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g < 4) pending(g);                       // gap 3: epilogue slice of the previous slab ...
+    else if (g < 8) late(g - 4);                 // ... then its activation-store steps (training forward)
+    __builtin_amdgcn_sched_barrier(0);
+    mma(3);
+    if (g & 1) { af[0] = n0; af[1] = n1; }
   }
   ring.template end_static<NP>();
+}
+
+// Epilogue blocks: four accumulator values -> four consecutive registers of the hand-managed AGPR file a[reg..reg+3]
+// (`reg` must fold to a constant, it is printed into the asm text).  One volatile asm per block: it keeps its program order
+// relative to the MFMA asm, and the compiler cannot pad VALU <-> asm dependences with s_nops inside it.
+SN_DEV void epi32_relu(int reg, float x0, float x1, float x2, float x3, float (&v)[4]) {     // v = relu(x) (nerf.py:73)
+  asm volatile("v_max_f32 %0, 0, %4\n\tv_max_f32 %1, 0, %5\n\tv_max_f32 %2, 0, %6\n\tv_max_f32 %3, 0, %7\n\t"
+               "v_accvgpr_write_b32 a[%8], %0\n\tv_accvgpr_write_b32 a[%9], %1\n\t"
+               "v_accvgpr_write_b32 a[%10], %2\n\tv_accvgpr_write_b32 a[%11], %3"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1), "n"(reg + 2), "n"(reg + 3));
+}
+SN_DEV void epi32_copy(int reg, float x0, float x1, float x2, float x3) {                     // no activation
+  asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%5], %1\n\t"
+               "v_accvgpr_write_b32 a[%6], %2\n\tv_accvgpr_write_b32 a[%7], %3"
+               :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1), "n"(reg + 2), "n"(reg + 3));
 }
 
 // ReLU as ONE v_max_f32 (fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max first: 2 VALU per value, and

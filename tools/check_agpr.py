@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Build check for sn_mlp_fwd_bf16.hip (run by sinnerf_amd/csrc/Makefile on the hipcc -S output).
+"""Build check for sn_mlp_fwd.hip / sn_mlp_fwd_bf16.hip (run by sinnerf_amd/csrc/Makefile on the hipcc -S output).
 
-The kernel manages the AGPR file by hand and emits its MFMAs as inline asm, so three things the compiler normally
+These kernels manage the AGPR file by hand and emit their MFMAs as inline asm, so three things the compiler normally
 guarantees are checked on the generated code instead:
   1. the compiler allocated no AGPR itself (every AGPR reference sits inside ASMSTART/ASMEND) and spilled nothing;
   2. no VALU instruction writes a register an MFMA reads within the next 2 wait states (VALU write -> MFMA read hazard);
   3. no VALU instruction reads an MFMA result before two further MFMAs (or 12 other instructions) have issued
-     (MFMA write -> VALU read hazard, 11 wait states for an 8-pass MFMA).
+     (MFMA write -> VALU read hazard: 11 wait states for the 8-pass bf16 MFMA, 18 for the 16-pass fp32 one).
 usage: check_agpr.py file.s"""
 import re, sys
 
@@ -24,7 +24,7 @@ def vregs(tok):
 
 kern = None; ina = False; ins = []; bad_agpr = []; spills = 0
 for ln, l in enumerate(open(sys.argv[1]), 1):
-    m = re.match(r'^(_Z\S*mlp_fwd_bf16\S*):', l)
+    m = re.match(r'^(_Z\S*mlp_fwd_(?:bf16|f32)_kernel\S*):', l)
     if m: kern = m.group(1); continue
     if kern is None: continue
     if re.match(r'^\s*s_endpgm', l): kern = None; continue
