@@ -189,7 +189,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
     SN_SLAB(5, NG0_, NG1_, S0_, S1_, GB_, NPA_, BV_, EPI_, W_, SLOT_);          \
     SN_SLAB(6, NG0_, NG1_, S0_, S1_, GB_, NPB_, BV_, EPI_, W_, SLOT_);          \
     SN_SLAB(7, NG0_, NG1_, S0_, S1_, GB_, NPB_, BV_, EPI_, W_, SLOT_);          \
-    mfma32_result_fence();                                                      \
+    mfma32_result_fence(acc1);                                                      \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) EPI_(SN_W(W_), SLOT_, 7, q_, acc1);   \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) store_rows(SLOT_, 7, i_);  \
   } while (0)
@@ -278,7 +278,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   SN_SLAB(1, 32, 4, 0, -1, 4, 9, de, ssp_slice, 0, 9);
   SN_SLAB(2, 32, 4, 0, -1, 4, 2, de, ssp_slice, 0, 9);          // tiles 2,3 stage the next point tile's layer 0
   SN_SLAB(3, 32, 4, 0, -1, 4, 2, de, ssp_slice, 0, 9);
-  mfma32_result_fence();
+  mfma32_result_fence(acc1);
 #pragma unroll
   for (int q = 0; q < 4; ++q) ssp_slice(SN_W(0), 9, 3, q, acc1);
 #pragma unroll

@@ -125,6 +125,8 @@ typedef RingT<128, RING_SLOT_BYTES> Ring;          // fp32 weights: 128 B per K 
 //              TWO groups).  Invariant at entry / exit: af = fragments of groups 0, 1 of the slab.
 //   NP         4 KB pieces of the slab staged at this slab's sync point (the slab two ahead): compile-time, so a DMA piece
 //              is m0 + address bump + global_load_lds with no compare/branch
+// (hipcc pads an `s_nop 0` between two dependent asm MFMAs -- ~90 per slab; bundling four MFMAs into one asm where a group's
+// gaps carry no work removes them and changes nothing measurable, so the simple form is kept.)
 // Issue discipline (measured: T = 64.2 N_mfma + 4.6 N_other, a single dependent accumulator chain hides nothing): the
 // non-MFMA work of a group is dealt over its four gaps --
 //     MFMA0 | A-fragment prefetch | MFMA1 | one DMA piece | MFMA2 | epilogue slice / activation-store step | MFMA3
@@ -144,7 +146,9 @@ SN_DEV void mma32_v(f32x16& acc, float a, float b) {       // ... B in a VGPR
   if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
-SN_DEV void mfma32_result_fence() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }
+// MFMA (16 passes) -> VALU read of its result at a layer end.  The accumulator is an operand: plain C++ arithmetic on it
+// (the softplus epilogue) could otherwise be scheduled above the wait.
+SN_DEV void mfma32_result_fence(f32x16& acc) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc)); }
 
 template <int NG0, int NG1, int SET0, int SET1, int GB, int NP, class Pending, class Late>
 SN_DEV void slab_f32a(f32x16& acc, f32x16& accn, f32x4 (&af)[2], const char* lw, const float* bv, const char* lw_next,
