@@ -72,8 +72,10 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
                    int sigma_only, int flags, float* out, void* stream);
 
 /* ---- training forward: sn_mlp_forward + the activations autograd would keep alive --------------
- * slot_rows = rows allocated per slot, >= n_points rounded up to a multiple of 128: the kernel stores whole 128-point
- * tiles without a predicate (rows >= n_points receive finite copies of the last point; their gradients are zero, so
+ * dtype SN_DTYPE_BF16 = mixed precision: bf16-operand contractions as in sn_mlp_forward, fp32 activations stored (the
+ * values before their bf16 rounding) for the fp32 backward.
+ * slot_rows = rows allocated per slot, >= n_points rounded up to a multiple of 128 (fp32) / 256 (bf16): the kernel stores
+ * whole point tiles without a predicate (rows >= n_points receive finite copies of the last point; their gradients are zero, so
  * sn_dw_gemm, which walks whole 16-point chunks, ignores them).
  * acts (10, slot_rows, 256): slots 0..7 = outputs of xyz_encoding_1..8 (post-ReLU), 8 = xyz_encoding_final,
  * 9 = dir_encoding output (128 wide, leading dimension 256).  emb (slot_rows, 128), ZERO-FILLED by the caller:

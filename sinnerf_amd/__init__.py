@@ -5,6 +5,6 @@ Drop-in names (reference: VITA-Group/SinNeRF):
   sinnerf_amd.nerf.Embedding / NeRF                <->  models/nerf.py
 """
 from .nerf import Embedding, NeRF                      # noqa: F401
-from .rendering import render_rays, sample_pdf         # noqa: F401
+from .rendering import eval_points, render_rays, sample_pdf   # noqa: F401
 
-__all__ = ["Embedding", "NeRF", "render_rays", "sample_pdf"]
+__all__ = ["Embedding", "NeRF", "render_rays", "sample_pdf", "eval_points"]

@@ -109,7 +109,8 @@ class _MLPFn(torch.autograd.Function):
         dev = rays.device
         code = dtype_code(model.compute_dtype)
         out = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
-        rows = -(-P // 128) * 128                      # the training forward stores whole 128-point tiles (pad rows: finite
+        tile = 256 if code == _lib.SN_DTYPE_BF16 else 128
+        rows = -(-P // tile) * tile                    # the training forward stores whole point tiles (pad rows: finite
         acts = torch.empty((10, rows, 256), dtype=torch.float32, device=dev)   # copies of the last point, zero gradient)
         emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
         _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
@@ -132,7 +133,7 @@ class _MLPFn(torch.autograd.Function):
             G[:, P:].zero_()
         g_o = torch.empty((P, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd()), dtype_code(model.compute_dtype),
+            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd()), _lib.SN_DTYPE_F32,     # backward is always fp32
                                                       _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")
             needs = ctx.needs_input_grad[3:]
@@ -181,8 +182,7 @@ def render_rays_autograd(models, rays, N_samples, use_disp, perturb, noise_std, 
     n = rays.shape[0]
     stream = _lib.stream_ptr()
     for m in models:
-        if dtype_code(m.compute_dtype) != _lib.SN_DTYPE_F32:
-            raise NotImplementedError("sinnerf_amd: the training (autograd) path is fp32 in this revision")
+        dtype_code(m.compute_dtype)              # 'fp32', or 'bf16' = mixed precision: bf16-operand forward, fp32 backward
     perturb_rand = torch.rand((n, N_samples), device=dev) if perturb > 0 else None
     z_vals = torch.empty((n, N_samples), dtype=torch.float32, device=dev)
     _lib.check(_lib.lib.sn_sample_coarse(_lib.ptr(rays), n, N_samples, int(bool(use_disp)), float(perturb),

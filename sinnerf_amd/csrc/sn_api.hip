@@ -20,7 +20,8 @@ int sn_render_loss_launch(const float* rgb_c, const float* rgb_f, const float* d
                           float w_rgb, float w_depth, float* g_rgb_c, float* g_rgb_f, float* g_depth_c, float* g_depth_f,
                           void* workspace, float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                               int sigma_only, int input_mode, float* out, hipStream_t stream);
+                               int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
+                               hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
                                  const float* g_depth, const float* g_w, float* g_raw, hipStream_t stream);
@@ -130,8 +131,8 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
                    int sigma_only, int flags, float* out, void* stream) {
   if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   if (dtype == SN_DTYPE_BF16)
-    return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out,
-                                      (hipStream_t)stream);
+    return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out, nullptr,
+                                      nullptr, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
                                    (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
@@ -140,9 +141,13 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                          float* out, float* acts, float* emb, long slot_rows, void* stream) {
   if (!blob || !rays || !z_vals || !out || !acts || !emb || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
-  if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
   const long n_points = n_rays * (long)n_samples;
-  if (slot_rows < (n_points + 127) / 128 * 128) return SN_E_BADSHAPE;      // whole 128-point tiles are stored
+  const long tile = dtype == SN_DTYPE_BF16 ? 256 : 128;                      // whole point tiles are stored
+  if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
+  if (dtype == SN_DTYPE_BF16)
+    return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
+                                      (hipStream_t)stream);
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, 1, out, acts, emb, slot_rows,
                                    (hipStream_t)stream);
 }
@@ -205,7 +210,7 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   if (!blob || !x || !out || n_rows < 0) return SN_E_BADARG;
   if (ld < (sigma_only ? 63 : 90)) return SN_E_BADSHAPE;
   if (dtype == SN_DTYPE_BF16)
-    return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, (hipStream_t)stream);
+    return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1,
                                    out, nullptr, nullptr, 0, (hipStream_t)stream);

@@ -44,6 +44,7 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 constexpr int PT = 2;                                       // point tiles per wave
 constexpr int RING_SLOT_BYTES_BF16 = snl::MAX_SLAB_K * 64;  // 20480
 constexpr int MLP_BF16_LDS_BYTES = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES_BF16;   // 73984
+constexpr int BF16_XPOSE_LDS_BYTES = 4 * PT * XPOSE_WAVE_BYTES;                  // training forward: staging tiles (36864)
 typedef RingT<64, RING_SLOT_BYTES_BF16> RingB;
 
 SN_DEV uint32_t pack2(float a, float b) {        // {bf16(a), bf16(b)}, RNE (asm: hipcc converts the halves separately + v_perm)
@@ -170,10 +171,14 @@ SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], con
   ring.template end_static_bytes<NBYTES>();
 }
 
-template <bool SIGMA_ONLY, int INPUT_MODE>
+// STORE: training forward with bf16 contractions -- additionally writes the fp32 activations of every layer
+// (acts[10][slot_rows][256]: the fp32 values BEFORE their bf16 rounding) and the fp32 embedded inputs (emb[slot_rows][128])
+// that the fp32 backward (sn_mlp_bwd.hip, sn_dw.hip) consumes: bf16 forward + fp32 backward, i.e. mixed precision.
+template <bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1,
-                    long P, int S, float* __restrict__ out) {
+                    long P, int S, float* __restrict__ out, float* __restrict__ acts, float* __restrict__ emb,
+                    long slot_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_bias = reinterpret_cast<float*>(smem);
   const float* lds_aux = lds_bias + snl::BIAS_FLOATS;
@@ -217,8 +222,18 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) acc0[pt] = load_bias(lds_bias, 0, h);
   const int n_used = ring.n_used;
+  // training forward: per-wave staging tiles (one per point tile) of the row-coalesced activation stores (sn_mlp_pipe.h)
+  char* const xp = smem + MLP_BF16_LDS_BYTES + wave * (PT * XPOSE_WAVE_BYTES);
+  const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
+  const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;
+  const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * (PT * 32);    // wave-uniform
+    int ht = h;
+    asm volatile("" : "+v"(ht));               // per-tile opaque copy of the lane half: keeps the embedding's frequency scales and
+                                                 // column selects from being hoisted out of the tile loop (16-32 VGPRs the training
+                                                 // variant does not have)
     long p_raw[PT], p[PT];
     bool valid[PT];
     u32x4 xe[4 * PT];                                        // [k-step][PT]
@@ -234,7 +249,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         const float x = __fadd_rn(rp[0], __fmul_rn(rp[3], zz));
         const float y = __fadd_rn(rp[1], __fmul_rn(rp[4], zz));
         const float z = __fadd_rn(rp[2], __fmul_rn(rp[5], zz));
-        embed_xyz(x, y, z, h, f);
+        embed_xyz(x, y, z, ht, f);
       } else {
         const float* row = in0 + p[pt] * (long)S;
         int hh = h;
@@ -244,6 +259,16 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
           const int c = hh ? c1 : c0;
           f[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
+        }
+      }
+      if (STORE) {                               // rows are allocated for whole 256-point tiles: no predicate
+        float* er = emb + p_raw[pt] * 128;       // caller zero-fills emb: pad columns 63, 91..127 stay 0
+        const int hs = ht;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+          const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
+          const int c = hs ? c1 : c0;
+          if (c >= 0) er[c] = f[e];
         }
       }
 #pragma unroll
@@ -259,6 +284,31 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) sg[pt] = 0.0f;
 
+    // training forward: four fp32 values (accumulator registers 4qq..4qq+3 of point tile pt) go to the wave's staging
+    // tile; store_tile() then writes the staged 32-point x 32-feature tiles of both point tiles to
+    // acts[slot][point][32t..32t+31] as whole 128-byte rows, non-temporal.
+    int cur_slot = 0;
+    auto stage = [&](int pt, int qq, const float (&v)[4]) __attribute__((always_inline)) {
+      if (STORE) {
+        f32x4 o;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        *reinterpret_cast<f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_w + 32 * qq) = o;
+      }
+    };
+    auto store_tile = [&](int slot, int t) __attribute__((always_inline)) {
+      if (STORE) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_r + 8 * i * XPOSE_PITCH * 4);
+            char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * t) * 4;
+            unsigned go = g_off;
+            asm volatile("" : "+v"(go));         // opaque per store: no hoisted per-slot address registers
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+          }
+      }
+    };
     // Epilogues of output tile t (results r) writing activation set W: dword q of the tile = accumulator registers
     // 2q, 2q+1 -> k-steps 2t, 2t+1 of the next layer (dwords q, q+1 for even q are adjacent registers).
     auto relu_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
@@ -266,8 +316,17 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int q = 0; q < 8; q += 2)
-          epi_relu(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]);
+        for (int q = 0; q < 8; q += 2) {
+          const int reg = act_reg(W, 2 * t + (q >> 2), pt) + (q & 3);
+          if (STORE) {
+            float v[4];
+            epi_relu_f32(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v);
+            stage(pt, q >> 1, v);
+          } else {
+            epi_relu(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]);
+          }
+        }
+      store_tile(cur_slot, t);
     };
     // layer 8: fp32 ReLU first, its output also feeds the sigma head (nerf.py:136)
     auto relu_sigma_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
@@ -284,16 +343,22 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           sg[pt] = __builtin_fmaf(w[1], v[1], sg[pt]);
           sg[pt] = __builtin_fmaf(w[2], v[2], sg[pt]);
           sg[pt] = __builtin_fmaf(w[3], v[3], sg[pt]);
+          stage(pt, q >> 1, v);
         }
       }
+      store_tile(7, t);
     };
     auto copy_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {     // xyz_encoding_final
       constexpr int W = decltype(wset)::value;
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int q = 0; q < 8; q += 2)
+        for (int q = 0; q < 8; q += 2) {
           epi_copy(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]);
+          const float v[4] = {r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]};
+          stage(pt, q >> 1, v);
+        }
+      store_tile(8, t);
     };
 #define SNB_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SNB_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
@@ -330,12 +395,14 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     constexpr int B_L0 = 64 * 64, B_H = 256 * 64, B_SKIP = 320 * 64, B_DIR = 288 * 64;
 
     // ---- layer 0: reads the xyz embedding (VGPRs), writes set 0
+    cur_slot = 0;
     SNB_LAYER(4, 0, -1, -1, 1, B_L0, B_H, xe, relu_tile, 0);
 
     // ---- layers 1..7: odd layers read set 0 and write set 1, even layers the reverse; skip concat at layer 4;
     //      layer 7's epilogues also feed the sigma head
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
+      cur_slot = l;
       if (l == 4) {
         SNB_LAYER(4, 16, -1, 1, 2, B_SKIP, B_H, xe, relu_tile, 0);
       } else if (l == 7) {
@@ -371,7 +438,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       float f[16];
       if (INPUT_MODE == 0) {
         const float* rp = in0 + (p[pt] / S) * 8;
-        embed_dir(rp[3], rp[4], rp[5], h, f);
+        embed_dir(rp[3], rp[4], rp[5], ht, f);
       } else {
         const float* row = in0 + p[pt] * (long)S;
         int hh = h;
@@ -381,6 +448,16 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
           const int c = hh ? c1 : c0;
           f[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
+        }
+      }
+      if (STORE) {
+        float* er = emb + p_raw[pt] * 128;
+        const int hs = ht;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
+          const int c = hs ? c1 : c0;
+          if (c >= 0) er[64 + c] = f[e];
         }
       }
       de[0 * PT + pt] = pack8(f);
@@ -408,17 +485,20 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           for (int i = 0; i < 4; ++i) x[i] = r[pt][4 * q + i];
           // the chunk's inputs and the running sums pass through one volatile asm: chunks execute strictly in order
           asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(c3[pt][0]), "+v"(c3[pt][1]), "+v"(c3[pt][2]));
+          float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float sx = x[i] - 1.0f;
             const float e = __builtin_amdgcn_exp2f(-fabsf(sx) * 1.44269504088896340736f);
-            const float v = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), 0.69314718055994530942f, fmaxf(sx, 0.0f));
+            v[i] = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), 0.69314718055994530942f, fmaxf(sx, 0.0f));
 #pragma unroll
-            for (int c = 0; c < 3; ++c) c3[pt][c] = __builtin_fmaf(w[c][i], v, c3[pt][c]);
+            for (int c = 0; c < 3; ++c) c3[pt][c] = __builtin_fmaf(w[c][i], v[i], c3[pt][c]);
           }
+          stage(pt, q, v);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      store_tile(9, t);
     };
     // 18 k-steps per slab: the fragment-ring phase alternates 0,2,0,2 (static); tiles 2,3 stage the next point tile
     SNB_SLAB(0, 16, 2, 0, -1, 2, 0, B_DIR, de, ssp_tile, 0);
@@ -453,24 +533,28 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 }  // namespace snk
 
 extern "C" int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                                          int sigma_only, int input_mode, float* out, hipStream_t stream) {
+                                          int sigma_only, int input_mode, float* out, float* acts, float* emb,
+                                          long slot_rows, hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 255) / 256;
+  const bool store = acts != nullptr;
+  if (store && (sigma_only || input_mode != 0 || emb == nullptr || slot_rows < tiles * 256)) return -1;
   int dev = 0, n_cu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
   dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
-  const size_t lds = MLP_BF16_LDS_BYTES;
+  const size_t lds = MLP_BF16_LDS_BYTES + (store ? BF16_XPOSE_LDS_BYTES : 0);
   const char* b = reinterpret_cast<const char*>(blob);
-#define SN_LAUNCH(SO, IM)                                                                                        \
+#define SN_LAUNCH(SO, IM, ST)                                                                                    \
   do {                                                                                                           \
-    auto kfn = mlp_fwd_bf16_kernel<SO, IM>;                                                                      \
+    auto kfn = mlp_fwd_bf16_kernel<SO, IM, ST>;                                                                  \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                          \
-    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out);                      \
+    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows); \
   } while (0)
-  if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0); else SN_LAUNCH(false, 0); }
-  else { if (sigma_only) SN_LAUNCH(true, 1); else SN_LAUNCH(false, 1); }
+  if (store) SN_LAUNCH(false, 0, true);
+  else if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false); }
+  else { if (sigma_only) SN_LAUNCH(true, 1, false); else SN_LAUNCH(false, 1, false); }
 #undef SN_LAUNCH
   return (int)hipGetLastError();
 }

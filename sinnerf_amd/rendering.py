@@ -168,6 +168,22 @@ def render_rays(models,
                                  test_time)
 
 
+@torch.no_grad()
+def eval_points(points, models, embeddings):
+    """``models/rendering.py:64-123``: raw sigma of the last (fine) model at free points.
+
+    points (B, 3) -> (B, 1).  The reference embeds all points with ``embeddings[0]`` and runs the model in chunks of
+    32 768 with ``sigma_only=True``; here the embedding is applied by the same ``Embedding`` module and the fused MLP
+    kernel takes the embedded rows in one launch (no chunk loop needed: nothing but the (B, 63) input is materialised).
+    (Unused by the reference's own scripts; kept for completeness of the rendering module's surface.)"""
+    _check_embeddings(embeddings)
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise RuntimeError(f"eval_points: points must be (B, 3), got {tuple(points.shape)}")
+    if points.shape[0] == 0:
+        return torch.empty((0, 1), dtype=torch.float32, device=points.device)
+    return models[-1](embeddings[0](points.float()), sigma_only=True)
+
+
 def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
     """Drop-in for reference ``models/rendering.py:15-61``: bins (N, M+1), weights (N, M) -> (N, N_importance)."""
     if not bins.is_cuda:

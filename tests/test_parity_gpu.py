@@ -303,6 +303,19 @@ def test_bf16_render_psnr_parity():
     assert O.psnr(got, ref) > 55.0, O.psnr(got, ref)
 
 
+def test_eval_points_vs_oracle():
+    """rendering.py:64-123: sigma of the fine model at free points."""
+    import sinnerf_amd
+    mc, _ = make_model(0, True)
+    mf, pf = make_model(1, True)
+    pts = np.random.RandomState(4).uniform(-3, 3, (1000, 3)).astype(np.float32)
+    got = sinnerf_amd.eval_points(torch.from_numpy(pts).to(dev()), [mc, mf], embeddings()).cpu().numpy()
+    ref = O.nerf_forward(pf, O.embedding(pts, 10), sigma_only=True)
+    assert got.shape == (1000, 1)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-5
+    assert sinnerf_amd.eval_points(torch.empty((0, 3), device=dev()), [mc, mf], embeddings()).shape == (0, 1)
+
+
 # ------------------------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("n,S,NI", [(1, 64, 64), (3, 64, 128), (5, 3, 1), (2, 512, 0), (129, 17, 33)])
 def test_ragged_and_extreme_shapes_vs_oracle(n, S, NI):

@@ -77,6 +77,21 @@ fl = lambda f: f * P / 1e9
 out["fine_pass"] = {"points": P, "fwd_train_ms": ms_fwd, "fwd_infer_ms": ms_inf, "bwd_chain_ms": ms_chain, "dW_gemm_ms": ms_dw,
                     "fwd_train_tflops": fl(1186816) / ms_fwd, "bwd_chain_tflops": fl(2 * 569344) / ms_chain,
                     "dW_tflops": fl(1186816) / ms_dw}
+# mixed precision: the same step with compute_dtype="bf16" (bf16-operand forward storing fp32 activations, fp32 backward)
+mb = []
+for seed in (0, 1):
+    mm = sinnerf_amd.NeRF(use_new_activation=True, compute_dtype="bf16")
+    mm.load_state_dict({k: torch.from_numpy(v) for k, v in O.init_params(seed, True).items()})
+    mb.append(mm.to(dev).train())
+models_fp32, models = models, mb
+step(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K):
+    step()
+torch.cuda.synchronize()
+dtb = (time.perf_counter() - t0) / K
+ms_fwd_b, _ = timed(lambda: A._MLPFn.apply(mb[1], rays, z, *mb[1].raw_tensors()))
+out["bf16_forward_training"] = {"ms_per_step": dtb * 1e3, "train_rays_per_s": N / dtb, "fine_fwd_train_ms": ms_fwd_b}
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/train_bench.json", "w"), indent=1)
 print(json.dumps(out))
