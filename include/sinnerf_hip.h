@@ -28,8 +28,9 @@ extern "C" {
 #define SN_E_UNSUPPORTED (-4)
 #define SN_E_BADSHAPE (-5)
 
-/* sn_mlp_forward flags */
-#define SN_FLAG_NO_LDS_DMA 1 /* stage weight slabs through VGPRs instead of global_load_lds (ablation/debug) */
+/* sn_mlp_forward flags: reserved, pass 0.  (Bit 0 selected a register-staged weight path in early builds; it is accepted
+ * and ignored -- weights always stream by global_load_lds.) */
+#define SN_FLAG_NO_LDS_DMA 1
 
 int sn_abi_version(void);
 const char* sn_error_string(int code);

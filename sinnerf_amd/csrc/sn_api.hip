@@ -135,7 +135,7 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
                                       nullptr, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
-                                   (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
+                                   1, out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
@@ -212,7 +212,7 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   if (dtype == SN_DTYPE_BF16)
     return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
-  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, (flags & SN_FLAG_NO_LDS_DMA) ? 0 : 1,
+  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, 1,
                                    out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 

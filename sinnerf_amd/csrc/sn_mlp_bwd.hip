@@ -53,7 +53,7 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
   const bool valid = p_raw < P;
   const long p = valid ? p_raw : P - 1;
 
-  Stager<true> st;
+  Stager st;
   const char* gnext = bblob;
   st.issue(gnext, buf0, snl::bslab_k(0) / 32, tid);
   gnext += snl::bslab_k(0) * 128;

@@ -12,32 +12,15 @@ constexpr int MLP_F32_LDS_BYTES = BIAS_LDS_BYTES + 2 * SLAB_LDS_BYTES_F32;   // 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
-// ---- slab staging: copy n_iter*4096 bytes global -> LDS, 16 B per thread per iteration -------------
-// DMA variant: global_load_lds_dwordx4 (LDS address = wave-uniform base + lane*16, no VGPR round trip).
-template <bool DMA>
+// ---- slab staging of the double-buffered backward chain: copy n_iter*4096 bytes global -> LDS by
+// global_load_lds_dwordx4 (LDS address = wave-uniform base + lane*16, no VGPR round trip), 16 B per thread per iteration
 struct Stager {
-  float4 pre[10];
-  int n;
   SN_DEV void issue(const char* __restrict__ g, char* lds, int n_iter, int tid) {
-    n = n_iter;
-    if (DMA) {
-      char* lw = lds + __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+    char* lw = lds + __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
 #pragma unroll
-      for (int i = 0; i < 10; ++i)
-        if (i < n_iter)
-          __builtin_amdgcn_global_load_lds((gbl_cvoid*)(g + i * 4096 + tid * 16), (lds_void*)(lw + i * 4096), 16, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 10; ++i)
-        if (i < n_iter) pre[i] = *reinterpret_cast<const float4*>(g + i * 4096 + tid * 16);
-    }
-  }
-  SN_DEV void commit(char* lds, int tid) {
-    if (!DMA) {
-#pragma unroll
-      for (int i = 0; i < 10; ++i)
-        if (i < n) *reinterpret_cast<float4*>(lds + i * 4096 + tid * 16) = pre[i];
-    }
+    for (int i = 0; i < 10; ++i)
+      if (i < n_iter)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(g + i * 4096 + tid * 16), (lds_void*)(lw + i * 4096), 16, 0, 0);
   }
 };
 

@@ -86,7 +86,7 @@ def test_sample_coarse_bit_exact(S, use_disp, perturb):
     assert np.array_equal(z.cpu().numpy(), ref)            # integer-like bar: identical bits
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1])                 # bit 0: retired ablation flag, accepted and ignored
 @pytest.mark.parametrize("sigma_only", [False, True])
 def test_mlp_forward_vs_oracle(flags, sigma_only):
     from sinnerf_amd import rendering
