@@ -20,16 +20,14 @@ _VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64), 4: (32,
 # cost of one point of a K-range on one CU, in cycles: max(MFMA issue time of the wave block, tile bytes / ~8 B/clk of
 # per-CU streaming bandwidth) -- the narrow problems are DMA-bound, not MFMA-bound (measured: splitting by FLOPs alone left
 # the 32x128 problem streaming 168 MB through a single CU, 2.5x the kernel time of the balanced split)
-_VARIANT_COST = {0: 512, 1: 160, 2: 256, 3: 96, 4: 144, 5: 80}
+_VARIANT_COST = {0: 512, 1: 161, 2: 260, 3: 95, 4: 101, 5: 59}      # measured per-point times (tools/dw_time.py), variant 0 = 512
 _KB = 16                      # csrc/sn_dw.hip: points per staged chunk
 _TARGET_WGS = 256             # exactly one workgroup per CU per launch
 
 
-def _weight_grads(model, acts, emb, G, g_o, needs):
-    """dW_l = g_l^T X_l, db_l = sum_p g_l over all sample points (autograd of the nn.Linear layers, nerf.py:66-103).
-    The ten wide contractions run in ONE launch of the K-split MFMA kernel (sn_dw_gemm, csrc/sn_dw.hip) followed by a
-    deterministic sum of the K-split partials; sigma (1 row) and rgb (3 rows) are tiny and go through torch.mm.
-    Order of the returned list = NeRF.raw_tensors()."""
+def _dw_tasks(acts, emb, G):
+    """Task table of the single sn_dw_gemm launch: the 13 contractions dW = G^T X of a network, K-split over ~one workgroup
+    per CU in proportion to their cost.  Returns (rows: list of 8-int64 task records, outs: [(key, partial dW, partial db)])."""
     import numpy as np
     P = acts.shape[1]                                        # padded to a multiple of 16 (pad rows of G are zero)
     dev = acts.device
@@ -75,6 +73,16 @@ def _weight_grads(model, acts, emb, G, g_o, needs):
             rows.append((a_ptr, b_ptr, cpart.data_ptr() + j * M * N * fsz,
                          (bpart.data_ptr() + j * M * fsz) if want_b else 0,
                          j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | (var << 32)))
+    return rows, outs
+
+
+def _weight_grads(model, acts, emb, G, g_o, needs):
+    """dW_l = g_l^T X_l, db_l = sum_p g_l over all sample points (autograd of the nn.Linear layers, nerf.py:66-103).
+    All contractions run in ONE launch of the K-split MFMA kernel (sn_dw_gemm, csrc/sn_dw.hip) followed by a deterministic
+    sum of the K-split partials.  Order of the returned list = NeRF.raw_tensors()."""
+    import numpy as np
+    dev = acts.device
+    rows, outs = _dw_tasks(acts, emb, G)
     tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
     _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], _lib.stream_ptr()), "sn_dw_gemm")
     res = {k: (c.sum(0), b.sum(0) if b is not None else None) for k, c, b in outs}

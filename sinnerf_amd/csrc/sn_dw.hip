@@ -35,23 +35,34 @@ struct Task {                                   // 64 bytes, built on the host (
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
-// copy KB x W floats (row-major, W*4 bytes per row) global -> LDS; rows past k_end (prefetch overrun) are clamped
+// copy KB x W floats (row-major, W*4 bytes per row) global -> LDS.  A chunk past k_end (the ring's prefetch overrun) is
+// replaced by the last real chunk of the task ((k1-k0) % KB == 0) -- a wave-uniform select on the chunk base, so the
+// per-thread part of the address is a 32-bit byte offset computed once per task (off[it]) and a DMA instruction costs one
+// address add instead of a 64-bit multiply + per-row clamp.
 template <int W>
-SN_DEV void stage_rows(const float* __restrict__ g, int ld, long k, long k_end, char* lds, int tid) {
-  constexpr int CHUNKS = KB * W / 4;            // 16-byte chunks
-  constexpr int PER_ROW = W / 4;
-  const int wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+struct RowStager {
+  static constexpr int CHUNKS = KB * W / 4;      // 16-byte pieces per chunk
+  static constexpr int PER_ROW = W / 4;
+  static constexpr int IT = (CHUNKS + 255) / 256;
+  unsigned off[IT];
+  SN_DEV void init(int ld, int tid) {
 #pragma unroll
-  for (int it = 0; it < (CHUNKS + 255) / 256; ++it) {
-    const int c = it * 256 + tid;
-    if (CHUNKS % 256 == 0 || c < CHUNKS) {
-      long row = k + c / PER_ROW;
-      row = row < k_end ? row : k_end - 1;
-      const float* src = g + row * ld + (c % PER_ROW) * 4;
-      __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(lds + it * 4096 + wbase), 16, 0, 0);
+    for (int it = 0; it < IT; ++it) {
+      const int c = it * 256 + tid;
+      off[it] = (unsigned)((c / PER_ROW) * ld + (c % PER_ROW) * 4) * 4u;
     }
   }
-}
+  SN_DEV void stage(const float* __restrict__ g, int ld, long k, long k_end, char* lds, int tid) const {
+    const long kc = k < k_end ? k : k_end - KB;
+    const char* base = reinterpret_cast<const char*>(g + kc * ld);             // wave-uniform
+    const int wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      if (CHUNKS % 256 == 0 || it * 256 + tid < CHUNKS)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(base + off[it]), (lds_void*)(lds + it * 4096 + wbase), 16, 0, 0);
+    }
+  }
+};
 
 template <int N>
 SN_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -65,7 +76,7 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   // DMA instructions per thread per chunk.  A 32-wide A tile (variants 4/5) is only 128 16-byte pieces: waves 2,3 issue
   // none of it, so their vmcnt budget is one instruction per chunk smaller (the wait must be exact per wave).
   constexpr int CH_A = KB * WA / 4, CH_B = KB * WB / 4;
-  static_assert(CH_B % 256 == 0 && CH_A % 64 == 0, "stage_rows predicates must be wave-uniform");
+  static_assert(CH_B % 256 == 0 && CH_A % 64 == 0, "staging predicates must be wave-uniform");
   constexpr int IT_A = (CH_A + 255) / 256, IT_B = CH_B / 256, PART_A = (CH_A % 256) / 64;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
@@ -85,12 +96,16 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
 
   const long k0 = t.k0, k1 = t.k1;
   if (k0 >= k1) return;
+  RowStager<WA> sa;
+  RowStager<WB> sb;
+  sa.init(t.lda, tid);
+  sb.init(t.ldb, tid);
   const int n_chunks = (int)((k1 - k0 + KB - 1) / KB);
   // prologue: NBUF-1 chunks in flight (chunks past the end are staged as clamped copies and never consumed)
 #pragma unroll
   for (int c = 0; c < NBUF - 1; ++c) {
-    stage_rows<WA>(t.a, t.lda, k0 + (long)c * KB, k1, smem + c * BUF, tid);
-    stage_rows<WB>(t.b, t.ldb, k0 + (long)c * KB, k1, smem + c * BUF + A_BYTES, tid);
+    sa.stage(t.a, t.lda, k0 + (long)c * KB, k1, smem + c * BUF, tid);
+    sb.stage(t.b, t.ldb, k0 + (long)c * KB, k1, smem + c * BUF + A_BYTES, tid);
   }
   for (int c = 0; c < n_chunks; ++c) {
     const long k = k0 + (long)c * KB;
@@ -101,8 +116,8 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
     {
       const int slot = (c + NBUF - 1) % NBUF;   // = slot of chunk c-1
       char* bn = smem + slot * BUF;
-      stage_rows<WA>(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, bn, tid);
-      stage_rows<WB>(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, bn + A_BYTES, tid);
+      sa.stage(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, bn, tid);
+      sb.stage(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, bn + A_BYTES, tid);
     }
     char* bc = smem + (c % NBUF) * BUF;
     const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;

@@ -1,0 +1,27 @@
+"""time the weight-gradient launch of the fine pass; mode 'hot' aliases every row to row 0 (lda = ldb = 0: same instruction
+stream, no HBM traffic) to separate memory effects from issue effects"""
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from oracle import oracle_np as O
+import sinnerf_amd
+from sinnerf_amd import autograd as A, _lib
+dev = torch.device("cuda:0")
+P = 4096 * 128
+acts = torch.randn((10, P, 256), device=dev); G = torch.randn((10, P, 256), device=dev); emb = torch.randn((P, 128), device=dev)
+rows, outs = A._dw_tasks(acts, emb, G)
+def timed(rows):
+    tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+    def run(): _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], None), "dw")
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): run()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 5
+print("tasks", len(rows), "normal %.3f ms" % timed(rows))
+hot = [r[:6] + (0, r[7]) for r in rows]
+print("hot (ld=0) %.3f ms" % timed(hot))
+by_var = {}
+for r in rows: by_var.setdefault(r[7] >> 32, []).append(r)
+for v, rs in sorted(by_var.items()):
+    print("variant", v, "tasks", len(rs), "alone %.3f ms" % timed(rs), " points/task", rs[0][5] - rs[0][4])
