@@ -74,7 +74,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

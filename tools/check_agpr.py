@@ -5,7 +5,7 @@ These kernels manage the AGPR file by hand and emit their MFMAs as inline asm, s
 guarantees are checked on the generated code instead:
   1. the compiler allocated no AGPR itself (every AGPR reference sits inside ASMSTART/ASMEND) and spilled nothing;
   2. no VALU instruction writes a register an MFMA reads within the next 2 wait states (VALU write -> MFMA read hazard);
-  3. no VALU instruction reads an MFMA result before two further MFMAs (or 12 other instructions) have issued
+  3. no VALU / LDS / memory instruction reads an MFMA result before two further MFMAs (or 12 other instructions) have issued
      (MFMA write -> VALU read hazard: 11 wait states for the 8-pass bf16 MFMA, 18 for the 16-pass fp32 one).
 usage: check_agpr.py file.s"""
 import re, sys
@@ -38,15 +38,16 @@ for ln, l in enumerate(open(sys.argv[1]), 1):
     parts = [a.strip() for a in args.split(',')] if args else []
     if not ina and any(k == 'a' for k, _ in vregs(args)): bad_agpr.append((ln, t))
     is_valu = op.startswith('v_') and not op.startswith('v_mfma')
+    reads_regs = is_valu or op.startswith(('ds_write', 'ds_read', 'global_store', 'global_load', 'flat_', 'scratch_', 'buffer_'))
     if op.startswith(('v_', 'ds_read', 'global_load_dword', 'scratch_load')) and not op.startswith(('v_cmp', 'v_readfirstlane')):
         dst = vregs(parts[0]) if parts else set(); src = set().union(*[vregs(p) for p in parts[1:]]) if len(parts) > 1 else set()
         if op.startswith(('v_fmac', 'v_pk_fma', 'v_mfma')): src |= dst if not op.startswith('v_mfma') else set()
     else:
         dst = set(); src = set().union(*[vregs(p) for p in parts]) if parts else set()
-    ins.append((ln, op, dst, src, is_valu, t))
+    ins.append((ln, op, dst, src, is_valu, t, reads_regs))
 
 haz1 = []; haz2 = []
-for i, (ln, op, dst, src, is_valu, t) in enumerate(ins):
+for i, (ln, op, dst, src, is_valu, t, _rr) in enumerate(ins):
     if not op.startswith('v_mfma'): continue
     # leading s_nop N inside the same asm statement shows up as the previous instruction
     ws = 0; j = i - 1
@@ -61,7 +62,7 @@ for i, (ln, op, dst, src, is_valu, t) in enumerate(ins):
     while j < len(ins) and nm < 2 and other < 12:
         if ins[j][1].startswith('v_mfma'): nm += 1
         else:
-            if ins[j][4] and (ins[j][3] & dst): haz2.append((ln, t, ins[j][5]))
+            if ins[j][6] and (ins[j][3] & dst): haz2.append((ln, t, ins[j][5]))
             other += (int(ins[j][5].split()[1], 0) + 1) if ins[j][1] == 's_nop' else 1
         j += 1
 
