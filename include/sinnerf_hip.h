@@ -58,6 +58,10 @@ int sn_pack_weights(const float* const* raw_host_array_of_device_ptrs, const int
 long sn_packed_weights_bytes_bwd(void);
 long sn_pack_table_entries_bwd(void);
 int sn_build_pack_table_bwd(int32_t* table_host);
+/* ... and its bf16-operand form (sn_mlp_backward_chain with dtype SN_DTYPE_BF16; pack with sn_pack_weights(..., SN_DTYPE_BF16)) */
+long sn_packed_weights_bytes_bwd_bf16(void);
+long sn_pack_table_entries_bwd_bf16(void);
+int sn_build_pack_table_bwd_bf16(int32_t* table_host);
 
 /* ---- models/rendering.py:264-282  z_vals = near*(1-t)+far*t (or disparity), stratified perturb -----------
  * rays (n_rays,8) = [o(3), d(3), near, far] (rendering.py:257-258); perturb_rand (n_rays,n_samples) = the
@@ -89,8 +93,9 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
  * blob_bwd: transposed-weight blob (sn_build_pack_table_bwd).  out_raw / g_raw (n_points,4): forward output and its
  * gradient.  Writes g_acts (10, slot_rows, 256): slots 0..7 = dL/d(pre-activation) of xyz_encoding_1..8, 8 = of
  * xyz_encoding_final, 9 = of dir_encoding (128 wide); g_out (n_points,4) = dL/d(pre-activation) of rgb (3), sigma (1).
- * slot_rows as for sn_mlp_forward_train (>= n_points rounded up to 128; rows >= n_points of slots' 256 columns are
- * written as zeros, the caller zero-fills the rest of the pad rows).  Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.   */
+ * dtype SN_DTYPE_BF16: blob_bwd from the *_bwd_bf16 table, bf16-operand contractions, everything stored stays fp32.
+ * slot_rows as for sn_mlp_forward_train (>= n_points rounded up to 128, 256 for bf16; rows >= n_points of slots' 256
+ * columns are written as zeros, the caller zero-fills the rest of the pad rows).  Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.   */
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream);
 

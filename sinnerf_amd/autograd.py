@@ -141,7 +141,8 @@ class _MLPFn(torch.autograd.Function):
             G[:, P:].zero_()
         g_o = torch.empty((P, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd()), _lib.SN_DTYPE_F32,     # backward is always fp32
+            code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain; G, the weight gradients and Adam stay fp32
+            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(model.compute_dtype)), code,
                                                       _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")
             needs = ctx.needs_input_grad[3:]

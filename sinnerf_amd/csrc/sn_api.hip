@@ -9,6 +9,8 @@ int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* i
                               long slot_rows, hipStream_t stream);
 int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
+int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
 int sn_generate_rays_launch(const float* c2w, int H, int W, float focal, float near, float far, int x0, int y0, int sx,
                             int sy, int pw, int ph, float* rays, hipStream_t stream);
@@ -108,6 +110,14 @@ int sn_build_pack_table_bwd(int32_t* table_host) {
   return 0;
 }
 
+long sn_packed_weights_bytes_bwd_bf16(void) { return snl::bbblob_bytes(); }
+long sn_pack_table_entries_bwd_bf16(void) { return snl::bb_table_entries(); }
+int sn_build_pack_table_bwd_bf16(int32_t* table_host) {
+  if (!table_host) return SN_E_BADARG;
+  snl::build_pack_table_bwd_bf16(reinterpret_cast<snl::PackEntry*>(table_host));
+  return 0;
+}
+
 int sn_pack_weights(const float* const* raw, const int32_t* table, long n_entries, void* blob, int dtype, void* stream) {
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
   if (!raw || !table || !blob || n_entries <= 0) return SN_E_BADARG;
@@ -155,8 +165,12 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream) {
   if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;
-  if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
-  if (slot_rows < (n_points + 127) / 128 * 128) return SN_E_BADSHAPE;      // whole 128-point tiles are written
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
+  const long tile = dtype == SN_DTYPE_BF16 ? 256 : 128;                      // whole point tiles are written
+  if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
+  if (dtype == SN_DTYPE_BF16)
+    return sn_mlp_backward_chain_bf16_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
+                                             (hipStream_t)stream);
   return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
                                           (hipStream_t)stream);
 }

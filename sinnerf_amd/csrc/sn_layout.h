@@ -251,4 +251,67 @@ inline void build_pack_table_bwd(PackEntry* out) {
   }
 }
 
+
+// ================================================================================================
+// Backward-chain blob, bf16 operands (mixed-precision training: sn_mlp_bwd_bf16.hip).  Same transposed scheme, 32x32x16
+// fragments (8 K-slots per lane per k-step), and the two narrow transposed heads moved to the VALU like in the forward:
+//   0.. 7  DIRT  K=128  rows = final features (dir_encoding.0[:, :256]^T)   k-slots: g_y2 (128)
+//   8..15  FINT  K=256  rows = h8 features (xyz_encoding_final^T)           k-slots: g_final (256)
+//  16..71  LT    K=256  layers i = 7..1 (xyz_encoding_{i+1}^T), 8 tiles each
+// followed by an fp32 tail: 72 x 32 zeros (the slab pipeline's bias slots: these layers have no bias term) and the aux
+// table  rgbT[3][2][64] (rgb.0.weight[c][f], f = K-slot order of the 128 h2 features) | sigT[2][128] (sigma.weight[f]).
+constexpr int NBB_SLABS = 72;
+constexpr int BBSLAB_FINT = 8, BBSLAB_LT = 16;
+constexpr int bbslab_k(int s) { return s < 8 ? 128 : 256; }
+constexpr long bbslab_elem_offset(int s) { return s < 8 ? (long)s * 32 * 128 : 8L * 32 * 128 + (long)(s - 8) * 32 * 256; }
+constexpr long BB_TOTAL_ELEMS = bbslab_elem_offset(NBB_SLABS);
+constexpr int BB_ZERO_FLOATS = NBB_SLABS * 32;
+constexpr int BB_AUX_RGBT = 0, BB_AUX_SIGT = 384, BB_AUX_FLOATS = 640;
+constexpr int BB_TAIL_FLOATS = BB_ZERO_FLOATS + BB_AUX_FLOATS;                   // 2944 floats = 11776 B
+constexpr long bb_tail_byte_offset() { return BB_TOTAL_ELEMS * 2; }
+constexpr long bbblob_bytes() { return bb_tail_byte_offset() + (long)BB_TAIL_FLOATS * 4; }
+constexpr long bb_table_entries() { return BB_TOTAL_ELEMS + BB_TAIL_FLOATS; }
+
+inline void build_pack_table_bwd_bf16(PackEntry* out) {
+  long n = 0;
+  for (int s = 0; s < NBB_SLABS; ++s) {
+    const int K = bbslab_k(s);
+    const long base = bbslab_elem_offset(s);
+    for (int ks = 0; ks < K / 16; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int i = lane & 31, h = lane >> 5, q = 8 * ks + j;
+          int32_t src;
+          if (s < BBSLAB_FINT) {                              // dir_encoding.0^T : W_d (128 x 283), cols 0..255
+            src = (RAW_DIR << 20) | (hid_slot_feature(q, h) * 283 + 32 * s + i);
+          } else if (s < BBSLAB_LT) {                         // xyz_encoding_final^T
+            src = (RAW_FIN << 20) | (hid_slot_feature(q, h) * 256 + 32 * (s - BBSLAB_FINT) + i);
+          } else {                                            // xyz_encoding_{li+1}^T, li = 7..1
+            const int li = 7 - (s - BBSLAB_LT) / 8, t = (s - BBSLAB_LT) % 8;
+            const int ncol = raw_cols(2 * li), coloff = (li == 4) ? 63 : 0;
+            src = ((2 * li) << 20) | (hid_slot_feature(q, h) * ncol + coloff + 32 * t + i);
+          }
+          PackEntry e;
+          e.dst = (int32_t)((base + ((long)ks * 64 + lane) * 8 + j) * 2);
+          e.src = src;
+          out[n++] = e;
+        }
+  }
+  const long tail = bb_tail_byte_offset();
+  for (int a = 0; a < BB_TAIL_FLOATS; ++a) {
+    PackEntry e;
+    e.dst = (int32_t)(tail + (long)a * 4);
+    e.src = -2;
+    const int x = a - BB_ZERO_FLOATS;
+    if (x >= BB_AUX_RGBT && x < BB_AUX_SIGT) {                // rgbT[c][h][q], q < 64
+      const int c = x / 128, h = (x % 128) / 64, q = x % 64;
+      e.src = SRC_F32_FLAG | (RAW_RGB << 20) | (c * 128 + hid_slot_feature(q, h));
+    } else if (x >= BB_AUX_SIGT) {                            // sigT[h][q], q < 128
+      const int h = (x - BB_AUX_SIGT) / 128, q = (x - BB_AUX_SIGT) % 128;
+      e.src = SRC_F32_FLAG | (RAW_SIG << 20) | hid_slot_feature(q, h);
+    }
+    out[n++] = e;
+  }
+}
+
 }  // namespace snl

@@ -34,142 +34,9 @@
 // by sched_barrier, or (b) at a layer end behind an explicit s_nop run.
 //
 // Persistent workgroups, 3-slot weight ring with a mid-slab barrier, compile-time DMA piece counts: sn_mlp_pipe.h.
-#include "sn_mlp_pipe.h"
-#include <type_traits>
+#include "sn_mlp_bf16.h"
 
 namespace snk {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef short i16x2 __attribute__((ext_vector_type(2)));
-constexpr int PT = 2;                                       // point tiles per wave
-constexpr int RING_SLOT_BYTES_BF16 = snl::MAX_SLAB_K * 64;  // 20480
-constexpr int MLP_BF16_LDS_BYTES = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES_BF16;   // 73984
-constexpr int BF16_XPOSE_LDS_BYTES = 4 * PT * XPOSE_WAVE_BYTES;                  // training forward: staging tiles (36864)
-typedef RingT<64, RING_SLOT_BYTES_BF16> RingB;
-
-SN_DEV uint32_t pack2(float a, float b) {        // {bf16(a), bf16(b)}, RNE (asm: hipcc converts the halves separately + v_perm)
-  uint32_t d;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-SN_DEV uint32_t relu_pk(uint32_t x) {            // ReLU on a packed bf16 pair: v_pk_max_i16 x, 0
-  const i16x2 z = {0, 0};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, x), z));
-}
-SN_DEV u32x4 pack8(const float* v) {
-  u32x4 o;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = pack2(v[2 * i], v[2 * i + 1]);
-  return o;
-}
-// Epilogue blocks: four fp32 accumulator values -> two packed dwords of the hand-managed AGPR file, a[reg], a[reg+1]
-// (`reg` must fold to a constant, it is printed into the asm text).  One asm per block: dependent instructions are one
-// slot apart (the compiler pads every VALU <-> inline-asm dependence with an s_nop for the dst_sel forwarding hazard
-// it has to assume), and as volatile asm they keep their program order relative to the MFMA asm -- which is what keeps
-// the MFMA-result hazard distance.
-SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3) {          // hidden layer: pack, ReLU on the pairs
-  uint32_t t0, t1;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
-               "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\t"
-               "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
-               : "=&v"(t0), "=&v"(t1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
-}
-SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3) {          // no activation
-  uint32_t t0, t1;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
-               "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
-               : "=&v"(t0), "=&v"(t1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
-}
-SN_DEV void epi_relu_f32(int reg, float x0, float x1, float x2, float x3, float (&v)[4]) {   // fp32 ReLU, kept for the head
-  uint32_t t0, t1;
-  asm volatile("v_max_f32 %2, 0, %6\n\tv_max_f32 %3, 0, %7\n\tv_max_f32 %4, 0, %8\n\tv_max_f32 %5, 0, %9\n\t"
-               "v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
-               "v_accvgpr_write_b32 a[%10], %0\n\tv_accvgpr_write_b32 a[%11], %1"
-               : "=&v"(t0), "=&v"(t1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
-}
-// D = A.B + D, D and A in VGPRs; B = a[reg : reg+3] ...
-// FIRST = first MFMA of a slab on this accumulator: its C operand was just written by VALU moves / its B operands by the
-// previous layer's v_accvgpr_write, and a VALU write -> MFMA read needs 2 wait states the compiler cannot insert for asm.
-template <bool FIRST>
-SN_DEV void mma_a(f32x16& acc, const u32x4& a, int reg) {
-  if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
-}
-// ... or B in VGPRs
-template <bool FIRST>
-SN_DEV void mma_v(f32x16& acc, const u32x4& a, const u32x4& b) {
-  if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-// MFMA (8 passes) -> VALU read of its result: the wait states the compiler would insert for a builtin MFMA
-SN_DEV void mfma_result_fence() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }
-constexpr int act_reg(int set, int kstep, int pt) { return set * 128 + (kstep * PT + pt) * 4; }
-
-// One slab: NK0 + NK1 k-steps (two K segments), barrier after k-step GB.
-//   SET0/SET1  B operands of the segment: AGPR activation set 0/1, or -1 = the VGPR array bv ([k-step][PT])
-//   acc        accumulator set of this slab, bias-initialised on entry
-//   accn       the other set: holds the previous slab's result until pending() has consumed it (after k-step 0), then
-//              receives the bias of slab s_next at the sync point
-//   af         4-entry ring of A fragments, prefetch distance 3 k-steps (a bf16 k-step is only 2 x 32 MFMA cycles, one
-//              step of lookahead does not cover the LDS latency).  Invariant at entry: fragments of k-steps 0,1,2 of this
-//              slab sit in af[(PHASE+0..2) & 3]; at exit the same holds for the next slab with PHASE' = (PHASE + NK) & 3
-//              (NK % 4 == 0 everywhere except the four dir_encoding slabs, whose phases 0,2,0,2 are still static).
-//   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead): compile-time -> no DMA branches
-//              (a K = 288 slab ends in a half piece that only waves 0,1 carry).
-template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, class Pending>
-SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], const char* lw, const u32x4* bv,
-                      const char* lw_next, const float* lds_bias, int s_next, int h, RingB& ring, Pending&& pending) {
-  constexpr int NK = NK0 + NK1;
-  constexpr int NP = (NBYTES + 4095) / 4096;
-  constexpr int PPK = (NP + (NK - GB) - 1) / (NK - GB);      // DMA pieces per k-step after the sync point (1; 2 in layer 0)
-  static_assert(GB >= 1 && GB < NK && NK >= 4 && GB + 3 <= NK, "sync point inside the slab, not after the first next-slab fragment read");
-#pragma unroll
-  for (int ks = 0; ks < NK; ++ks) {
-    if (ks == GB) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      ring.begin_static();
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) accn[pt] = load_bias(lds_bias, s_next, h);
-    }
-    {   // AFTER the sync point: in layer 0 (NK = 4, GB = 1) the fragment of k-step 1+3 already belongs to the NEXT slab,
-        // which is only guaranteed to have landed once this slab's barrier has been passed
-      const int kn = ks + 3;
-      af[(PHASE + kn) & 3] = (kn < NK) ? *reinterpret_cast<const u32x4*>(lw + kn * 1024)
-                                       : *reinterpret_cast<const u32x4*>(lw_next + (kn - NK) * 1024);
-    }
-    if (ks >= GB) {
-#pragma unroll
-      for (int i = 0; i < PPK; ++i) {
-        const int piece = (ks - GB) * PPK + i;
-        if (piece < NP) {
-          if ((piece + 1) * 4096 <= NBYTES || ring.wbase < NBYTES - piece * 4096) ring.piece_static();   // wave-uniform
-          else ring.skip_static();
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const u32x4 a_cur = af[(PHASE + ks) & 3];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      if (ks == 0) {
-        if (SET0 < 0) mma_v<true>(acc[pt], a_cur, bv[pt]); else mma_a<true>(acc[pt], a_cur, act_reg(SET0, 0, pt));
-      } else if (ks < NK0) {
-        if (SET0 < 0) mma_v<false>(acc[pt], a_cur, bv[ks * PT + pt]); else mma_a<false>(acc[pt], a_cur, act_reg(SET0, ks, pt));
-      } else {
-        if (SET1 < 0) mma_v<false>(acc[pt], a_cur, bv[(ks - NK0) * PT + pt]);
-        else mma_a<false>(acc[pt], a_cur, act_reg(SET1, ks - NK0, pt));
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (ks == 0) {
-      pending();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  ring.template end_static_bytes<NBYTES>();
-}
 
 // STORE: training forward with bf16 contractions -- additionally writes the fp32 activations of every layer
 // (acts[10][slot_rows][256]: the fp32 values BEFORE their bf16 rounding) and the fp32 embedded inputs (emb[slot_rows][128])

@@ -144,30 +144,37 @@ class NeRF(nn.Module):
         self._packed[code] = (blob, sig)
         return blob
 
-    def packed_bwd(self):
-        """Transposed-weight blob for ``sn_mlp_backward_chain`` (fp32), cached like ``packed()``."""
+    def packed_bwd(self, dtype="fp32"):
+        """Transposed-weight blob for ``sn_mlp_backward_chain`` (fp32, or bf16 operands for the mixed-precision chain),
+        cached like ``packed()``."""
+        code = dtype_code(dtype)
         raws = self.raw_tensors()
         dev = raws[0].device
         if dev.type != "cuda":
             raise RuntimeError("sinnerf_amd.NeRF: parameters must live on a ROCm device (no CPU fallback)")
         sig = self._signature(raws)
-        hit = self._packed.get("bwd")
+        slot = ("bwd", code)
+        hit = self._packed.get(slot)
         if hit is not None and hit[1] == sig and hit[0].device == dev:
             return hit[0]
-        key = (str(dev), "bwd")
+        bf16 = code == _lib.SN_DTYPE_BF16
+        n_entries, build, n_bytes = ((_lib.lib.sn_pack_table_entries_bwd_bf16, _lib.lib.sn_build_pack_table_bwd_bf16,
+                                      _lib.lib.sn_packed_weights_bytes_bwd_bf16) if bf16 else
+                                     (_lib.lib.sn_pack_table_entries_bwd, _lib.lib.sn_build_pack_table_bwd,
+                                      _lib.lib.sn_packed_weights_bytes_bwd))
+        key = (str(dev), "bwd", code)
         if key not in _PACK_TABLES:
-            n = _lib.lib.sn_pack_table_entries_bwd()
-            host = torch.empty((n, 2), dtype=torch.int32)
-            _lib.check(_lib.lib.sn_build_pack_table_bwd(ctypes.c_void_p(host.data_ptr())), "sn_build_pack_table_bwd")
+            host = torch.empty((n_entries(), 2), dtype=torch.int32)
+            _lib.check(build(ctypes.c_void_p(host.data_ptr())), "sn_build_pack_table_bwd")
             _PACK_TABLES[key] = host.to(dev)
         table = _PACK_TABLES[key]
         blob = hit[0] if (hit is not None and hit[0].device == dev) else \
-            torch.empty(_lib.lib.sn_packed_weights_bytes_bwd(), dtype=torch.uint8, device=dev)
+            torch.empty(n_bytes(), dtype=torch.uint8, device=dev)
         arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[t.data_ptr() for t in raws])
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib.sn_pack_weights(arr, _lib.ptr(table), table.shape[0], _lib.ptr(blob), _lib.SN_DTYPE_F32,
+            _lib.check(_lib.lib.sn_pack_weights(arr, _lib.ptr(table), table.shape[0], _lib.ptr(blob), code,
                                                 _lib.stream_ptr()), "sn_pack_weights")
-        self._packed["bwd"] = (blob, sig)
+        self._packed[slot] = (blob, sig)
         return blob
 
     # ---- nerf.py:105-148 ------------------------------------------------------------------------------

@@ -81,3 +81,37 @@ def test_emulated_backward_chain_matches_oracle():
     for slot in range(10):
         scale = max(np.abs(ref[slot]).max(), 1e-9)
         assert np.abs(G[slot] - ref[slot]).max() <= 2e-5 * scale, (slot, np.abs(G[slot] - ref[slot]).max(), scale)
+
+
+def test_bf16_backward_blob_table_covers_the_transposed_weights_once():
+    """sn_build_pack_table_bwd_bf16: every element of dir_encoding[:, :256], xyz_encoding_final and the hidden blocks of
+    xyz_encoding_2..8 appears exactly once among the bf16 slabs; the fp32 tail carries 72 x 32 zeros, rgb.0.weight and
+    sigma.weight once each."""
+    import ctypes
+    from sinnerf_amd import _lib
+    n = _lib.lib.sn_pack_table_entries_bwd_bf16()
+    tab = np.zeros((n, 2), np.int32)
+    assert _lib.lib.sn_build_pack_table_bwd_bf16(ctypes.c_void_p(tab.ctypes.data)) == 0
+    dst, src = tab[:, 0].astype(np.int64), tab[:, 1].astype(np.int64)
+    n_w = 8 * 32 * 128 + 64 * 32 * 256
+    assert n == n_w + 72 * 32 + 640 and _lib.lib.sn_packed_weights_bytes_bwd_bf16() == 2 * n_w + 4 * (72 * 32 + 640)
+    assert np.array_equal(np.sort(dst[:n_w]), 2 * np.arange(n_w))                    # bf16 slabs: dense, no overlap
+    assert np.array_equal(dst[n_w:], 2 * n_w + 4 * np.arange(72 * 32 + 640))         # fp32 tail
+    w = src[:n_w]
+    assert (w >= 0).all() and ((w >> 30) & 1 == 0).all()
+    tid, off = (w >> 20) & 0x3ff, w & 0xfffff
+    def cols(t, ncol, c0, c1, rows):
+        m = tid == t
+        r, c = off[m] // ncol, off[m] % ncol
+        assert m.sum() == rows * (c1 - c0) and len(set(zip(r.tolist(), c.tolist()))) == m.sum(), t
+        assert r.min() == 0 and r.max() == rows - 1 and c.min() == c0 and c.max() == c1 - 1, t
+    cols(18, 283, 0, 256, 128)                                                        # dir_encoding.0.weight[:, :256]
+    cols(16, 256, 0, 256, 256)                                                        # xyz_encoding_final.weight
+    for li in range(1, 8):
+        cols(2 * li, 319 if li == 4 else 256, 63 if li == 4 else 0, 319 if li == 4 else 256, 256)
+    tail = src[n_w:]
+    assert (tail[:72 * 32] == -2).all()
+    aux = tail[72 * 32:]
+    assert ((aux >> 30) & 1 == 1).all()
+    at, ao = (aux >> 20) & 0x3ff, aux & 0xfffff
+    assert sorted(ao[at == 22].tolist()) == list(range(384)) and sorted(ao[at == 20].tolist()) == list(range(256))

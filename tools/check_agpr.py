@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build check for sn_mlp_fwd.hip / sn_mlp_fwd_bf16.hip (run by sinnerf_amd/csrc/Makefile on the hipcc -S output).
+"""Build check for sn_mlp_fwd.hip / sn_mlp_fwd_bf16.hip / sn_mlp_bwd_bf16.hip (run by sinnerf_amd/csrc/Makefile on the hipcc -S output).
 
 These kernels manage the AGPR file by hand and emit their MFMAs as inline asm, so three things the compiler normally
 guarantees are checked on the generated code instead:
@@ -24,7 +24,7 @@ def vregs(tok):
 
 kern = None; ina = False; ins = []; bad_agpr = []; spills = 0
 for ln, l in enumerate(open(sys.argv[1]), 1):
-    m = re.match(r'^(_Z\S*mlp_fwd_(?:bf16|f32)_kernel\S*):', l)
+    m = re.match(r'^(_Z\S*mlp_(?:fwd_bf16|fwd_f32|bwd_chain_bf16)_kernel\S*):', l)
     if m: kern = m.group(1); continue
     if kern is None: continue
     if re.match(r'^\s*s_endpgm', l): kern = None; continue
