@@ -25,7 +25,7 @@ _KB = 16                      # csrc/sn_dw.hip: points per staged chunk
 _TARGET_WGS = 256             # exactly one workgroup per CU per launch
 
 
-def _dw_tasks(acts, emb, G):
+def _dw_tasks(acts, emb, G, bf16=False):
     """Task table of the single sn_dw_gemm launch: the 13 contractions dW = G^T X of a network, K-split over ~one workgroup
     per CU in proportion to their cost.  Returns (rows: list of 8-int64 task records, outs: [(key, partial dW, partial db)])."""
     import numpy as np
@@ -72,7 +72,7 @@ def _dw_tasks(acts, emb, G):
         for j in range(ns):
             rows.append((a_ptr, b_ptr, cpart.data_ptr() + j * M * N * fsz,
                          (bpart.data_ptr() + j * M * fsz) if want_b else 0,
-                         j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | (var << 32)))
+                         j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | ((var | (0x100 if bf16 else 0)) << 32)))
     return rows, outs
 
 
@@ -82,7 +82,8 @@ def _weight_grads(model, acts, emb, G, g_o, needs):
     sum of the K-split partials.  Order of the returned list = NeRF.raw_tensors()."""
     import numpy as np
     dev = acts.device
-    rows, outs = _dw_tasks(acts, emb, G)
+    # mixed precision: bf16-operand contractions (fp32 tiles converted on the fly, fp32 accumulation and partial sums)
+    rows, outs = _dw_tasks(acts, emb, G, bf16=dtype_code(model.compute_dtype) == _lib.SN_DTYPE_BF16)
     tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
     _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], _lib.stream_ptr()), "sn_dw_gemm")
     res = {k: (c.sum(0), b.sum(0) if b is not None else None) for k, c, b in outs}

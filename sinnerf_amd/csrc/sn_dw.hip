@@ -29,7 +29,8 @@ struct Task {                                   // 64 bytes, built on the host (
   float* bias;                                  // partial db  [M_wg] or nullptr
   long k0, k1;                                  // point range: (k1-k0) % 16 == 0, rows [k0,k1) readable (callers zero-pad G)
   int lda, ldb;
-  int ldc, variant;                             // M x N: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64, 4 = 32x256, 5 = 32x128
+  int ldc, variant;                             // M x N: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64, 4 = 32x256, 5 = 32x128;
+                                                // | 0x100: bf16 operands (mixed-precision training), fp32 accumulate
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -68,7 +69,23 @@ template <int N>
 SN_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 // WM x WN waves, each wave an (MT*32) x (NT*32) accumulator block.
-template <int MT, int NT, int WM, int WN>
+typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
+typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dw_bf16x2 __attribute__((ext_vector_type(2)));
+// {bf16(a), bf16(b)}, RNE: one v_cvt_pk_bf16_f32.  A builtin, NOT inline asm: the MFMAs of this kernel are builtins too and
+// the compiler must see the VALU write -> MFMA read dependence to pad it (an asm conversion right in front of the MFMA
+// that consumes it returned garbage in the narrow variants).
+SN_DEV unsigned dw_pack2(float a, float b) {
+  const dw_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dw_bf16x2));
+}
+
+// BF16: the same fp32 row-major tiles are staged (nothing changes on the memory side), but a chunk of 16 points is ONE
+// k-step of v_mfma_f32_32x32x16_bf16: lane (i, h) gathers its 8 points of feature i from the LDS tile (stride = row pitch,
+// conflict-free across lanes), converts them to a bf16x8 fragment (RNE) and keeps the fp32 column sums for the bias
+// gradient.  16 MFMAs of 32 cycles per chunk instead of 128 of 64: the kernel becomes HBM-bound.
+template <int MT, int NT, int WM, int WN, bool BF16>
 SN_DEV void run_task(const Task& t, char* smem, int tid) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int WA = WM * MT * 32, WB = WN * NT * 32;
@@ -122,18 +139,46 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
     char* bc = smem + (c % NBUF) * BUF;
     const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;
     const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
-#pragma unroll
-    for (int s = 0; s < KB / 2; ++s) {
-      float av[MT], bv[NT];
-#pragma unroll
-      for (int a = 0; a < MT; ++a) av[a] = la[(2 * s) * WA + 32 * a];
-#pragma unroll
-      for (int b = 0; b < NT; ++b) bv[b] = lb[(2 * s) * WB + 32 * b];
+    if (BF16) {
+      static_assert(KB == 16, "one 32x32x16 k-step per chunk");
+      dw_bf16x8 af[MT], bf[NT];
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
-        bsum[a] += av[a];
+        float v[8];
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int jj = 0; jj < 8; ++jj) v[jj] = la[(7 * h + jj) * WA + 32 * a];      // la already carries h * WA: row 8h + jj
+        dw_u32x4 q;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) q[w] = dw_pack2(v[2 * w], v[2 * w + 1]);
+        af[a] = __builtin_bit_cast(dw_bf16x8, q);
+        bsum[a] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        dw_u32x4 q;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          q[w] = dw_pack2(lb[(7 * h + 2 * w) * WB + 32 * b], lb[(7 * h + 2 * w + 1) * WB + 32 * b]);
+        bf[b] = __builtin_bit_cast(dw_bf16x8, q);
+      }
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < KB / 2; ++s) {
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) av[a] = la[(2 * s) * WA + 32 * a];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bv[b] = lb[(2 * s) * WB + 32 * b];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          bsum[a] += av[a];
+#pragma unroll
+          for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
       }
     }
   }
@@ -161,13 +206,24 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Task t = tasks[blockIdx.x];
   const int tid = threadIdx.x;
+  if (t.variant & 0x100) {
+    switch (t.variant & 0xff) {
+      case 0: run_task<4, 4, 2, 2, true>(t, smem, tid); break;
+      case 1: run_task<4, 1, 2, 2, true>(t, smem, tid); break;
+      case 2: run_task<2, 4, 2, 2, true>(t, smem, tid); break;
+      case 3: run_task<2, 1, 2, 2, true>(t, smem, tid); break;
+      case 4: run_task<1, 2, 1, 4, true>(t, smem, tid); break;
+      default: run_task<1, 1, 1, 4, true>(t, smem, tid); break;
+    }
+    return;
+  }
   switch (t.variant) {
-    case 0: run_task<4, 4, 2, 2>(t, smem, tid); break;
-    case 1: run_task<4, 1, 2, 2>(t, smem, tid); break;
-    case 2: run_task<2, 4, 2, 2>(t, smem, tid); break;
-    case 3: run_task<2, 1, 2, 2>(t, smem, tid); break;
-    case 4: run_task<1, 2, 1, 4>(t, smem, tid); break;
-    default: run_task<1, 1, 1, 4>(t, smem, tid); break;
+    case 0: run_task<4, 4, 2, 2, false>(t, smem, tid); break;
+    case 1: run_task<4, 1, 2, 2, false>(t, smem, tid); break;
+    case 2: run_task<2, 4, 2, 2, false>(t, smem, tid); break;
+    case 3: run_task<2, 1, 2, 2, false>(t, smem, tid); break;
+    case 4: run_task<1, 2, 1, 4, false>(t, smem, tid); break;
+    default: run_task<1, 1, 1, 4, false>(t, smem, tid); break;
   }
 }
 

@@ -298,3 +298,27 @@ def test_bf16_backward_chain_close_to_fp32_chain():
         assert err < 2e-2, (slot, err)
         assert (G16[slot, P:, :w] == 0).all(), slot
     assert np.array_equal(G32[9, :P, 128:160], G16[9, :P, 128:160])          # the rgb / sigma block of the dW kernel
+
+
+def test_bf16_weight_gradient_launch_close_to_fp32():
+    """sn_dw_gemm with bf16 operands (variant | 0x100) against the fp32 launch on the same random matrices, every problem
+    of a network including the narrow rgb / sigma ones: relative Frobenius error < 5e-3 (bf16 rounding of the operands,
+    fp32 accumulation), bias gradients (fp32 column sums in both) within 1e-5."""
+    from sinnerf_amd import _lib, autograd as A
+    d = dev()
+    P = 4096
+    torch.manual_seed(0)
+    acts = torch.randn((10, P, 256), device=d); G = torch.randn((10, P, 256), device=d); emb = torch.randn((P, 128), device=d)
+    res = {}
+    for bf in (False, True):
+        rows, outs = A._dw_tasks(acts, emb, G, bf16=bf)
+        tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(d)
+        _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], None), "dw")
+        torch.cuda.synchronize()
+        res[bf] = {k: (c.sum(0).cpu().numpy(), None if b is None else b.sum(0).cpu().numpy()) for k, c, b in outs}
+    for k, (w32, b32) in res[False].items():
+        w16, b16 = res[True][k]
+        assert np.isfinite(w16).all(), k
+        assert np.linalg.norm(w32 - w16) / np.linalg.norm(w32) < 5e-3, k
+        if b32 is not None:
+            assert np.linalg.norm(b32 - b16) / np.linalg.norm(b32) < 1e-5, k

@@ -21,6 +21,8 @@ def timed(rows):
 print("tasks", len(rows), "normal %.3f ms" % timed(rows))
 hot = [r[:6] + (0, r[7]) for r in rows]
 print("hot (ld=0) %.3f ms" % timed(hot))
+rows16, _ = A._dw_tasks(acts, emb, G, bf16=True)
+print("bf16 operands %.3f ms" % timed(rows16))
 by_var = {}
 for r in rows: by_var.setdefault(r[7] >> 32, []).append(r)
 for v, rs in sorted(by_var.items()):
