@@ -21,6 +21,8 @@ _VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64), 4: (32,
 # per-CU streaming bandwidth) -- the narrow problems are DMA-bound, not MFMA-bound (measured: splitting by FLOPs alone left
 # the 32x128 problem streaming 168 MB through a single CU, 2.5x the kernel time of the balanced split)
 _VARIANT_COST = {0: 512, 1: 161, 2: 260, 3: 95, 4: 101, 5: 59}      # measured per-point times (tools/dw_time.py), variant 0 = 512
+# bf16-operand mode: 8x less MFMA time, every variant is bound by its per-CU DMA stream -- measured per-point times again
+_VARIANT_COST_BF16 = {0: 512, 1: 189, 2: 226, 3: 126, 4: 138, 5: 125}
 _KB = 16                      # csrc/sn_dw.hip: points per staged chunk
 _TARGET_WGS = 256             # exactly one workgroup per CU per launch
 
@@ -47,7 +49,8 @@ def _dw_tasks(acts, emb, G, bf16=False):
     # rows 0..2 = g_y of rgb, row 3 = g_y of sigma (zero-padded 32-wide block at G[9][:, 128:160], sn_mlp_bwd.hip)
     probs.append((("sig", 10), G[9], 128, 256, acts[7], 0, 256, 4, False))    # sigma  (nerf.py:136)
     probs.append((("rgb", 11), G[9], 128, 256, acts[9], 0, 256, 5, True))     # rgb    (nerf.py:144)
-    work = [_VARIANT_COST[p[7]] for p in probs]
+    cost = _VARIANT_COST_BF16 if bf16 else _VARIANT_COST
+    work = [cost[p[7]] for p in probs]
     tot = float(sum(work))
     max_split = max(1, P // (4 * _KB))
     # K-splits proportional to the work of a problem, summing to _TARGET_WGS (largest remainders get the slack)

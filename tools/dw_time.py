@@ -23,6 +23,10 @@ hot = [r[:6] + (0, r[7]) for r in rows]
 print("hot (ld=0) %.3f ms" % timed(hot))
 rows16, _ = A._dw_tasks(acts, emb, G, bf16=True)
 print("bf16 operands %.3f ms" % timed(rows16))
+print("bf16 hot (ld=0) %.3f ms" % timed([r[:6] + (0, r[7]) for r in rows16]))
+by16 = {}
+for r in rows16: by16.setdefault((r[7] >> 32) & 0xff, []).append(r)
+for v, rs in sorted(by16.items()): print("bf16 variant", v, "tasks", len(rs), "alone %.3f ms" % timed(rs))
 by_var = {}
 for r in rows: by_var.setdefault(r[7] >> 32, []).append(r)
 for v, rs in sorted(by_var.items()):
