@@ -132,8 +132,11 @@ def main():
                          "mlp_share_of_step": (ms_fine + ms_coarse) / (dt / args.steps * 1e3)},
             "roofline_rays_per_s_per_gpu": peak * 1e12 / (FLOP_PER_POINT * (NS + NS + NI)),
         }
-        if world == 1 and args.dtype == "fp32":
-            # secondary figure: one optimisation-shaped step (fwd+bwd of render_rays, 4096 rays, perturb=1, noise_std=1)
+        if world == 1:
+            # secondary figure: one optimisation-shaped step (fwd+bwd of render_rays, 4096 rays, perturb=1, noise_std=1).
+            # fp32: every kernel is MFMA-bound (fraction of the fp32 peak).  bf16 = mixed precision (bf16-operand forward,
+            # chain and weight gradients over fp32 activations / gradients in HBM): every kernel is bound by that fp32
+            # traffic, ~51 KB per sample point (10.75 written by the forward, 20.5 moved by the chain, ~20 read by dW).
             try:
                 for m in models:
                     m.train()
@@ -151,9 +154,14 @@ def main():
                     tstep()
                 torch.cuda.synchronize()
                 tdt = (time.perf_counter() - t1) / 3
-                tflop = 3489024 * 4096 * (NS + NS + NI) / tdt / 1e12
-                res["train_step"] = {"rays": 4096, "ms": tdt * 1e3, "rays_per_s": 4096 / tdt, "achieved_tflops": tflop,
-                                     "frac_of_fp32_mfma_peak": tflop / peak}
+                pts = 4096 * (NS + NS + NI)
+                res["train_step"] = {"rays": 4096, "ms": tdt * 1e3, "rays_per_s": 4096 / tdt}
+                if args.dtype == "fp32":
+                    tflop = 3489024 * pts / tdt / 1e12
+                    res["train_step"].update({"bound": "mfma", "achieved_tflops": tflop, "frac_of_fp32_mfma_peak": tflop / peak})
+                else:
+                    tbs = 51000.0 * pts / tdt / 1e12
+                    res["train_step"].update({"bound": "hbm", "approx_hbm_tb_per_s": tbs, "frac_of_8_tb_per_s": tbs / 8.0})
             except Exception as e:                      # noqa: BLE001
                 res["train_step"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
