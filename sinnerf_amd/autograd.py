@@ -33,7 +33,6 @@ def _dw_tasks(acts, emb, G, bf16=False):
     import numpy as np
     P = acts.shape[1]                                        # padded to a multiple of 16 (pad rows of G are zero)
     dev = acts.device
-    fsz = 4
     # (key, A tensor, A col, lda, B tensor, B col, ldb, variant, want_bias)
     probs = []
     for i in range(8):                                       # xyz_encoding_{i+1}
@@ -50,6 +49,10 @@ def _dw_tasks(acts, emb, G, bf16=False):
     probs.append((("sig", 10), G[9], 128, 256, acts[7], 0, 256, 4, False))    # sigma  (nerf.py:136)
     probs.append((("rgb", 11), G[9], 128, 256, acts[9], 0, 256, 5, True))     # rgb    (nerf.py:144)
     cost = _VARIANT_COST_BF16 if bf16 else _VARIANT_COST
+    # 0x100: bf16 operands; 0x200: G and the activations are STORED as bf16 (emb stays fp32)
+    state16 = G.dtype == torch.bfloat16
+    assert (not state16) or (bf16 and acts.dtype == torch.bfloat16 and emb.dtype == torch.float32)
+    flags = (0x100 if bf16 else 0) | (0x200 if state16 else 0)
     work = [cost[p[7]] for p in probs]
     tot = float(sum(work))
     max_split = max(1, P // (4 * _KB))
@@ -71,11 +74,11 @@ def _dw_tasks(acts, emb, G, bf16=False):
         cpart = torch.empty((ns, M, N), dtype=torch.float32, device=dev)
         bpart = torch.empty((ns, M), dtype=torch.float32, device=dev) if want_b else None
         outs.append((key, cpart, bpart))
-        a_ptr, b_ptr = A.data_ptr() + ac * fsz, B.data_ptr() + bc * fsz
+        a_ptr, b_ptr = A.data_ptr() + ac * A.element_size(), B.data_ptr() + bc * B.element_size()
         for j in range(ns):
-            rows.append((a_ptr, b_ptr, cpart.data_ptr() + j * M * N * fsz,
-                         (bpart.data_ptr() + j * M * fsz) if want_b else 0,
-                         j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | ((var | (0x100 if bf16 else 0)) << 32)))
+            rows.append((a_ptr, b_ptr, cpart.data_ptr() + j * M * N * 4,
+                         (bpart.data_ptr() + j * M * 4) if want_b else 0,
+                         j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | ((var | flags) << 32)))
     return rows, outs
 
 

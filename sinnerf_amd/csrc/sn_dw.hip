@@ -26,14 +26,16 @@ constexpr int NBUF = 4;                         // LDS ring depth (NBUF-1 chunks
 constexpr int DW_LDS_BYTES = NBUF * KB * (256 + 256) * 4;   // 131072
 
 struct Task {                                   // 64 bytes, built on the host (sinnerf_amd/autograd.py)
-  const float* a;                               // G  + column offset
-  const float* b;                               // X  + column offset
+  const void* a;                                // G  + column offset (fp32, or bf16 with 0x200)
+  const void* b;                                // X  + column offset (fp32; bf16 with 0x200 except in variants 1 / 3)
   float* c;                                     // partial dW  [M_wg][ldc]
   float* bias;                                  // partial db  [M_wg] or nullptr
   long k0, k1;                                  // point range: (k1-k0) % 16 == 0, rows [k0,k1) readable (callers zero-pad G)
   int lda, ldb;
   int ldc, variant;                             // M x N: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64, 4 = 32x256, 5 = 32x128;
-                                                // | 0x100: bf16 operands (mixed-precision training), fp32 accumulate
+                                                // | 0x100: bf16 operands (mixed-precision training), fp32 accumulate;
+                                                // | 0x200: G and the 256-wide activations are stored as bf16 (the embedded
+                                                //   inputs of variants 1 / 3 stay fp32); lda / ldb stay in ELEMENTS
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -43,22 +45,22 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid;
 // replaced by the last real chunk of the task ((k1-k0) % KB == 0) -- a wave-uniform select on the chunk base, so the
 // per-thread part of the address is a 32-bit byte offset computed once per task (off[it]) and a DMA instruction costs one
 // address add instead of a 64-bit multiply + per-row clamp.
-template <int W>
+template <int W, int ES>                        // ES = element size in bytes (4: fp32 tile, 2: bf16 tile)
 struct RowStager {
-  static constexpr int CHUNKS = KB * W / 4;      // 16-byte pieces per chunk
-  static constexpr int PER_ROW = W / 4;
+  static constexpr int CHUNKS = KB * W * ES / 16;   // 16-byte pieces per chunk
+  static constexpr int PER_ROW = W * ES / 16;
   static constexpr int IT = (CHUNKS + 255) / 256;
   unsigned off[IT];
   SN_DEV void init(int ld, int tid) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int c = it * 256 + tid;
-      off[it] = (unsigned)((c / PER_ROW) * ld + (c % PER_ROW) * 4) * 4u;
+      off[it] = (unsigned)((c / PER_ROW) * ld * ES + (c % PER_ROW) * 16);
     }
   }
-  SN_DEV void stage(const float* __restrict__ g, int ld, long k, long k_end, char* lds, int tid) const {
+  SN_DEV void stage(const void* __restrict__ g, int ld, long k, long k_end, char* lds, int tid) const {
     const long kc = k < k_end ? k : k_end - KB;
-    const char* base = reinterpret_cast<const char*>(g + kc * ld);             // wave-uniform
+    const char* base = reinterpret_cast<const char*>(g) + kc * ld * ES;        // wave-uniform
     const int wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -88,14 +90,17 @@ SN_DEV unsigned dw_pack2(float a, float b) {
 // k-step of v_mfma_f32_32x32x16_bf16: lane (i, h) gathers its 8 points of feature i from the LDS tile (stride = row pitch,
 // conflict-free across lanes), converts them to a bf16x8 fragment (RNE) and keeps the fp32 column sums for the bias
 // gradient.  16 MFMAs of 32 cycles per chunk instead of 128 of 64: the kernel becomes HBM-bound.
-template <int MT, int NT, int WM, int WN, bool BF16>
+// MODE 0: fp32 MFMAs.  1: bf16 MFMAs, fp32 tiles.  2: bf16 MFMAs, bf16 A and B tiles.  3: bf16 MFMAs, bf16 A tile, fp32 B tile.
+template <int MT, int NT, int WM, int WN, int MODE>
 SN_DEV void run_task(const Task& t, char* smem, int tid) {
+  constexpr bool BF16 = MODE != 0;
+  constexpr int EA = (MODE >= 2) ? 2 : 4, EB = (MODE == 2) ? 2 : 4;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int WA = WM * MT * 32, WB = WN * NT * 32;
-  constexpr int A_BYTES = KB * WA * 4, B_BYTES = KB * WB * 4, BUF = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = KB * WA * EA, B_BYTES = KB * WB * EB, BUF = A_BYTES + B_BYTES;
   // DMA instructions per thread per chunk.  A 32-wide A tile (variants 4/5) is only 128 16-byte pieces: waves 2,3 issue
   // none of it, so their vmcnt budget is one instruction per chunk smaller (the wait must be exact per wave).
-  constexpr int CH_A = KB * WA / 4, CH_B = KB * WB / 4;
+  constexpr int CH_A = KB * WA * EA / 16, CH_B = KB * WB * EB / 16;
   static_assert(CH_B % 256 == 0 && CH_A % 64 == 0, "staging predicates must be wave-uniform");
   constexpr int IT_A = (CH_A + 255) / 256, IT_B = CH_B / 256, PART_A = (CH_A % 256) / 64;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,8 +121,8 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
 
   const long k0 = t.k0, k1 = t.k1;
   if (k0 >= k1) return;
-  RowStager<WA> sa;
-  RowStager<WB> sb;
+  RowStager<WA, EA> sa;
+  RowStager<WB, EB> sb;
   sa.init(t.lda, tid);
   sb.init(t.ldb, tid);
   const int n_chunks = (int)((k1 - k0 + KB - 1) / KB);
@@ -147,21 +152,39 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
       dw_bf16x8 af[MT], bf[NT];
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
-        float v[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) v[jj] = la[(7 * h + jj) * WA + 32 * a];      // la already carries h * WA: row 8h + jj
         dw_u32x4 q;
+        if (EA == 2) {                                                     // bf16 tile: two points per dword, no conversion
+          const unsigned short* l16 = reinterpret_cast<const unsigned short*>(bc) + 8 * h * WA + m0 + i + 32 * a;
+          float sum = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) q[w] = dw_pack2(v[2 * w], v[2 * w + 1]);
+          for (int w = 0; w < 4; ++w) {
+            const unsigned lo = l16[(2 * w) * WA], hi = l16[(2 * w + 1) * WA];
+            q[w] = lo | (hi << 16);
+            sum += __builtin_bit_cast(float, lo << 16) + __builtin_bit_cast(float, hi << 16);
+          }
+          bsum[a] += sum;
+        } else {
+          float v[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) v[jj] = la[(7 * h + jj) * WA + 32 * a];    // la already carries h * WA: row 8h + jj
+#pragma unroll
+          for (int w = 0; w < 4; ++w) q[w] = dw_pack2(v[2 * w], v[2 * w + 1]);
+          bsum[a] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
         af[a] = __builtin_bit_cast(dw_bf16x8, q);
-        bsum[a] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       }
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
         dw_u32x4 q;
+        if (EB == 2) {
+          const unsigned short* l16 = reinterpret_cast<const unsigned short*>(bc + A_BYTES) + 8 * h * WB + n0 + i + 32 * b;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
-          q[w] = dw_pack2(lb[(7 * h + 2 * w) * WB + 32 * b], lb[(7 * h + 2 * w + 1) * WB + 32 * b]);
+          for (int w = 0; w < 4; ++w) q[w] = (unsigned)l16[(2 * w) * WB] | ((unsigned)l16[(2 * w + 1) * WB] << 16);
+        } else {
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+            q[w] = dw_pack2(lb[(7 * h + 2 * w) * WB + 32 * b], lb[(7 * h + 2 * w + 1) * WB + 32 * b]);
+        }
         bf[b] = __builtin_bit_cast(dw_bf16x8, q);
       }
 #pragma unroll
@@ -210,23 +233,28 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks)
   const Task t = tasks[blockIdx.x];
   const int tid = threadIdx.x;
   if (t.variant & 0x100) {
-    switch (t.variant & 0xff) {
-      case 0: run_task<4, 4, 2, 2, true>(t, smem, tid); break;
-      case 1: run_task<4, 1, 2, 2, true>(t, smem, tid); break;
-      case 2: run_task<2, 4, 2, 2, true>(t, smem, tid); break;
-      case 3: run_task<2, 1, 2, 2, true>(t, smem, tid); break;
-      case 4: run_task<1, 2, 1, 4, true>(t, smem, tid); break;
-      default: run_task<1, 1, 1, 4, true>(t, smem, tid); break;
+    const int mode = (t.variant & 0x200) ? 2 : 1;     // 0x200: G and the activations are stored as bf16
+#define SN_DW_CASES(MODE_, MODE_EMB_)                                   \
+    switch (t.variant & 0xff) {                                         \
+      case 0: run_task<4, 4, 2, 2, MODE_>(t, smem, tid); break;         \
+      case 1: run_task<4, 1, 2, 2, MODE_EMB_>(t, smem, tid); break;     \
+      case 2: run_task<2, 4, 2, 2, MODE_>(t, smem, tid); break;         \
+      case 3: run_task<2, 1, 2, 2, MODE_EMB_>(t, smem, tid); break;     \
+      case 4: run_task<1, 2, 1, 4, MODE_>(t, smem, tid); break;         \
+      default: run_task<1, 1, 1, 4, MODE_>(t, smem, tid); break;        \
     }
+    // variants 1 / 3 contract with the embedded inputs, which stay fp32 in every mode
+    if (mode == 1) { SN_DW_CASES(1, 1) } else { SN_DW_CASES(2, 3) }
+#undef SN_DW_CASES
     return;
   }
   switch (t.variant) {
-    case 0: run_task<4, 4, 2, 2, false>(t, smem, tid); break;
-    case 1: run_task<4, 1, 2, 2, false>(t, smem, tid); break;
-    case 2: run_task<2, 4, 2, 2, false>(t, smem, tid); break;
-    case 3: run_task<2, 1, 2, 2, false>(t, smem, tid); break;
-    case 4: run_task<1, 2, 1, 4, false>(t, smem, tid); break;
-    default: run_task<1, 1, 1, 4, false>(t, smem, tid); break;
+    case 0: run_task<4, 4, 2, 2, 0>(t, smem, tid); break;
+    case 1: run_task<4, 1, 2, 2, 0>(t, smem, tid); break;
+    case 2: run_task<2, 4, 2, 2, 0>(t, smem, tid); break;
+    case 3: run_task<2, 1, 2, 2, 0>(t, smem, tid); break;
+    case 4: run_task<1, 2, 1, 4, 0>(t, smem, tid); break;
+    default: run_task<1, 1, 1, 4, 0>(t, smem, tid); break;
   }
 }
 

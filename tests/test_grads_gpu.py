@@ -322,3 +322,27 @@ def test_bf16_weight_gradient_launch_close_to_fp32():
         assert np.linalg.norm(w32 - w16) / np.linalg.norm(w32) < 5e-3, k
         if b32 is not None:
             assert np.linalg.norm(b32 - b16) / np.linalg.norm(b32) < 1e-5, k
+
+
+def test_weight_gradient_launch_from_bf16_stored_state():
+    """sn_dw_gemm reading G and the activations stored as bf16 (variant | 0x300) = the bf16-operand launch on the same
+    values held in fp32: identical operands, so the results agree to fp32 summation noise."""
+    from sinnerf_amd import _lib, autograd as A
+    d = dev()
+    P = 4096
+    torch.manual_seed(1)
+    acts16 = torch.randn((10, P, 256), device=d).bfloat16(); G16 = torch.randn((10, P, 256), device=d).bfloat16()
+    emb = torch.randn((P, 128), device=d)
+    res = {}
+    for name, (a, g) in (("fp32-held", (acts16.float(), G16.float())), ("bf16-held", (acts16, G16))):
+        rows, outs = A._dw_tasks(a, emb, g, bf16=True)
+        tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(d)
+        _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], None), "dw")
+        torch.cuda.synchronize()
+        res[name] = {k: (c.sum(0).cpu().numpy(), None if b is None else b.sum(0).cpu().numpy()) for k, c, b in outs}
+    for k, (w32, b32) in res["fp32-held"].items():
+        w16, b16 = res["bf16-held"][k]
+        assert np.isfinite(w16).all(), k
+        assert np.linalg.norm(w32 - w16) / np.linalg.norm(w32) < 1e-5, (k, np.linalg.norm(w32 - w16) / np.linalg.norm(w32))
+        if b32 is not None:
+            assert np.linalg.norm(b32 - b16) / np.linalg.norm(b32) < 1e-5, k
