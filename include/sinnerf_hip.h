@@ -21,6 +21,8 @@ extern "C" {
 
 #define SN_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32                                          */
 #define SN_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate                    */
+#define SN_DTYPE_BF16_STATE 2 /* training entries only: SN_DTYPE_BF16 arithmetic AND acts / g_acts stored as bf16
+                               * (same shapes; the float* parameters then point at bf16 arrays; emb stays fp32)   */
 
 #define SN_E_BADARG (-1)
 #define SN_E_TOOLARGE (-2)

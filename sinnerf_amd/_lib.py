@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SINNERF_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 
 SN_DTYPE_F32 = 0
 SN_DTYPE_BF16 = 1
+SN_DTYPE_BF16_STATE = 2
 SN_FLAG_NO_LDS_DMA = 1
 N_RAW_TENSORS = 24
 

@@ -123,10 +123,15 @@ class _MLPFn(torch.autograd.Function):
         P = n * s
         dev = rays.device
         code = dtype_code(model.compute_dtype)
+        # mixed precision keeps the training state (activations, pre-activation gradients) in bf16 as well: every stage of
+        # that mode is HBM-bound on exactly this traffic, and the stored values are the ones the kernels consume anyway
+        bf16 = code == _lib.SN_DTYPE_BF16
+        if bf16:
+            code = _lib.SN_DTYPE_BF16_STATE
         out = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
-        tile = 256 if code == _lib.SN_DTYPE_BF16 else 128
+        tile = 256 if bf16 else 128
         rows = -(-P // tile) * tile                    # the training forward stores whole point tiles (pad rows: finite
-        acts = torch.empty((10, rows, 256), dtype=torch.float32, device=dev)   # copies of the last point, zero gradient)
+        acts = torch.empty((10, rows, 256), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)   # copies of the last point, zero gradient)
         emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
         _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                                  _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
@@ -143,12 +148,14 @@ class _MLPFn(torch.autograd.Function):
         P, rows = ctx.n_points, acts.shape[1]
         dev = acts.device
         g_out = g_out.contiguous().float()
-        G = torch.empty((10, rows, 256), dtype=torch.float32, device=dev)
+        G = torch.empty((10, rows, 256), dtype=acts.dtype, device=dev)
         if rows > P:
             G[:, P:].zero_()
         g_o = torch.empty((P, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain; G, the weight gradients and Adam stay fp32
+            code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
+            if acts.dtype == torch.bfloat16:
+                code = _lib.SN_DTYPE_BF16_STATE
             _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(model.compute_dtype)), code,
                                                       _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")

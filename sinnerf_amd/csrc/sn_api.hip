@@ -10,7 +10,8 @@ int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* i
 int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
-                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
+                                      long n_points, long slot_rows, float* G, float* g_out, int state_bf16,
+                                      hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
 int sn_generate_rays_launch(const float* c2w, int H, int W, float focal, float near, float far, int x0, int y0, int sx,
                             int sy, int pw, int ph, float* rays, hipStream_t stream);
@@ -23,7 +24,7 @@ int sn_render_loss_launch(const float* rgb_c, const float* rgb_f, const float* d
                           void* workspace, float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
-                               hipStream_t stream);
+                               int state_bf16, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
                                  const float* g_depth, const float* g_w, float* g_raw, hipStream_t stream);
@@ -142,7 +143,7 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
   if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   if (dtype == SN_DTYPE_BF16)
     return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out, nullptr,
-                                      nullptr, 0, (hipStream_t)stream);
+                                      nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
                                    1, out, nullptr, nullptr, 0, (hipStream_t)stream);
@@ -151,13 +152,13 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                          float* out, float* acts, float* emb, long slot_rows, void* stream) {
   if (!blob || !rays || !z_vals || !out || !acts || !emb || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
   const long n_points = n_rays * (long)n_samples;
-  const long tile = dtype == SN_DTYPE_BF16 ? 256 : 128;                      // whole point tiles are stored
+  const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are stored
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
-  if (dtype == SN_DTYPE_BF16)
+  if (dtype != SN_DTYPE_F32)
     return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
-                                      (hipStream_t)stream);
+                                      dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, 1, out, acts, emb, slot_rows,
                                    (hipStream_t)stream);
 }
@@ -165,12 +166,12 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream) {
   if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
-  const long tile = dtype == SN_DTYPE_BF16 ? 256 : 128;                      // whole point tiles are written
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
+  const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are written
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
-  if (dtype == SN_DTYPE_BF16)
+  if (dtype != SN_DTYPE_F32)
     return sn_mlp_backward_chain_bf16_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
-                                             (hipStream_t)stream);
+                                             dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
   return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
                                           (hipStream_t)stream);
 }
@@ -224,7 +225,7 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   if (!blob || !x || !out || n_rows < 0) return SN_E_BADARG;
   if (ld < (sigma_only ? 63 : 90)) return SN_E_BADSHAPE;
   if (dtype == SN_DTYPE_BF16)
-    return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
+    return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, 1,
                                    out, nullptr, nullptr, 0, (hipStream_t)stream);

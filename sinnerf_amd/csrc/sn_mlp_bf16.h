@@ -35,27 +35,42 @@ SN_DEV u32x4 pack8(const float* v) {
 // slot apart (the compiler pads every VALU <-> inline-asm dependence with an s_nop for the dst_sel forwarding hazard
 // it has to assume), and as volatile asm they keep their program order relative to the MFMA asm -- which is what keeps
 // the MFMA-result hazard distance.
-SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3) {          // hidden layer: pack, ReLU on the pairs
-  uint32_t t0, t1;
+// (the packed dwords t0, t1 = the bf16 pairs written to the AGPR file are returned: the bf16-state training variants
+//  store exactly these values)
+SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1) {   // pack, ReLU on the pairs
   asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
                "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\t"
                "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
                : "=&v"(t0), "=&v"(t1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
 }
-SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3) {          // no activation
+SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3) {
   uint32_t t0, t1;
+  epi_relu(reg, x0, x1, x2, x3, t0, t1);
+}
+SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1) {   // no activation
   asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
                "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
                : "=&v"(t0), "=&v"(t1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
 }
-SN_DEV void epi_relu_f32(int reg, float x0, float x1, float x2, float x3, float (&v)[4]) {   // fp32 ReLU, kept for the head
+SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3) {
   uint32_t t0, t1;
+  epi_copy(reg, x0, x1, x2, x3, t0, t1);
+}
+SN_DEV void epi_relu_f32(int reg, float x0, float x1, float x2, float x3, float (&v)[4], uint32_t& t0, uint32_t& t1) {   // fp32 ReLU
   asm volatile("v_max_f32 %2, 0, %6\n\tv_max_f32 %3, 0, %7\n\tv_max_f32 %4, 0, %8\n\tv_max_f32 %5, 0, %9\n\t"
                "v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
                "v_accvgpr_write_b32 a[%10], %0\n\tv_accvgpr_write_b32 a[%11], %1"
                : "=&v"(t0), "=&v"(t1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
                : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
 }
+SN_DEV void epi_relu_f32(int reg, float x0, float x1, float x2, float x3, float (&v)[4]) {   // ... kept for the sigma head
+  uint32_t t0, t1;
+  epi_relu_f32(reg, x0, x1, x2, x3, v, t0, t1);
+}
+// Training variants that keep the state in bf16: per-wave staging tile of packed rows (32 points x 32 features x 2 B,
+// pitch 80 B), read back as 16-byte chunks -- one store instruction writes sixteen whole 64-byte rows.
+constexpr int XP16_PITCH = 80;
+constexpr int XP16_WAVE_BYTES = 32 * XP16_PITCH;            // 2560
 // D = A.B + D, D and A in VGPRs; B = a[reg : reg+3] ...
 // FIRST = first MFMA of a slab on this accumulator: its C operand was just written by VALU moves / its B operands by the
 // previous layer's v_accvgpr_write, and a VALU write -> MFMA read needs 2 wait states the compiler cannot insert for asm.

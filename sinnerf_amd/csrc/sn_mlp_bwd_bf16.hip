@@ -21,8 +21,8 @@ constexpr int BWD16_LDS_BYTES = BWD16_TAIL_BYTES + 3 * BWD16_RING_SLOT + 4 * PT 
 
 // masked epilogue block: four accumulator values x, four activations a -> v = (a > 0 ? x : 0) (returned for the store),
 // packed to bf16 into a[reg], a[reg+1]
-SN_DEV void epi_mask(int reg, float x0, float x1, float x2, float x3, float a0, float a1, float a2, float a3, float (&v)[4]) {
-  uint32_t t0, t1;
+SN_DEV void epi_mask(int reg, float x0, float x1, float x2, float x3, float a0, float a1, float a2, float a3, float (&v)[4],
+                     uint32_t& t0, uint32_t& t1) {
   asm volatile("v_cmp_lt_f32 vcc, 0, %10\n\tv_cndmask_b32 %2, 0, %6, vcc\n\t"
                "v_cmp_lt_f32 vcc, 0, %11\n\tv_cndmask_b32 %3, 0, %7, vcc\n\t"
                "v_cmp_lt_f32 vcc, 0, %12\n\tv_cndmask_b32 %4, 0, %8, vcc\n\t"
@@ -34,6 +34,9 @@ SN_DEV void epi_mask(int reg, float x0, float x1, float x2, float x3, float a0, 
                : "vcc");
 }
 
+// S16: acts and G are bf16 arrays (SN_DTYPE_BF16_STATE): half the HBM traffic of this bandwidth-bound kernel; G then holds
+// exactly the bf16 values the next transposed layer and the weight-gradient kernel consume.
+template <bool S16>
 __global__ void __launch_bounds__(256)
 mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restrict__ acts, const float* __restrict__ out_raw,
                           const float* __restrict__ g_raw, long P, long slot_rows, float* __restrict__ G,
@@ -88,6 +91,9 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
   const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
+  const unsigned xp16_w = (unsigned)(j * XP16_PITCH + 8 * h);
+  const unsigned xp16_r = (unsigned)((lane >> 2) * XP16_PITCH + 16 * (lane & 3));
+  const unsigned g16_off = (unsigned)((lane >> 2) * 512 + 16 * (lane & 3));
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * (PT * 32);
@@ -113,10 +119,17 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
         reinterpret_cast<float4*>(g_out)[p_raw] = gy;                     // g_y of rgb.0 (3) and of sigma (1)
         // the same 4 values as a zero-padded 32-wide block in the unused half of slot 9 (columns 128..159): the A operand
         // of the rgb / sigma weight-gradient contractions (sn_dw.hip variants 4/5)
-        float4* row = reinterpret_cast<float4*>(G + ((long)9 * slot_rows + p_raw) * 256 + 128);
-        row[0] = gy;
+        if (S16) {
+          uint4* row = reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(G) + ((long)9 * slot_rows + p_raw) * 256 + 128);
+          row[0] = make_uint4(pack2(gy.x, gy.y), pack2(gy.z, gy.w), 0u, 0u);
 #pragma unroll
-        for (int q = 1; q < 8; ++q) row[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          for (int q = 1; q < 4; ++q) row[q] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+          float4* row = reinterpret_cast<float4*>(G + ((long)9 * slot_rows + p_raw) * 256 + 128);
+          row[0] = gy;
+#pragma unroll
+          for (int q = 1; q < 8; ++q) row[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
       }
     }
 
@@ -126,27 +139,56 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
     auto load_act = [&](int slot, int t) __attribute__((always_inline)) {
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
-        const float* src = acts + ((long)slot * slot_rows + p[pt]) * 256 + 32 * t + 4 * h;
+        if (S16) {
+          const unsigned short* src = reinterpret_cast<const unsigned short*>(acts) + ((long)slot * slot_rows + p[pt]) * 256 + 32 * t + 4 * h;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) av[pt][q4] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 8 * q4));
+          for (int q4 = 0; q4 < 4; ++q4) {
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t u = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(src + 8 * q4));
+            av[pt][q4][0] = __builtin_bit_cast(float, u[0] << 16); av[pt][q4][1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+            av[pt][q4][2] = __builtin_bit_cast(float, u[1] << 16); av[pt][q4][3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+          }
+        } else {
+          const float* src = acts + ((long)slot * slot_rows + p[pt]) * 256 + 32 * t + 4 * h;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) av[pt][q4] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 8 * q4));
+        }
       }
     };
-    auto stage = [&](int pt, int qq, const float (&v)[4]) __attribute__((always_inline)) {
-      f32x4 o;
-      o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-      *reinterpret_cast<f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_w + 32 * qq) = o;
+    auto stage = [&](int pt, int qq, const float (&v)[4], uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
+      if (S16) {
+        uint2 o;
+        o.x = t0; o.y = t1;
+        *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xp16_w + 16 * qq) = o;
+      } else {
+        f32x4 o;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        *reinterpret_cast<f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_w + 32 * qq) = o;
+      }
     };
     auto store_tile = [&](int slot, int t) __attribute__((always_inline)) {      // rows >= P receive the zeros their lanes hold
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
+      for (int pt = 0; pt < PT; ++pt) {
+        if (S16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_r + 8 * i * XPOSE_PITCH * 4);
-          char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * t) * 4;
-          unsigned go = g_off;
-          asm volatile("" : "+v"(go));
-          __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+          for (int i = 0; i < 2; ++i) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp16_r + 16 * i * XP16_PITCH);
+            char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 16 * i) * 256 + 32 * t) * 2;
+            unsigned go = g16_off;
+            asm volatile("" : "+v"(go));
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_r + 8 * i * XPOSE_PITCH * 4);
+            char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * t) * 4;
+            unsigned go = g_off;
+            asm volatile("" : "+v"(go));
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+          }
         }
+      }
     };
 
     // ---- rgb.0^T on the VALU: g_h2 = W_r^T g_y3 ; g_y2 = g_h2 (1 - exp(-h2)); written to set 0 (K-slots 16t + r)
@@ -167,8 +209,9 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
             const float gh = __builtin_fmaf(w2, gy3[pt][2], __builtin_fmaf(w1, gy3[pt][1], w0 * gy3[pt][0]));
             v[i] = gh * (1.0f - __expf(-av[pt][r >> 2][r & 3]));
           }
-          epi_copy(act_reg(0, 2 * t + (q >> 2), pt) + (q & 3), v[0], v[1], v[2], v[3]);
-          stage(pt, q >> 1, v);
+          uint32_t t0, t1;
+          epi_copy(act_reg(0, 2 * t + (q >> 2), pt) + (q & 3), v[0], v[1], v[2], v[3], t0, t1);
+          stage(pt, q >> 1, v, t0, t1);
         }
       store_tile(9, t);
     }
@@ -182,9 +225,10 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
-          epi_copy(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]);
+          uint32_t t0, t1;
+          epi_copy(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1);
           const float v[4] = {r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]};
-          stage(pt, q >> 1, v);
+          stage(pt, q >> 1, v, t0, t1);
         }
       store_tile(8, t);
     };
@@ -204,8 +248,9 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
           }
           float v[4];
           const f32x4 a = av[pt][q >> 1];
-          epi_mask(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), x[0], x[1], x[2], x[3], a[0], a[1], a[2], a[3], v);
-          stage(pt, q >> 1, v);
+          uint32_t t0, t1;
+          epi_mask(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), x[0], x[1], x[2], x[3], a[0], a[1], a[2], a[3], v, t0, t1);
+          stage(pt, q >> 1, v, t0, t1);
         }
       store_tile(out_slot, t);
     };
@@ -272,18 +317,23 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
 
 extern "C" int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float* acts, const float* out_raw,
                                                  const float* g_raw, long n_points, long slot_rows, float* G,
-                                                 float* g_out, hipStream_t stream) {
+                                                 float* g_out, int state_bf16, hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 255) / 256;
   if (slot_rows < tiles * 256) return -1;
   int dev = 0, n_cu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-  auto kfn = mlp_bwd_chain_bf16_kernel;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)BWD16_LDS_BYTES);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles < n_cu ? tiles : n_cu)), dim3(256), BWD16_LDS_BYTES, stream,
-                     reinterpret_cast<const char*>(bblob), acts, out_raw, g_raw, n_points, slot_rows, G, g_out);
+#define SN_LAUNCH(S16_)                                                                                            \
+  do {                                                                                                             \
+    auto kfn = mlp_bwd_chain_bf16_kernel<S16_>;                                                                    \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)BWD16_LDS_BYTES);                                                      \
+    if (e != hipSuccess) return (int)e;                                                                            \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles < n_cu ? tiles : n_cu)), dim3(256), BWD16_LDS_BYTES, stream,     \
+                       reinterpret_cast<const char*>(bblob), acts, out_raw, g_raw, n_points, slot_rows, G, g_out); \
+  } while (0)
+  if (state_bf16) SN_LAUNCH(true); else SN_LAUNCH(false);
+#undef SN_LAUNCH
   return (int)hipGetLastError();
 }

@@ -41,7 +41,9 @@ namespace snk {
 // STORE: training forward with bf16 contractions -- additionally writes the fp32 activations of every layer
 // (acts[10][slot_rows][256]: the fp32 values BEFORE their bf16 rounding) and the fp32 embedded inputs (emb[slot_rows][128])
 // that the fp32 backward (sn_mlp_bwd.hip, sn_dw.hip) consumes: bf16 forward + fp32 backward, i.e. mixed precision.
-template <bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
+// STORE 2: the activations are stored as bf16 (acts is then a bf16 array of the same shape: exactly the values the next
+// layer consumed); emb stays fp32.
+template <bool SIGMA_ONLY, int INPUT_MODE, int STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1,
                     long P, int S, float* __restrict__ out, float* __restrict__ acts, float* __restrict__ emb,
@@ -94,6 +96,9 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
+  const unsigned xp16_w = (unsigned)(j * XP16_PITCH + 8 * h);                       // bf16 state: this lane's packed pairs
+  const unsigned xp16_r = (unsigned)((lane >> 2) * XP16_PITCH + 16 * (lane & 3));    // row lane>>2, 16-byte chunk lane&3
+  const unsigned g16_off = (unsigned)((lane >> 2) * 512 + 16 * (lane & 3));
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * (PT * 32);    // wave-uniform
@@ -156,14 +161,21 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     // acts[slot][point][32t..32t+31] as whole 128-byte rows, non-temporal.
     int cur_slot = 0;
     auto stage = [&](int pt, int qq, const float (&v)[4]) __attribute__((always_inline)) {
-      if (STORE) {
+      if (STORE == 1) {
         f32x4 o;
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
         *reinterpret_cast<f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_w + 32 * qq) = o;
       }
     };
+    auto stage16 = [&](int pt, int qq, uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
+      if (STORE == 2) {
+        uint2 o;
+        o.x = t0; o.y = t1;
+        *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xp16_w + 16 * qq) = o;
+      }
+    };
     auto store_tile = [&](int slot, int t) __attribute__((always_inline)) {
-      if (STORE) {
+      if (STORE == 1) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -172,6 +184,17 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * t) * 4;
             unsigned go = g_off;
             asm volatile("" : "+v"(go));         // opaque per store: no hoisted per-slot address registers
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+          }
+      } else if (STORE == 2) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp16_r + 16 * i * XP16_PITCH);
+            char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 16 * i) * 256 + 32 * t) * 2;
+            unsigned go = g16_off;
+            asm volatile("" : "+v"(go));
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
           }
       }
@@ -185,12 +208,14 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
           const int reg = act_reg(W, 2 * t + (q >> 2), pt) + (q & 3);
-          if (STORE) {
+          if (STORE == 1) {
             float v[4];
             epi_relu_f32(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v);
             stage(pt, q >> 1, v);
           } else {
-            epi_relu(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]);
+            uint32_t t0, t1;
+            epi_relu(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1);
+            stage16(pt, q >> 1, t0, t1);
           }
         }
       store_tile(cur_slot, t);
@@ -205,7 +230,9 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
           float v[4];
-          epi_relu_f32(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v);
+          uint32_t t0, t1;
+          epi_relu_f32(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v, t0, t1);
+          stage16(pt, q >> 1, t0, t1);
           sg[pt] = __builtin_fmaf(w[0], v[0], sg[pt]);
           sg[pt] = __builtin_fmaf(w[1], v[1], sg[pt]);
           sg[pt] = __builtin_fmaf(w[2], v[2], sg[pt]);
@@ -221,9 +248,11 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
-          epi_copy(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]);
+          uint32_t t0, t1;
+          epi_copy(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1);
           const float v[4] = {r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]};
           stage(pt, q >> 1, v);
+          stage16(pt, q >> 1, t0, t1);
         }
       store_tile(8, t);
     };
@@ -362,6 +391,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             for (int c = 0; c < 3; ++c) c3[pt][c] = __builtin_fmaf(w[c][i], v[i], c3[pt][c]);
           }
           stage(pt, q, v);
+          if (STORE == 2) stage16(pt, q, pack2(v[0], v[1]), pack2(v[2], v[3]));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -401,7 +431,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 
 extern "C" int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                           int sigma_only, int input_mode, float* out, float* acts, float* emb,
-                                          long slot_rows, hipStream_t stream) {
+                                          long slot_rows, int state_bf16, hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 255) / 256;
@@ -419,9 +449,9 @@ extern "C" int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, co
     if (e != hipSuccess) return (int)e;                                                                          \
     hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows); \
   } while (0)
-  if (store) SN_LAUNCH(false, 0, true);
-  else if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false); }
-  else { if (sigma_only) SN_LAUNCH(true, 1, false); else SN_LAUNCH(false, 1, false); }
+  if (store) { if (state_bf16) SN_LAUNCH(false, 0, 2); else SN_LAUNCH(false, 0, 1); }
+  else if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, 0); else SN_LAUNCH(false, 0, 0); }
+  else { if (sigma_only) SN_LAUNCH(true, 1, 0); else SN_LAUNCH(false, 1, 0); }
 #undef SN_LAUNCH
   return (int)hipGetLastError();
 }

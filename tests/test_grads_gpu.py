@@ -298,6 +298,41 @@ def test_bf16_backward_chain_close_to_fp32_chain():
         assert err < 2e-2, (slot, err)
         assert (G16[slot, P:, :w] == 0).all(), slot
     assert np.array_equal(G32[9, :P, 128:160], G16[9, :P, 128:160])          # the rgb / sigma block of the dW kernel
+    # bf16 state (SN_DTYPE_BF16_STATE): the forward stores bf16 activations, the chain reads them and writes bf16 G --
+    # the same values rounded once more
+    acts16 = torch.empty((10, rows, 256), dtype=torch.bfloat16, device=d); out16 = torch.empty((n, S, 4), device=d)
+    emb16 = torch.zeros((rows, 128), device=d)
+    mb, _ = make_model(1, True, dtype="bf16")
+    _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(mb.packed()), 2, _lib.ptr(rays), _lib.ptr(z), n, S, _lib.ptr(out16),
+                                             _lib.ptr(acts16), _lib.ptr(emb16), rows, None), "fwd bf16 state")
+    torch.cuda.synchronize()
+    a32 = acts.cpu().numpy()[:, :P]; a16 = acts16.float().cpu().numpy()[:, :P]
+    for slot in range(10):
+        w = 128 if slot == 9 else 256
+        assert np.linalg.norm(a32[slot, :, :w] - a16[slot, :, :w]) / np.linalg.norm(a32[slot, :, :w]) < 2e-2, slot
+    assert np.abs(emb16.cpu().numpy()[:P] - emb.cpu().numpy()[:P]).max() <= 1e-6
+    # reference for the bf16-state chain: the fp32-state bf16 chain on the SAME activations held in fp32 (a different
+    # forward has different ReLU masks near zero, which is not what is being tested here)
+    Gr = torch.full((10, rows, 256), float("nan"), device=d); Gr[:, P:] = 0
+    g_or = torch.full((P, 4), float("nan"), device=d)
+    acts_f = acts16.float()
+    _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(mb.packed_bwd("bf16")), 1, _lib.ptr(acts_f), _lib.ptr(out16), _lib.ptr(g),
+                                              P, rows, _lib.ptr(Gr), _lib.ptr(g_or), None), "chain bf16, fp32 state")
+    Gs = torch.full((10, rows, 256), float("nan"), dtype=torch.bfloat16, device=d); Gs[:, P:] = 0
+    g_os = torch.full((P, 4), float("nan"), device=d)
+    _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(mb.packed_bwd("bf16")), 2, _lib.ptr(acts16), _lib.ptr(out16), _lib.ptr(g),
+                                              P, rows, _lib.ptr(Gs), _lib.ptr(g_os), None), "chain bf16 state")
+    torch.cuda.synchronize()
+    Gs, Gr = Gs.float().cpu().numpy(), Gr.cpu().numpy()
+    assert np.array_equal(g_os.cpu().numpy(), g_or.cpu().numpy())
+    for slot in range(10):
+        w = 128 if slot == 9 else 256
+        assert np.isfinite(Gs[slot, :, :w]).all(), slot
+        err = np.linalg.norm(Gr[slot, :P, :w] - Gs[slot, :P, :w]) / np.linalg.norm(Gr[slot, :P, :w])
+        assert err < 5e-3, (slot, err)                                      # one more bf16 rounding of the stored value
+        assert (Gs[slot, P:, :w] == 0).all(), slot
+    ref_blk = torch.from_numpy(Gr[9, :P, 128:160]).bfloat16().float().numpy()
+    assert np.array_equal(Gs[9, :P, 128:160], ref_blk)
 
 
 def test_bf16_weight_gradient_launch_close_to_fp32():

@@ -91,10 +91,14 @@ for _ in range(K):
 torch.cuda.synchronize()
 dtb = (time.perf_counter() - t0) / K
 ms_fwd_b, _ = timed(lambda: A._MLPFn.apply(mb[1], rays, z, *mb[1].raw_tensors()))
-ms_chain_b, _ = timed(lambda: _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(mb[1].packed_bwd("bf16")), 1, _lib.ptr(acts), _lib.ptr(outt),
-                                                                        _lib.ptr(g), P, acts.shape[1], _lib.ptr(G), _lib.ptr(g_o), None), "chain"))
+raw_b = A._MLPFn.apply(mb[1], rays, z, *mb[1].raw_tensors())
+acts_b, emb_b, out_b = raw_b.grad_fn.saved_tensors
+G_b = torch.zeros((10, acts_b.shape[1], 256), dtype=acts_b.dtype, device=dev)
+ms_chain_b, _ = timed(lambda: _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(mb[1].packed_bwd("bf16")), 2, _lib.ptr(acts_b), _lib.ptr(out_b),
+                                                                        _lib.ptr(g), P, acts_b.shape[1], _lib.ptr(G_b), _lib.ptr(g_o), None), "chain"))
+ms_dw_b, _ = timed(lambda: A._weight_grads(mb[1], acts_b, emb_b, G_b, g_o, [True] * 24))
 out["bf16_training"] = {"ms_per_step": dtb * 1e3, "train_rays_per_s": N / dtb, "fine_fwd_train_ms": ms_fwd_b,
-                        "fine_bwd_chain_ms": ms_chain_b}
+                        "fine_bwd_chain_ms": ms_chain_b, "fine_dW_ms": ms_dw_b}
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/train_bench.json", "w"), indent=1)
 print(json.dumps(out))
