@@ -135,8 +135,8 @@ def main():
         if world == 1:
             # secondary figure: one optimisation-shaped step (fwd+bwd of render_rays, 4096 rays, perturb=1, noise_std=1).
             # fp32: every kernel is MFMA-bound (fraction of the fp32 peak).  bf16 = mixed precision (bf16-operand forward,
-            # chain and weight gradients over fp32 activations / gradients in HBM): every kernel is bound by that fp32
-            # traffic, ~51 KB per sample point (10.75 written by the forward, 20.5 moved by the chain, ~20 read by dW).
+            # chain and weight gradients over bf16 activations / gradients in HBM, ~26 KB per sample point: 5.6 written by
+            # the forward, 10.25 moved by the chain, ~10.5 read by dW).
             try:
                 for m in models:
                     m.train()
@@ -160,8 +160,8 @@ def main():
                     tflop = 3489024 * pts / tdt / 1e12
                     res["train_step"].update({"bound": "mfma", "achieved_tflops": tflop, "frac_of_fp32_mfma_peak": tflop / peak})
                 else:
-                    tbs = 51000.0 * pts / tdt / 1e12
-                    res["train_step"].update({"bound": "hbm", "approx_hbm_tb_per_s": tbs, "frac_of_8_tb_per_s": tbs / 8.0})
+                    tbs = 26000.0 * pts / tdt / 1e12
+                    res["train_step"].update({"bound": "mixed (hbm / issue)", "approx_hbm_tb_per_s": tbs, "frac_of_8_tb_per_s": tbs / 8.0})
             except Exception as e:                      # noqa: BLE001
                 res["train_step"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
