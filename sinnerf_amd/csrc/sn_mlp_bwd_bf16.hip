@@ -17,7 +17,8 @@ namespace snk {
 
 constexpr int BWD16_RING_SLOT = RING_SLOT_BYTES_BF16;                      // the forward's ring type (slots of 20480 B; widest slab here 16384)
 constexpr int BWD16_TAIL_BYTES = snl::BB_TAIL_FLOATS * 4;                  // 11776: zero "bias" slots + aux table
-constexpr int BWD16_LDS_BYTES = BWD16_TAIL_BYTES + 3 * BWD16_RING_SLOT + 4 * PT * XPOSE_WAVE_BYTES;   // 110080
+constexpr int BWD16_LDS_BYTES = BWD16_TAIL_BYTES + 3 * BWD16_RING_SLOT + 4 * PT * XPOSE_WAVE_BYTES     // 110080
+                                + 4 * PT * XP16_WAVE_BYTES;   // + per-wave staging of the incoming activation tiles (bf16 state): 130560
 
 // masked epilogue block: four accumulator values x, four activations a -> v = (a > 0 ? x : 0) (returned for the store),
 // packed to bf16 into a[reg], a[reg+1]
@@ -32,6 +33,21 @@ SN_DEV void epi_mask(int reg, float x0, float x1, float x2, float x3, float a0, 
                : "=&v"(t0), "=&v"(t1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
                : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(reg), "n"(reg + 1)
                : "vcc");
+}
+
+// bf16 state: the mask comes straight from the PACKED activation pair (post-ReLU values are >= 0, so "h > 0" is "bits != 0"):
+// min(u, 1) per half -> 0 / 1, 0 - that -> 0x0000 / 0xffff, AND with the packed gradient pair: 2.5 instructions per value
+// instead of 4.5 (unpack, compare, select, convert).  c01 = 0x00010001.
+SN_DEV void epi_mask16(int reg, float x0, float x1, float x2, float x3, uint32_t u0, uint32_t u1, uint32_t c01,
+                       uint32_t& t0, uint32_t& t1) {
+  uint32_t m0, m1;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\t"
+               "v_pk_min_u16 %2, %8, %10\n\tv_pk_min_u16 %3, %9, %10\n\t"
+               "v_pk_sub_u16 %2, 0, %2\n\tv_pk_sub_u16 %3, 0, %3\n\t"
+               "v_and_b32 %0, %0, %2\n\tv_and_b32 %1, %1, %3\n\t"
+               "v_accvgpr_write_b32 a[%11], %0\n\tv_accvgpr_write_b32 a[%12], %1"
+               : "=&v"(t0), "=&v"(t1), "=&v"(m0), "=&v"(m1)
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(u0), "v"(u1), "v"(c01), "n"(reg), "n"(reg + 1));
 }
 
 // S16: acts and G are bf16 arrays (SN_DTYPE_BF16_STATE): half the HBM traffic of this bandwidth-bound kernel; G then holds
@@ -94,6 +110,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
   const unsigned xp16_w = (unsigned)(j * XP16_PITCH + 8 * h);
   const unsigned xp16_r = (unsigned)((lane >> 2) * XP16_PITCH + 16 * (lane & 3));
   const unsigned g16_off = (unsigned)((lane >> 2) * 512 + 16 * (lane & 3));
+  char* const xl = smem + BWD16_TAIL_BYTES + 3 * BWD16_RING_SLOT + 4 * PT * XPOSE_WAVE_BYTES + wave * (PT * XP16_WAVE_BYTES);
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * (PT * 32);
@@ -135,18 +152,43 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
 
     // forward activation tile of both point tiles in the accumulator layout (4 x 16 B per lane and point tile), requested
     // one slab ahead of the epilogue that needs it
-    f32x4 av[PT][4];
-    auto load_act = [&](int slot, int t) __attribute__((always_inline)) {
+    f32x4 av[PT][4];                                                        // fp32 state (and the softplus tile)
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t au[PT][4];                                                      // bf16 state: the packed pairs, accumulator layout
+    f32x4 ald[PT][2];                                                       // ... as loaded (row chunks), before the LDS turn
+    // rows -> accumulator layout through the wave's second staging tile; run right before the epilogue that needs au / av
+    auto act_turn = [&](bool values) __attribute__((always_inline)) {
+      if (S16) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(xl + pt * XP16_WAVE_BYTES + xp16_r + 16 * i * XP16_PITCH) = ald[pt][i];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const u32x2_t u = *reinterpret_cast<const u32x2_t*>(xl + pt * XP16_WAVE_BYTES + xp16_w + 16 * q4);
+            au[pt][q4] = u;
+            if (values) {                                                   // softplus derivative needs the values
+              av[pt][q4][0] = __builtin_bit_cast(float, u[0] << 16); av[pt][q4][1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+              av[pt][q4][2] = __builtin_bit_cast(float, u[1] << 16); av[pt][q4][3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+            }
+          }
+        }
+      }
+    };
+    uint32_t c01 = 0x00010001u;
+    asm volatile("" : "+v"(c01));
+    auto load_act = [&](int slot, int t, bool values = false) __attribute__((always_inline)) {
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         if (S16) {
-          const unsigned short* src = reinterpret_cast<const unsigned short*>(acts) + ((long)slot * slot_rows + p[pt]) * 256 + 32 * t + 4 * h;
+          // row-coalesced: lane -> (row lane>>2 [+16], 16-byte chunk lane&3) of the 32-point x 64-byte tile; 2 loads per
+          // point tile instead of 4 scattered 8-byte ones (64 cache lines per instruction: the TA, not HBM, was the limit)
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-            const u32x2_t u = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(src + 8 * q4));
-            av[pt][q4][0] = __builtin_bit_cast(float, u[0] << 16); av[pt][q4][1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
-            av[pt][q4][2] = __builtin_bit_cast(float, u[1] << 16); av[pt][q4][3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+          for (int i = 0; i < 2; ++i) {
+            const long row = p_wave + pt * 32 + 16 * i + (lane >> 2);
+            const long rc = row < P ? row : P - 1;
+            const char* src = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + rc) * 256 + 32 * t) * 2 + 16 * (lane & 3);
+            ald[pt][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
           }
         } else {
           const float* src = acts + ((long)slot * slot_rows + p[pt]) * 256 + 32 * t + 4 * h;
@@ -194,7 +236,8 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
     // ---- rgb.0^T on the VALU: g_h2 = W_r^T g_y3 ; g_y2 = g_h2 (1 - exp(-h2)); written to set 0 (K-slots 16t + r)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      load_act(9, t);
+      load_act(9, t, true);
+      act_turn(true);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -230,12 +273,12 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
           const float v[4] = {r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]};
           stage(pt, q >> 1, v, t0, t1);
         }
-      store_tile(8, t);
     };
     // g_y = g_h [h > 0]; with_sigma: g_h8 also gets the sigma head's term  sigma.weight[f] g_sigma  (nerf.py:136)
     auto mask_tile_impl = [&](auto wset, auto with_sigma, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
       constexpr int W = decltype(wset)::value;
       constexpr bool SIG = decltype(with_sigma)::value;
+      act_turn(false);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -246,13 +289,16 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
             x[i] = r[pt][2 * q + i];
             if (SIG) x[i] = __builtin_fmaf(lds_aux[snl::BB_AUX_SIGT + h * 128 + 16 * t + 2 * q + i], gsig[pt], x[i]);
           }
-          float v[4];
-          const f32x4 a = av[pt][q >> 1];
+          float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
           uint32_t t0, t1;
-          epi_mask(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), x[0], x[1], x[2], x[3], a[0], a[1], a[2], a[3], v, t0, t1);
+          if (S16) {
+            epi_mask16(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), x[0], x[1], x[2], x[3], au[pt][q >> 1][0], au[pt][q >> 1][1], c01, t0, t1);
+          } else {
+            const f32x4 a = av[pt][q >> 1];
+            epi_mask(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), x[0], x[1], x[2], x[3], a[0], a[1], a[2], a[3], v, t0, t1);
+          }
           stage(pt, q >> 1, v, t0, t1);
         }
-      store_tile(out_slot, t);
     };
     auto mask_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
       mask_tile_impl(wset, std::false_type{}, t, r);
@@ -264,16 +310,19 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
 #define SNC_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
 #define SNC_SNEXT (s + 1 == snl::NBB_SLABS ? 0 : s + 1)
 #define SNC_W(W_) std::integral_constant<int, W_>{}
-    // slab of output tile T_ (literal).  The deferred epilogue of tile T_-1 runs behind the first MFMA pair; the activation
-    // tile of THIS slab's epilogue is requested right after it (MASK_: the layer has a mask to load).
+    // slab of output tile T_ (literal).  The deferred epilogue of tile T_-1 runs behind the first MFMA pair; its row stores and
+    // the loads of the activation tile THIS slab's epilogue needs (MASK_) are issued right after the sync point, so that they
+    // have a whole slab before the next s_waitcnt vmcnt(0).
 #define SNC_SLAB(T_, NK_, SET_, NB_, EPI_, W_, MASK_)                                                              \
   do {                                                                                                             \
     if (((T_) & 1) == 0)                                                                                           \
       slab_bf16<NK_, 0, SET_, SET_, 2, 0, NB_>(acc0, acc1, af, SNC_LW_CUR, static_cast<const u32x4*>(nullptr), SNC_LW_NEXT, lds_zero, SNC_SNEXT, h, \
-          ring, [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNC_W(W_), (T_) - 1, acc1); if (MASK_) load_act(mask_slot, T_); }); \
+          ring, [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNC_W(W_), (T_) - 1, acc1); },           \
+          [&]() __attribute__((always_inline)) { if ((T_) > 0) store_tile(out_slot, (T_) - 1); if (MASK_) load_act(mask_slot, T_); }); \
     else                                                                                                           \
       slab_bf16<NK_, 0, SET_, SET_, 2, 0, NB_>(acc1, acc0, af, SNC_LW_CUR, static_cast<const u32x4*>(nullptr), SNC_LW_NEXT, lds_zero, SNC_SNEXT, h, \
-          ring, [&]() __attribute__((always_inline)) { EPI_(SNC_W(W_), (T_) - 1, acc0); if (MASK_) load_act(mask_slot, T_); }); \
+          ring, [&]() __attribute__((always_inline)) { EPI_(SNC_W(W_), (T_) - 1, acc0); },                         \
+          [&]() __attribute__((always_inline)) { store_tile(out_slot, (T_) - 1); if (MASK_) load_act(mask_slot, T_); }); \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
   } while (0)
 #define SNC_LAYER(NK_, SET_, NBA_, NBB_, EPI_, W_, MASK_)   \
@@ -288,9 +337,11 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
     SNC_SLAB(7, NK_, SET_, NBB_, EPI_, W_, MASK_);          \
     mfma_result_fence();                                    \
     EPI_(SNC_W(W_), 7, acc1);                               \
+    store_tile(out_slot, 7);                                \
   } while (0)
 
     // ---- dir_encoding.0^T (first 256 inputs): g_final = W_d[:, :256]^T g_y2; reads set 0 (8 k-steps), writes set 1
+    out_slot = 8;
     SNC_LAYER(8, 0, B_D, B_H, copy_tile, 1, false);
     // ---- xyz_encoding_final^T (+ sigma^T on the VALU): g_y8 = (W_f^T g_final + w_sigma g_sigma) [h8 > 0]; set 1 -> set 0
     mask_slot = 7; out_slot = 7;

@@ -218,7 +218,6 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             stage16(pt, q >> 1, t0, t1);
           }
         }
-      store_tile(cur_slot, t);
     };
     // layer 8: fp32 ReLU first, its output also feeds the sigma head (nerf.py:136)
     auto relu_sigma_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
@@ -240,7 +239,6 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           stage(pt, q >> 1, v);
         }
       }
-      store_tile(7, t);
     };
     auto copy_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {     // xyz_encoding_final
       constexpr int W = decltype(wset)::value;
@@ -254,7 +252,6 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           stage(pt, q >> 1, v);
           stage16(pt, q >> 1, t0, t1);
         }
-      store_tile(8, t);
     };
 #define SNB_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SNB_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
@@ -267,10 +264,12 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     if (((T_) & 1) == 0)                                                                                           \
       slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(acc0, acc1, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
                                                      SNB_SNEXT, h, ring,                                           \
-                                                     [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNB_W(W_), (T_) - 1, acc1); }); \
+                                                     [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNB_W(W_), (T_) - 1, acc1); }, \
+                                                     [&]() __attribute__((always_inline)) { if ((T_) > 0) store_tile(cur_slot, (T_) - 1); }); \
     else                                                                                                           \
       slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(acc1, acc0, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
-                                                     SNB_SNEXT, h, ring, [&]() __attribute__((always_inline)) { EPI_(SNB_W(W_), (T_) - 1, acc0); });\
+                                                     SNB_SNEXT, h, ring, [&]() __attribute__((always_inline)) { EPI_(SNB_W(W_), (T_) - 1, acc0); }, \
+                                                     [&]() __attribute__((always_inline)) { store_tile(cur_slot, (T_) - 1); }); \
     SNB_ADVANCE();                                                                                                 \
   } while (0)
     // the 8 output tiles of a layer, T_ literal (it ends up in asm immediates); tiles 6,7 stage the NEXT layer's slabs
@@ -286,6 +285,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     SNB_SLAB(7, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, BV_, EPI_, W_);       \
     mfma_result_fence();                                                  \
     EPI_(SNB_W(W_), 7, acc1);                                             \
+    store_tile(cur_slot, 7);                                              \
   } while (0)
     // bytes of the slab kinds (K * 64): the NB_ argument is the slab TWO ahead in the stream
     constexpr int B_L0 = 64 * 64, B_H = 256 * 64, B_SKIP = 320 * 64, B_DIR = 288 * 64;
@@ -324,6 +324,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     }
 
     // ---- xyz_encoding_final (no activation): reads set 1, writes set 0
+    cur_slot = 8;
     SNB_LAYER(16, 0, 1, 1, 2, B_H, B_DIR, xe, copy_tile, 0);
 
     // ---- dir_encoding + ShiftedSoftplus: reads set 0 and the dir embedding (VGPRs); the rgb head is accumulated from
@@ -395,15 +396,16 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      store_tile(9, t);
     };
     // 18 k-steps per slab: the fragment-ring phase alternates 0,2,0,2 (static); tiles 2,3 stage the next point tile
+    cur_slot = 9;
     SNB_SLAB(0, 16, 2, 0, -1, 2, 0, B_DIR, de, ssp_tile, 0);
     SNB_SLAB(1, 16, 2, 0, -1, 2, 2, B_DIR, de, ssp_tile, 0);
     SNB_SLAB(2, 16, 2, 0, -1, 2, 0, B_L0, de, ssp_tile, 0);
     SNB_SLAB(3, 16, 2, 0, -1, 2, 2, B_L0, de, ssp_tile, 0);
     mfma_result_fence();
     ssp_tile(SNB_W(0), 3, acc1);
+    store_tile(9, 3);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       float o3[3];
