@@ -23,6 +23,8 @@ _VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64), 4: (32,
 _VARIANT_COST = {0: 512, 1: 161, 2: 260, 3: 95, 4: 101, 5: 59}      # measured per-point times (tools/dw_time.py), variant 0 = 512
 # bf16-operand mode: 8x less MFMA time, every variant is bound by its per-CU DMA stream -- measured per-point times again
 _VARIANT_COST_BF16 = {0: 512, 1: 189, 2: 226, 3: 126, 4: 138, 5: 125}
+# ... and with G / the activations stored as bf16 (gather-bound inner loop, half the bytes)
+_VARIANT_COST_BF16_STATE = {0: 512, 1: 222, 2: 256, 3: 163, 4: 171, 5: 141}
 _KB = 16                      # csrc/sn_dw.hip: points per staged chunk
 _TARGET_WGS = 256             # exactly one workgroup per CU per launch
 
@@ -48,7 +50,7 @@ def _dw_tasks(acts, emb, G, bf16=False):
     # rows 0..2 = g_y of rgb, row 3 = g_y of sigma (zero-padded 32-wide block at G[9][:, 128:160], sn_mlp_bwd.hip)
     probs.append((("sig", 10), G[9], 128, 256, acts[7], 0, 256, 4, False))    # sigma  (nerf.py:136)
     probs.append((("rgb", 11), G[9], 128, 256, acts[9], 0, 256, 5, True))     # rgb    (nerf.py:144)
-    cost = _VARIANT_COST_BF16 if bf16 else _VARIANT_COST
+    cost = (_VARIANT_COST_BF16_STATE if G.dtype == torch.bfloat16 else _VARIANT_COST_BF16) if bf16 else _VARIANT_COST
     # 0x100: bf16 operands; 0x200: G and the activations are STORED as bf16 (emb stays fp32)
     state16 = G.dtype == torch.bfloat16
     assert (not state16) or (bf16 and acts.dtype == torch.bfloat16 and emb.dtype == torch.float32)

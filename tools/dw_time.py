@@ -31,3 +31,11 @@ by_var = {}
 for r in rows: by_var.setdefault(r[7] >> 32, []).append(r)
 for v, rs in sorted(by_var.items()):
     print("variant", v, "tasks", len(rs), "alone %.3f ms" % timed(rs), " points/task", rs[0][5] - rs[0][4])
+
+acts16, G16 = acts.bfloat16(), G.bfloat16()
+rows_s, _ = A._dw_tasks(acts16, emb, G16, bf16=True)
+print("bf16 state %.3f ms" % timed(rows_s))
+print("bf16 state hot (ld=0) %.3f ms" % timed([r[:6] + (0, r[7]) for r in rows_s]))
+bys = {}
+for r in rows_s: bys.setdefault((r[7] >> 32) & 0xff, []).append(r)
+for v, rs in sorted(bys.items()): print("bf16 state variant", v, "tasks", len(rs), "alone %.3f ms" % timed(rs), "points/task", rs[0][5] - rs[0][4])
