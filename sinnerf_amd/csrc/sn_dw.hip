@@ -132,66 +132,93 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
     sa.stage(t.a, t.lda, k0 + (long)c * KB, k1, smem + c * BUF, tid);
     sb.stage(t.b, t.ldb, k0 + (long)c * KB, k1, smem + c * BUF + A_BYTES, tid);
   }
-  for (int c = 0; c < n_chunks; ++c) {
-    const long k = k0 + (long)c * KB;
-    // chunk c was issued NBUF-1 chunks ago: everything but the (NBUF-2) younger chunks must have landed
-    if (PART_A != 0 && wave >= PART_A) wait_vmcnt<(NBUF - 2) * (IT_A - 1 + IT_B)>();
-    else wait_vmcnt<(NBUF - 2) * (IT_A + IT_B)>();
-    __builtin_amdgcn_s_barrier();               // all waves' pieces of chunk c landed; chunk c-1 fully consumed
-    {
-      const int slot = (c + NBUF - 1) % NBUF;   // = slot of chunk c-1
-      char* bn = smem + slot * BUF;
-      sa.stage(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, bn, tid);
-      sb.stage(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, bn + A_BYTES, tid);
-    }
-    char* bc = smem + (c % NBUF) * BUF;
-    const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;
-    const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
-    if (BF16) {
-      static_assert(KB == 16, "one 32x32x16 k-step per chunk");
-      dw_bf16x8 af[MT], bf[NT];
+  if (BF16) {
+    // One 32x32x16 k-step per 16-point chunk.  The fragment gathers of chunk c are ISSUED in iteration c and consumed
+    // (packed, summed, multiplied) in iteration c+1: their LDS latency hides behind the 16 MFMAs of chunk c-1 -- consumed in
+    // place hipcc waits on them 19 times per chunk (measured: 2.5 k cycles per chunk against 512 of MFMA work).
+    static_assert(KB == 16, "one 32x32x16 k-step per chunk");
+    unsigned ra[MT][8], rb[NT][8];                 // raw gathered values: bf16 bits (zero-extended) or fp32 bits
+    for (int c = 0; c <= n_chunks; ++c) {
+      char* bc = smem + (c % NBUF) * BUF;
+      if (c < n_chunks) {
+        const long k = k0 + (long)c * KB;
+        if (PART_A != 0 && wave >= PART_A) wait_vmcnt<(NBUF - 2) * (IT_A - 1 + IT_B)>();
+        else wait_vmcnt<(NBUF - 2) * (IT_A + IT_B)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own gathers of chunk c-1 done before its slot is restaged
+        __builtin_amdgcn_s_barrier();             // all waves' pieces of chunk c landed; chunk c-1 fully gathered
+        const int slot = (c + NBUF - 1) % NBUF;   // = slot of chunk c-1
+        char* bn = smem + slot * BUF;
+        sa.stage(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, bn, tid);
+        sb.stage(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, bn + A_BYTES, tid);
+      }
+      if (c > 0) {                                 // chunk c-1: pack, column sums, 16 MFMAs
+        dw_bf16x8 af[MT], bf[NT];
 #pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        dw_u32x4 q;
-        if (EA == 2) {                                                     // bf16 tile: two points per dword, no conversion
-          const unsigned short* l16 = reinterpret_cast<const unsigned short*>(bc) + 8 * h * WA + m0 + i + 32 * a;
+        for (int a = 0; a < MT; ++a) {
+          dw_u32x4 q;
           float sum = 0.0f;
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
-            const unsigned lo = l16[(2 * w) * WA], hi = l16[(2 * w + 1) * WA];
-            q[w] = lo | (hi << 16);
-            sum += __builtin_bit_cast(float, lo << 16) + __builtin_bit_cast(float, hi << 16);
+            if (EA == 2) {
+              q[w] = ra[a][2 * w] | (ra[a][2 * w + 1] << 16);
+              sum += __builtin_bit_cast(float, ra[a][2 * w] << 16) + __builtin_bit_cast(float, ra[a][2 * w + 1] << 16);
+            } else {
+              const float v0 = __builtin_bit_cast(float, ra[a][2 * w]), v1 = __builtin_bit_cast(float, ra[a][2 * w + 1]);
+              q[w] = dw_pack2(v0, v1);
+              sum += v0 + v1;
+            }
           }
           bsum[a] += sum;
-        } else {
-          float v[8];
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) v[jj] = la[(7 * h + jj) * WA + 32 * a];    // la already carries h * WA: row 8h + jj
-#pragma unroll
-          for (int w = 0; w < 4; ++w) q[w] = dw_pack2(v[2 * w], v[2 * w + 1]);
-          bsum[a] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          af[a] = __builtin_bit_cast(dw_bf16x8, q);
         }
-        af[a] = __builtin_bit_cast(dw_bf16x8, q);
-      }
 #pragma unroll
-      for (int b = 0; b < NT; ++b) {
-        dw_u32x4 q;
-        if (EB == 2) {
-          const unsigned short* l16 = reinterpret_cast<const unsigned short*>(bc + A_BYTES) + 8 * h * WB + n0 + i + 32 * b;
+        for (int b = 0; b < NT; ++b) {
+          dw_u32x4 q;
 #pragma unroll
-          for (int w = 0; w < 4; ++w) q[w] = (unsigned)l16[(2 * w) * WB] | ((unsigned)l16[(2 * w + 1) * WB] << 16);
-        } else {
-#pragma unroll
-          for (int w = 0; w < 4; ++w)
-            q[w] = dw_pack2(lb[(7 * h + 2 * w) * WB + 32 * b], lb[(7 * h + 2 * w + 1) * WB + 32 * b]);
+          for (int w = 0; w < 4; ++w) {
+            if (EB == 2) q[w] = rb[b][2 * w] | (rb[b][2 * w + 1] << 16);
+            else q[w] = dw_pack2(__builtin_bit_cast(float, rb[b][2 * w]), __builtin_bit_cast(float, rb[b][2 * w + 1]));
+          }
+          bf[b] = __builtin_bit_cast(dw_bf16x8, q);
         }
-        bf[b] = __builtin_bit_cast(dw_bf16x8, q);
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
+      if (c < n_chunks) {                          // gathers of chunk c: lane (i, h) takes rows 8h .. 8h+7 of its feature
 #pragma unroll
-      for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
-    } else {
+          for (int jj = 0; jj < 8; ++jj) {
+            if (EA == 2) ra[a][jj] = reinterpret_cast<const unsigned short*>(bc)[(8 * h + jj) * WA + m0 + i + 32 * a];
+            else ra[a][jj] = reinterpret_cast<const unsigned*>(bc)[(8 * h + jj) * WA + m0 + i + 32 * a];
+          }
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            if (EB == 2) rb[b][jj] = reinterpret_cast<const unsigned short*>(bc + A_BYTES)[(8 * h + jj) * WB + n0 + i + 32 * b];
+            else rb[b][jj] = reinterpret_cast<const unsigned*>(bc + A_BYTES)[(8 * h + jj) * WB + n0 + i + 32 * b];
+          }
+      }
+    }
+  } else {
+    for (int c = 0; c < n_chunks; ++c) {
+      const long k = k0 + (long)c * KB;
+      // chunk c was issued NBUF-1 chunks ago: everything but the (NBUF-2) younger chunks must have landed
+      if (PART_A != 0 && wave >= PART_A) wait_vmcnt<(NBUF - 2) * (IT_A - 1 + IT_B)>();
+      else wait_vmcnt<(NBUF - 2) * (IT_A + IT_B)>();
+      __builtin_amdgcn_s_barrier();               // all waves' pieces of chunk c landed; chunk c-1 fully consumed
+      {
+        const int slot = (c + NBUF - 1) % NBUF;   // = slot of chunk c-1
+        char* bn = smem + slot * BUF;
+        sa.stage(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, bn, tid);
+        sb.stage(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, bn + A_BYTES, tid);
+      }
+      char* bc = smem + (c % NBUF) * BUF;
+      const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;
+      const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
 #pragma unroll
       for (int s = 0; s < KB / 2; ++s) {
         float av[MT], bv[NT];
