@@ -30,9 +30,7 @@ extern "C" {
 #define SN_E_UNSUPPORTED (-4)
 #define SN_E_BADSHAPE (-5)
 
-/* sn_mlp_forward flags: reserved, pass 0.  (Bit 0 selected a register-staged weight path in early builds; it is accepted
- * and ignored -- weights always stream by global_load_lds.) */
-#define SN_FLAG_NO_LDS_DMA 1
+/* sn_mlp_forward / sn_mlp_forward_embedded `flags`: reserved, pass 0. */
 
 int sn_abi_version(void);
 const char* sn_error_string(int code);
@@ -90,6 +88,13 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
  * order (nerf.py:36-41).                                                                                     */
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                          float* out, float* acts, float* emb, long slot_rows, void* stream);
+
+/* ---- the same for NeRF.forward(x) under autograd (models/nerf.py:105-148 is an ordinary differentiable nn.Module): x
+ * (n_rows, ld >= 90) pre-embedded rows as for sn_mlp_forward_embedded; acts / slot_rows as above.  The `emb` matrix of the
+ * weight-gradient contractions is a column re-layout of x the caller builds itself ([0,63) = x[:, 0:63], [64,91) =
+ * x[:, 63:90], zeros elsewhere).  dtype: SN_DTYPE_F32 or SN_DTYPE_BF16_STATE.                                   */
+int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, long n_rows, int ld, float* out,
+                                  float* acts, long slot_rows, void* stream);
 
 /* ---- backward of models/nerf.py:122-148 w.r.t. layer outputs (what loss.backward() at sinnerf.py:551 runs) ----
  * blob_bwd: transposed-weight blob (sn_build_pack_table_bwd).  out_raw / g_raw (n_points,4): forward output and its

@@ -55,8 +55,46 @@ def widened_sigmoid(x):
     return (F(0.5) * (F(1) + scale * np.tanh((F(0.5) * x).astype(F)).astype(F))).astype(F)
 
 
-def _linear(x, w, b):
+def bf16_round(a):
+    """Round fp32 -> bf16 -> fp32 (round to nearest even), the conversion ``v_cvt_pk_bf16_f32`` performs on the MFMA
+    operands of the bf16-operand kernels.  Used to build the *bf16-emulated* oracle the reduced-precision path is compared
+    with (same operand roundings, fp32 accumulation in another order)."""
+    a = np.ascontiguousarray(a, F)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = r.astype(np.uint32).view(F)
+    return np.where(np.isfinite(a), out, a).astype(F)
+
+
+_OPERAND_ROUND = None          # None = fp32 reference arithmetic; bf16_round = emulate the bf16-operand MFMA path
+
+
+class bf16_operands:
+    """Context manager: every ``_linear`` inside rounds BOTH operands (activations and weights) to bf16, accumulates in
+    fp32 and adds the fp32 bias -- the arithmetic of ``v_mfma_f32_32x32x16_bf16`` in csrc/sn_mlp_fwd_bf16.hip.
+    ``heads_fp32=True`` keeps the two narrow heads (sigma, rgb) in fp32 as the kernels do (VALU work on fp32 values)."""
+
+    def __init__(self, heads_fp32=True):
+        self.heads_fp32 = heads_fp32
+
+    def __enter__(self):
+        global _OPERAND_ROUND, _HEADS_FP32
+        self._saved = (_OPERAND_ROUND, _HEADS_FP32)
+        _OPERAND_ROUND, _HEADS_FP32 = bf16_round, self.heads_fp32
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND_ROUND, _HEADS_FP32
+        _OPERAND_ROUND, _HEADS_FP32 = self._saved
+
+
+_HEADS_FP32 = True
+
+
+def _linear(x, w, b, head=False):
     """nn.Linear: x @ W^T + b (``nerf.py:68-76``)."""
+    if _OPERAND_ROUND is not None and not (head and _HEADS_FP32):
+        return (_OPERAND_ROUND(x) @ _OPERAND_ROUND(w).T + b).astype(F)
     return (x @ w.T + b).astype(F)
 
 
@@ -82,14 +120,14 @@ def nerf_forward(params, x, sigma_only=False, D=8, W=256, in_xyz=63, in_dir=27, 
         hidden.append(h)
         if cache is not None:
             cache[f"h{i+1}"] = h
-    sigma = _linear(h, params["sigma.weight"], params["sigma.bias"])        # :136
+    sigma = _linear(h, params["sigma.weight"], params["sigma.bias"], head=True)        # :136
     if sigma_only:
         return sigma
     final = _linear(h, params["xyz_encoding_final.weight"], params["xyz_encoding_final.bias"])  # :140
     d_in = np.concatenate([final, input_dir], -1)                            # :142
     y2 = _linear(d_in, params["dir_encoding.0.weight"], params["dir_encoding.0.bias"])
     d = shifted_softplus(y2)                                                 # :143
-    y3 = _linear(d, params["rgb.0.weight"], params["rgb.0.bias"])
+    y3 = _linear(d, params["rgb.0.weight"], params["rgb.0.bias"], head=True)
     rgb = widened_sigmoid(y3)                                                # :144
     out = np.concatenate([rgb, sigma], -1)                                   # :146
     if cache is not None:
@@ -315,12 +353,19 @@ def render_loss(results, rgbs, depths=None, w_rgb=1.0, w_depth=1.0, mask=None, u
     return st, gr
 
 
-def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None):
+def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None, operand_round=None):
     """Parameter gradients of ``nerf_forward`` (non sigma_only) for upstream ``g_out`` (B,4) -- what torch autograd
     derives from ``models/nerf.py:122-148`` + ``models/activations.py`` (Linear: gW = g^T x, gb = sum g, gx = g W;
     ReLU(inplace): g*[out>0]; ShiftedSoftplus': sigmoid(x-1); WidenedSigmoid': .2505*(1-tanh(.5x)^2)).
-    float64 accumulation (reference = fp32 autograd; compare with a norm-wise tolerance)."""
+    float64 accumulation (reference = fp32 autograd; compare with a norm-wise tolerance).
+
+    ``operand_round`` (e.g. ``bf16_round``): emulate the mixed-precision backward of csrc/sn_mlp_bwd_bf16.hip + sn_dw.hip
+    (SN_DTYPE_BF16_STATE) -- every contraction sees BOTH operands rounded (the pre-activation gradients g_y are rounded once,
+    when they are packed for the next transposed layer / stored; activations and weights as in the forward), accumulation
+    stays wide; the two narrow transposed heads (rgb.0^T, sigma^T) are fp32 VALU work on unrounded values; the softplus
+    derivative is taken from the STORED activation, sigmoid(y2-1) = 1 - exp(-d), as the kernel does."""
     f8 = np.float64
+    rd = (lambda a: operand_round(np.asarray(a, F)).astype(f8)) if operand_round is not None else (lambda a: np.asarray(a, f8))
     g = {}
     x = cache["x"].astype(f8)
     input_xyz, input_dir = x[:, :in_xyz], x[:, in_xyz:]
@@ -328,20 +373,23 @@ def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None)
     t = np.tanh(0.5 * cache["y3"].astype(f8))
     g_y3 = g_rgb * (0.5 * 1.002 * 0.5) * (1.0 - t * t)
     d = cache["d"].astype(f8)
-    g["rgb.0.weight"], g["rgb.0.bias"] = g_y3.T @ d, g_y3.sum(0)
+    g["rgb.0.weight"], g["rgb.0.bias"] = rd(g_y3).T @ rd(d), rd(g_y3).sum(0)
     if gy_out is not None:
         gy_out["rgb"], gy_out["sigma"] = g_y3, g_sigma
     g_d = g_y3 @ params["rgb.0.weight"].astype(f8)
-    g_y2 = g_d / (1.0 + np.exp(-(cache["y2"].astype(f8) - 1.0)))
+    if operand_round is not None:
+        g_y2 = g_d * (1.0 - np.exp(-d))
+    else:
+        g_y2 = g_d / (1.0 + np.exp(-(cache["y2"].astype(f8) - 1.0)))
     d_in = np.concatenate([cache["final"].astype(f8), input_dir], -1)
-    g["dir_encoding.0.weight"], g["dir_encoding.0.bias"] = g_y2.T @ d_in, g_y2.sum(0)
-    g_final = (g_y2 @ params["dir_encoding.0.weight"].astype(f8))[:, :256]
+    g["dir_encoding.0.weight"], g["dir_encoding.0.bias"] = rd(g_y2).T @ rd(d_in), rd(g_y2).sum(0)
+    g_final = (rd(g_y2) @ rd(params["dir_encoding.0.weight"]))[:, :256]
     if gy_out is not None:
         gy_out["dir"], gy_out["final"] = g_y2, g_final
     h8 = cache[f"h{D}"].astype(f8)
-    g["xyz_encoding_final.weight"], g["xyz_encoding_final.bias"] = g_final.T @ h8, g_final.sum(0)
-    g["sigma.weight"], g["sigma.bias"] = g_sigma.T @ h8, g_sigma.sum(0)
-    g_h = g_final @ params["xyz_encoding_final.weight"].astype(f8) + g_sigma @ params["sigma.weight"].astype(f8)
+    g["xyz_encoding_final.weight"], g["xyz_encoding_final.bias"] = rd(g_final).T @ rd(h8), rd(g_final).sum(0)
+    g["sigma.weight"], g["sigma.bias"] = rd(g_sigma).T @ rd(h8), rd(g_sigma).sum(0)
+    g_h = rd(g_final) @ rd(params["xyz_encoding_final.weight"]) + g_sigma @ params["sigma.weight"].astype(f8)
     for i in reversed(range(D)):
         h_out = cache[f"h{i+1}"]
         g_y = g_h * (h_out > 0)
@@ -353,9 +401,9 @@ def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None)
             xin = cache[f"h{i}"].astype(f8)
             if i in skips:
                 xin = np.concatenate([input_xyz, xin], -1)
-        g[f"xyz_encoding_{i+1}.0.weight"], g[f"xyz_encoding_{i+1}.0.bias"] = g_y.T @ xin, g_y.sum(0)
+        g[f"xyz_encoding_{i+1}.0.weight"], g[f"xyz_encoding_{i+1}.0.bias"] = rd(g_y).T @ rd(xin), rd(g_y).sum(0)
         if i > 0:
-            g_x = g_y @ params[f"xyz_encoding_{i+1}.0.weight"].astype(f8)
+            g_x = rd(g_y) @ rd(params[f"xyz_encoding_{i+1}.0.weight"])
             g_h = g_x[:, in_xyz:] if i in skips else g_x
     return g
 
@@ -492,3 +540,50 @@ def lego_rays(H, W, seed=0, camera_angle_x=0.6911112, radius=4.0, near=2.0, far=
     if sel is not None:
         rays = rays[sel]
     return np.ascontiguousarray(rays)
+
+
+def llff_like_rays(n, seed, W=504, H=378, near=1.2, far=8.0):
+    """n random pixels of a forward-facing llff/room-shaped frame (504x378, f ~ 0.82 W, near/far ~ 1.2/8,
+    ``white_back=False``; the reference's values are data-dependent, ``datasets/llff.py:237-238``)."""
+    r = np.random.RandomState(seed)
+    f = W * 0.82
+    idx = r.choice(W * H, n, replace=False)
+    i, j = (idx % W).astype(np.float64), (idx // W).astype(np.float64)
+    d = np.stack([(i - W / 2) / f, -(j - H / 2) / f, -np.ones_like(i)], -1)
+    o = np.broadcast_to(np.array([0.1, -0.05, 0.2]), d.shape)
+    return np.concatenate([o, d, np.full((n, 1), near), np.full((n, 1), far)], 1).astype(F)
+
+
+def _look_at_c2w(c):
+    fwd = -c / np.linalg.norm(c)
+    right = np.cross(fwd, np.array([0, 0, 1.0])); right /= np.linalg.norm(right)
+    return np.stack([right, np.cross(right, fwd), -fwd, c], 1)                # (3,4)
+
+
+def patch_rays(H, W, focal, c2w, near, far, x0, y0, pw, ph, sx, sy):
+    """Strided pixel window of a pin-hole frame, row-major over (iy, ix): the patch sampling of the ray-patch datasets
+    (``blender_ray_patch_1image_rot3d.py:487-498``, ``llff_ray_patch...:647-668``, ``dtu_proj.py:629-651``) applied to
+    ``get_rays``.  Returns (pw*ph, 8)."""
+    full = get_rays(H, W, focal, c2w, near, far).reshape(H, W, 8)
+    return np.ascontiguousarray(full[y0:y0 + ph * sy:sy, x0:x0 + pw * sx:sx].reshape(-1, 8))
+
+
+def llff_patch_rays(seed=0, pw=84, ph=63, sx=4, sy=4):
+    """BASELINE configs[2]: llff/room 504x378, patch 63x84 (rows x columns) with sW = sH = 4 -> N = 5292 rays, near/far 1.2/8, forward-facing pose."""
+    W, H = 504, 378
+    r = np.random.RandomState(2000 + seed)
+    c2w = np.concatenate([np.eye(3), r.uniform(-0.2, 0.2, (3, 1))], 1)
+    return patch_rays(H, W, W * 0.82, c2w, 1.2, 8.0, int(r.randint(0, W - (pw - 1) * sx)), int(r.randint(0, H - (ph - 1) * sy)),
+                      pw, ph, sx, sy)
+
+
+def dtu_patch_rays(seed=0, pw=70, ph=56, sx=8, sy=8):
+    """BASELINE configs[3]: dtu scan 640x512, patch 56x70 (rows x columns) with sW = sH = 8 -> N = 3920 rays; near/far 2.125/4.525 (DTU
+    depth_min 425 mm, 192 x 2.5 mm intervals, scaled by 1/200: ``dtu_proj.py:290,396-398``), camera ~3.3 units from the
+    object looking at it, focal ~ 1.8 W (DTU intrinsics at 640x512), ``white_back=True``."""
+    W, H = 640, 512
+    r = np.random.RandomState(3000 + seed)
+    th, ph_ = r.uniform(0, 2 * np.pi), r.uniform(0.25, 0.4) * np.pi
+    c = 3.3 * np.array([np.cos(th) * np.sin(ph_), np.sin(th) * np.sin(ph_), np.cos(ph_)])
+    return patch_rays(H, W, 1.8 * W, _look_at_c2w(c), 2.125, 4.525, int(r.randint(0, W - (pw - 1) * sx)),
+                      int(r.randint(0, H - (ph - 1) * sy)), pw, ph, sx, sy)

@@ -13,7 +13,6 @@ LIB_PATH = os.environ.get("SINNERF_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 SN_DTYPE_F32 = 0
 SN_DTYPE_BF16 = 1
 SN_DTYPE_BF16_STATE = 2
-SN_FLAG_NO_LDS_DMA = 1
 N_RAW_TENSORS = 24
 
 c_fp = ctypes.c_void_p      # device float*
@@ -41,6 +40,7 @@ SIGNATURES = {
     "sn_sample_coarse": (_int, [c_fp, _long, _int, _int, _float, c_fp, c_fp, c_vp]),
     "sn_mlp_forward": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
     "sn_mlp_forward_train": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, c_fp, c_fp, c_fp, _long, c_vp]),
+    "sn_mlp_forward_train_embedded": (_int, [c_vp, _int, c_fp, _long, _int, c_fp, c_fp, _long, c_vp]),
     "sn_mlp_backward_chain": (_int, [c_vp, _int, c_fp, c_fp, c_fp, _long, _long, c_fp, c_fp, c_vp]),
     "sn_dw_gemm": (_int, [c_vp, _int, c_vp]),
     "sn_generate_rays": (_int, [c_fp, _int, _int, _float, _float, _float, _int, _int, _int, _int, _int, _int, c_fp, c_vp]),

@@ -119,9 +119,13 @@ def _weight_grads(model, acts, emb, G, g_o, needs):
 
 
 class _MLPFn(torch.autograd.Function):
+    """rays mode: (rays (N,8), z_vals (N,S)) -> raw (N,S,4).  Embedded mode (``z_vals is None``): ``rays`` is the
+    pre-embedded (B, 90) matrix of ``NeRF.forward`` (nerf.py:105-148) -> (B, 4)."""
+
     @staticmethod
     def forward(ctx, model, rays, z_vals, *params):
-        n, s = z_vals.shape
+        embedded = z_vals is None
+        n, s = (rays.shape[0], 1) if embedded else z_vals.shape
         P = n * s
         dev = rays.device
         code = dtype_code(model.compute_dtype)
@@ -130,14 +134,27 @@ class _MLPFn(torch.autograd.Function):
         bf16 = code == _lib.SN_DTYPE_BF16
         if bf16:
             code = _lib.SN_DTYPE_BF16_STATE
-        out = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
+        out = torch.empty((n, 4) if embedded else (n, s, 4), dtype=torch.float32, device=dev)
         tile = 256 if bf16 else 128
         rows = -(-P // tile) * tile                    # the training forward stores whole point tiles (pad rows: finite
         acts = torch.empty((10, rows, 256), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)   # copies of the last point, zero gradient)
-        emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
-                                                 _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
-                   "sn_mlp_forward_train")
+        if embedded:
+            # emb = the column layout the weight-gradient contractions read: [0,63) xyz, [64,91) dir (nerf.py:123-125)
+            emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
+            emb[:n, :63] = rays[:, :63]
+            emb[:n, 64:91] = rays[:, 63:90]
+            _lib.check(_lib.lib.sn_mlp_forward_train_embedded(_lib.ptr(model.packed()), code, _lib.ptr(rays), n, rays.shape[1],
+                                                              _lib.ptr(out), _lib.ptr(acts), rows, _lib.stream_ptr()),
+                       "sn_mlp_forward_train_embedded")
+        else:
+            # NOT zero-filled (that was a 268 MB memset per 4096-ray fine pass): the kernel writes columns [0,63) and [64,91)
+            # of EVERY row of the whole point tiles; the pad columns 63, 91..127 only ever feed columns of the 64-wide dW
+            # blocks that _weight_grads slices away ([:, :63], [:, :27]) -- a contraction's output column depends on its own
+            # X column only
+            emb = torch.empty((rows, 128), dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
+                                                     _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
+                       "sn_mlp_forward_train")
         ctx.model = model
         ctx.n_points = P
         ctx.save_for_backward(acts, emb, out)
@@ -149,7 +166,7 @@ class _MLPFn(torch.autograd.Function):
         model = ctx.model
         P, rows = ctx.n_points, acts.shape[1]
         dev = acts.device
-        g_out = g_out.contiguous().float()
+        g_out = g_out.contiguous().float()               # (N,S,4) or (B,4): P x 4 either way
         G = torch.empty((10, rows, 256), dtype=acts.dtype, device=dev)
         if rows > P:
             G[:, P:].zero_()
@@ -264,5 +281,18 @@ def render_rays_autograd(models, rays, N_samples, use_disp, perturb, noise_std, 
 
 
 def mlp_embedded_autograd(model, x, sigma_only):
-    raise NotImplementedError("sinnerf_amd: NeRF.forward on a pre-embedded matrix is inference-only in this revision; "
-                              "gradients flow through sinnerf_amd.render_rays")
+    """``NeRF.forward(x, sigma_only)`` under autograd (reference ``models/nerf.py:105-148`` is an ordinary differentiable
+    module): parameter gradients through the same kernels as ``render_rays`` (training forward on the pre-embedded rows,
+    backward chain, weight-gradient contractions).  The gradient w.r.t. ``x`` itself is not implemented (both reference call
+    sites feed embeddings of data: rays / sample depths carry no gradient, rendering.py:312) -- asking for it raises.
+    ``sigma_only`` (nerf.py:136-138) runs the full network on a zero direction embedding and returns the sigma column;
+    the head / dir-branch parameters then receive exact zeros where torch would leave ``.grad`` at None."""
+    if x.requires_grad:
+        raise NotImplementedError("sinnerf_amd.NeRF.forward: the gradient with respect to the embedded input x is not "
+                                  "implemented (parameter gradients are); detach x, or differentiate through render_rays")
+    x = x.contiguous().float()
+    if sigma_only:
+        x = torch.cat([x, torch.zeros((x.shape[0], 27), dtype=torch.float32, device=x.device)], 1)
+    with torch.cuda.device(x.device):
+        out = _MLPFn.apply(model, x, None, *model.raw_tensors())
+    return out[:, 3:4] if sigma_only else out

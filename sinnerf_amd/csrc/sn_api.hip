@@ -163,6 +163,20 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
                                    (hipStream_t)stream);
 }
 
+int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, long n_rows, int ld, float* out,
+                                  float* acts, long slot_rows, void* stream) {
+  if (!blob || !x || !out || !acts || n_rows < 0) return SN_E_BADARG;
+  float* emb = acts;                             // not written for pre-embedded rows (the kernels only need it non-null)
+  if (ld < 90) return SN_E_BADSHAPE;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;   // mixed precision keeps bf16 state
+  const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;
+  if (slot_rows < (n_rows + tile - 1) / tile * tile) return SN_E_BADSHAPE;
+  if (dtype != SN_DTYPE_F32)
+    return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows,
+                                      dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
+  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, 0, 1, 1, out, acts, emb, slot_rows, (hipStream_t)stream);
+}
+
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream) {
   if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;

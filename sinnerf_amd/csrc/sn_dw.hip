@@ -15,6 +15,7 @@
 // three chunks in flight, COUNTED s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the queue).
 // Partial results go to a per-task slab; the K-split partials are summed afterwards (deterministic, no atomics).
 #include "sn_device.h"
+#include "sn_launch.h"
 
 namespace snd {
 
@@ -291,9 +292,7 @@ extern "C" int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream) 
   using namespace snd;
   if (n_tasks <= 0) return 0;
   static_assert(sizeof(Task) == 64, "Task must be 64 bytes (host packs it as 8 x int64)");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)DW_LDS_BYTES);
-  if (e != hipSuccess) return (int)e;
+  SN_ENSURE_DYN_LDS(dw_kernel, DW_LDS_BYTES);
   hipLaunchKernelGGL(dw_kernel, dim3((unsigned)n_tasks), dim3(256), DW_LDS_BYTES, stream,
                      reinterpret_cast<const Task*>(tasks));
   return (int)hipGetLastError();

@@ -202,9 +202,7 @@ extern "C" int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* 
   const long tiles = (n_points + 127) / 128;
   if (tiles > 0x7fffffffL) return -2;
   auto kfn = mlp_bwd_chain_f32_kernel;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)MLP_BWD_LDS_BYTES);
-  if (e != hipSuccess) return (int)e;
+  SN_ENSURE_DYN_LDS(kfn, MLP_BWD_LDS_BYTES);
   hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(256), MLP_BWD_LDS_BYTES, stream,
                      reinterpret_cast<const char*>(bblob), acts, out_raw, g_raw, n_points, slot_rows, G, g_out);
   return (int)hipGetLastError();

@@ -373,14 +373,11 @@ extern "C" int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float*
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 255) / 256;
   if (slot_rows < tiles * 256) return -1;
-  int dev = 0, n_cu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int n_cu = snh::cu_count();
 #define SN_LAUNCH(S16_)                                                                                            \
   do {                                                                                                             \
     auto kfn = mlp_bwd_chain_bf16_kernel<S16_>;                                                                    \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)BWD16_LDS_BYTES);                                                      \
-    if (e != hipSuccess) return (int)e;                                                                            \
+    SN_ENSURE_DYN_LDS(kfn, BWD16_LDS_BYTES);                                                                       \
     hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles < n_cu ? tiles : n_cu)), dim3(256), BWD16_LDS_BYTES, stream,     \
                        reinterpret_cast<const char*>(bblob), acts, out_raw, g_raw, n_points, slot_rows, G, g_out); \
   } while (0)

@@ -2,6 +2,7 @@
 #pragma once
 #include "sn_device.h"
 #include "sn_layout.h"
+#include "sn_launch.h"
 
 namespace snk {
 

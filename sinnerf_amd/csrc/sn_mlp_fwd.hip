@@ -100,7 +100,8 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       xe[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
     }
   }
-  if (STORE) {                                   // rows are allocated for whole 128-point tiles: no predicate
+  if (STORE && INPUT_MODE == 0) {                // rows are allocated for whole 128-point tiles: no predicate.  (Pre-embedded
+                                                 // rows, INPUT_MODE 1: the caller builds emb itself, it is a column re-layout of x)
     float* er = emb + p_raw * 128;               // caller zero-fills emb: pad columns 63, 91..127 stay 0
     int hh = h;
     asm volatile("" : "+v"(hh));                 // column selects stay inside the tile loop (hoisted they cost 32 VGPRs)
@@ -246,7 +247,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       de[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
     }
   }
-  if (STORE) {
+  if (STORE && INPUT_MODE == 0) {
     float* er = emb + p_raw * 128;
     int hh = h;
     asm volatile("" : "+v"(hh));
@@ -318,22 +319,20 @@ extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, con
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
   const bool store = acts != nullptr;
-  if (store && (sigma_only || input_mode != 0 || emb == nullptr || slot_rows < tiles * 128)) return -1;
+  if (store && (sigma_only || emb == nullptr || slot_rows < tiles * 128)) return -1;
   // persistent launch: one workgroup per CU (the 135 KB LDS ring admits exactly one), each walks tiles b, b+grid, ...
-  int dev = 0, n_cu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int n_cu = snh::cu_count();
   dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
   const size_t lds = MLP_F32_LDS_BYTES_V2 + (store ? XPOSE_LDS_BYTES : 0);
   const char* b = reinterpret_cast<const char*>(blob);
 #define SN_LAUNCH(SO, IM, ST)                                                                                    \
   do {                                                                                                           \
     auto kfn = mlp_fwd_f32_kernel<SO, IM, ST>;                                                                   \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return (int)e;                                                                          \
+    SN_ENSURE_DYN_LDS(kfn, lds);                                                                                 \
     hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows); \
   } while (0)
   if (store) {
-    SN_LAUNCH(false, 0, true);
+    if (input_mode == 0) SN_LAUNCH(false, 0, true); else SN_LAUNCH(false, 1, true);
   } else if (input_mode == 0) {
     if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false);
   } else {

@@ -133,7 +133,8 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           f[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
         }
       }
-      if (STORE) {                               // rows are allocated for whole 256-point tiles: no predicate
+      if (STORE && INPUT_MODE == 0) {            // rows are allocated for whole 256-point tiles: no predicate.  (Pre-embedded
+                                                 // rows, INPUT_MODE 1: the caller builds emb itself, it is a column re-layout of x)
         float* er = emb + p_raw[pt] * 128;       // caller zero-fills emb: pad columns 63, 91..127 stay 0
         const int hs = ht;
 #pragma unroll
@@ -347,7 +348,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           f[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
         }
       }
-      if (STORE) {
+      if (STORE && INPUT_MODE == 0) {
         float* er = emb + p_raw[pt] * 128;
         const int hs = ht;
 #pragma unroll
@@ -438,20 +439,21 @@ extern "C" int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, co
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 255) / 256;
   const bool store = acts != nullptr;
-  if (store && (sigma_only || input_mode != 0 || emb == nullptr || slot_rows < tiles * 256)) return -1;
-  int dev = 0, n_cu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (store && (sigma_only || emb == nullptr || slot_rows < tiles * 256)) return -1;
+  const int n_cu = snh::cu_count();
   dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
   const size_t lds = MLP_BF16_LDS_BYTES + (store ? BF16_XPOSE_LDS_BYTES : 0);
   const char* b = reinterpret_cast<const char*>(blob);
 #define SN_LAUNCH(SO, IM, ST)                                                                                    \
   do {                                                                                                           \
     auto kfn = mlp_fwd_bf16_kernel<SO, IM, ST>;                                                                  \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return (int)e;                                                                          \
+    SN_ENSURE_DYN_LDS(kfn, lds);                                                                                 \
     hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows); \
   } while (0)
-  if (store) { if (state_bf16) SN_LAUNCH(false, 0, 2); else SN_LAUNCH(false, 0, 1); }
+  if (store) {
+    if (input_mode == 0) { if (state_bf16) SN_LAUNCH(false, 0, 2); else SN_LAUNCH(false, 0, 1); }
+    else { if (state_bf16) SN_LAUNCH(false, 1, 2); else return -4; }    // embedded rows + fp32 state: out of registers, not built
+  }
   else if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, 0); else SN_LAUNCH(false, 0, 0); }
   else { if (sigma_only) SN_LAUNCH(true, 1, 0); else SN_LAUNCH(false, 1, 0); }
 #undef SN_LAUNCH

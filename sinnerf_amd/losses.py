@@ -13,15 +13,10 @@ import torch
 
 from . import _lib
 
-_WS = {}
-
-
 def _workspace(device):
-    ws = _WS.get(device)
-    if ws is None:
-        ws = torch.empty(_lib.lib.sn_render_loss_workspace_bytes(), dtype=torch.uint8, device=device)
-        _WS[device] = ws
-    return ws
+    # ~10 KB of per-block partial sums, allocated per call from torch's caching allocator (stream-ordered: two streams
+    # computing losses concurrently never share it)
+    return torch.empty(_lib.lib.sn_render_loss_workspace_bytes(), dtype=torch.uint8, device=device)
 
 
 def _prep(t, n, width, name):
@@ -51,11 +46,21 @@ class _RenderLossFn(torch.autograd.Function):
         grads = [torch.empty_like(t) if (t is not None and orig.requires_grad) else None
                  for t, orig in zip(p, preds)]
         out = torch.empty(8, dtype=torch.float32, device=dev)
-        ws = _workspace(dev)
-        _lib.check(_lib.lib.sn_render_loss(_lib.ptr(p[0]), _lib.ptr(p[1]), _lib.ptr(p[2]), _lib.ptr(p[3]), _lib.ptr(gt_rgb),
-                                           _lib.ptr(gt_d), _lib.ptr(m), int(mask_mode), n, float(w_rgb), float(w_depth),
-                                           _lib.ptr(grads[0]), _lib.ptr(grads[1]), _lib.ptr(grads[2]), _lib.ptr(grads[3]),
-                                           _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()), "sn_render_loss")
+        if n == 0:                                  # empty batch: the reference's 'mean' reductions return NaN (0/0), no raise
+            out.fill_(float("nan"))
+            out[7] = 0.0
+            ctx.shapes = [None if t is None else t.shape for t in preds]
+            ctx.save_for_backward(*[g for g in grads if g is not None])
+            ctx.have = [g is not None for g in grads]
+            ctx.mark_non_differentiable(out)
+            return out[4].clone(), out
+        with torch.cuda.device(dev):
+            ws = _workspace(dev)
+            _lib.check(_lib.lib.sn_render_loss(_lib.ptr(p[0]), _lib.ptr(p[1]), _lib.ptr(p[2]), _lib.ptr(p[3]),
+                                               _lib.ptr(gt_rgb),
+                                               _lib.ptr(gt_d), _lib.ptr(m), int(mask_mode), n, float(w_rgb), float(w_depth),
+                                               _lib.ptr(grads[0]), _lib.ptr(grads[1]), _lib.ptr(grads[2]), _lib.ptr(grads[3]),
+                                               _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()), "sn_render_loss")
         ctx.shapes = [None if t is None else t.shape for t in preds]
         ctx.save_for_backward(*[g for g in grads if g is not None])
         ctx.have = [g is not None for g in grads]

@@ -103,6 +103,7 @@ class NeRF(nn.Module):
         self.sigma = nn.Linear(W, 1)
         self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Identity())
         self._packed = {}          # dtype_code -> (blob tensor, version signature)
+        self._pack_generation = 0  # bumped by invalidate_packed(): writes through .data do not bump Parameter._version
 
     # ---- packed weights -------------------------------------------------------------------------------
     def raw_tensors(self):
@@ -117,7 +118,15 @@ class NeRF(nn.Module):
         return out
 
     def _signature(self, raws):
-        return tuple((t.data_ptr(), t._version) for t in raws)
+        return (self._pack_generation,) + tuple((t.data_ptr(), t._version) for t in raws)
+
+    def invalidate_packed(self):
+        """Mark the MFMA-packed weight blobs stale.  ``packed()`` notices in-place updates of the parameters through
+        ``Parameter._version`` (optimizer steps, ``load_state_dict``, ``p.mul_()`` under ``no_grad``) and replaced storage
+        through ``data_ptr``; a write THROUGH ``p.data`` (``dist.broadcast(p.data)``, ``p.data.copy_()``, EMA / clipping code,
+        a fused optimiser writing a flat buffer the parameters are views of) bumps neither -- call this after such a write.
+        ``parallel.broadcast_parameters`` and ``optim.FlatAdam`` do.  The blob tensors are kept and re-filled in place."""
+        self._pack_generation += 1
 
     def packed(self, dtype=None):
         """uint8 device tensor holding the weights in MFMA-fragment order (``csrc/sn_layout.h``); rebuilt

@@ -67,22 +67,56 @@ class FlatGradBuffer:
     def zero(self):
         """Replaces ``optimizer.zero_grad()``: one memset, views stay attached."""
         self.flat.zero_()
-        lo = self.flat.data_ptr()
-        hi = lo + self.flat.numel() * self.flat.element_size()
-        for p in self.params:                      # re-attach if someone set grads to None / replaced them
-            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
-                self._reattach()
-                break
+        self._reattach()
+
+    def _slot(self, i):
+        off = self._offsets[i]
+        p = self.params[i]
+        return self.flat[off:off + p.numel()].view_as(p)
+
+    @property
+    def _offsets(self):
+        if not hasattr(self, "_off"):
+            self._off, o = [], 0
+            for p in self.params:
+                self._off.append(o)
+                o += p.numel()
+        return self._off
+
+    def _is_view(self, g, i):
+        p = self.params[i]
+        return (g is not None and g.data_ptr() == self.flat.data_ptr() + self._offsets[i] * self.flat.element_size()
+                and g.shape == p.shape and g.is_contiguous() and g.dtype == self.flat.dtype)
 
     def _reattach(self):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for i, p in enumerate(self.params):
+            if not self._is_view(p.grad, i):
+                p.grad = self._slot(i)
+
+    def sync_views(self):
+        """Make the flat buffer hold the gradients autograd actually produced.  ``param.grad`` normally IS a view into it
+        (autograd accumulates in place), but ``module.zero_grad()`` / ``optimizer.zero_grad()`` with PyTorch's default
+        ``set_to_none=True`` detach the views: autograd then allocates fresh ``.grad`` tensors and the flat buffer would go
+        stale (all-reduce and optimizer step on zeros -- training silently stops).  Stray gradients are copied into their
+        slot, a ``None`` gradient (parameter unused this step) becomes zeros, and the views are re-attached.  Called by
+        ``all_reduce_mean`` and ``FlatAdam.step``.  Returns the number of parameters that had to be repaired."""
+        fixed = 0
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if self._is_view(g, i):
+                continue
+            slot = self._slot(i)
+            if g is None:
+                slot.zero_()
+            else:
+                slot.copy_(g.reshape(p.shape))
+            p.grad = slot
+            fixed += 1
+        return fixed
 
     def all_reduce_mean(self, group=None):
         """The single exchange step of a training iteration: sum over ranks, then scale by 1/world (DDP semantics)."""
+        self.sync_views()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.mul_(1.0 / dist.get_world_size(group))
@@ -95,3 +129,5 @@ def broadcast_parameters(modules, src=0):
         for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):
                 dist.broadcast(t.data, src=src)
+            if hasattr(m, "invalidate_packed"):          # written through .data: Parameter._version did not move
+                m.invalidate_packed()

@@ -20,7 +20,8 @@ import torch
 from torch import nn
 
 from .nerf import Embedding, NeRF
-from .parallel import FlatGradBuffer, broadcast_parameters
+from .optim import FlatAdam
+from .parallel import broadcast_parameters
 from .losses import psnr, render_loss      # noqa: F401  (psnr re-exported: metrics.py:14-15)
 from .rendering import render_rays
 
@@ -63,9 +64,17 @@ class SinNeRFSystem(nn.Module):
 
     # ---- sinnerf.py:202-210 + utils/__init__.py:11-57 -----------------------------------------------------------
     def configure_optimizers(self):
+        """Adam(lr, eps=1e-8, weight_decay) + MultiStepLR as ``get_optimizer`` / ``get_scheduler`` build them
+        (utils/__init__.py:19-21, 27-31).  The optimiser is ``FlatAdam`` (a ``torch.optim.Optimizer``): parameters and
+        gradients of both NeRFs live in flat buffers, one step = the single all-reduce + one ``sn_adam_step`` launch."""
         hp = self.hparams
         params = [p for m in self.models for p in m.parameters()]
-        self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=1e-8, weight_decay=hp.weight_decay)
+        if params[0].is_cuda:
+            self.optimizer = FlatAdam(self.models, lr=hp.lr, eps=1e-8, weight_decay=hp.weight_decay)
+            self._flat = self.optimizer.grads
+        else:       # module still on the host (Lightning calls configure_optimizers before .to(device) in some versions):
+            # the reference's own optimiser; the render path itself has no CPU form and raises on CPU tensors
+            self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=1e-8, weight_decay=hp.weight_decay)
         scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=hp.decay_step, gamma=hp.decay_gamma)
         return [self.optimizer], [scheduler]
 
@@ -97,18 +106,26 @@ class SinNeRFSystem(nn.Module):
 
     # ---- minimal driver: one optimisation step with the single flat all-reduce -----------------------
     def setup_distributed(self):
+        """Replicas start identical (what DDP's constructor does, train.py:51-52); returns the flat gradient buffer whose
+        all-reduce is the step's one exchange."""
         broadcast_parameters(self.models)
-        self._flat = FlatGradBuffer(self.models)
+        if not hasattr(self, "optimizer"):
+            self.configure_optimizers()          # (an existing FlatAdam already saw the broadcast: its flat buffer IS p.data)
         return self._flat
 
     def train_step(self, batch):
+        """zero -> forward -> loss -> backward -> [all-reduce of the flat gradient buffer + fused Adam] (FlatAdam.step)."""
         if not hasattr(self, "optimizer"):
             self.configure_optimizers()
-        if self._flat is None:
-            self._flat = FlatGradBuffer(self.models)
-        self._flat.zero()
+        self.optimizer.zero_grad()
         out = self.training_step(batch)
         out["loss"].backward()
-        self._flat.all_reduce_mean()             # the one exchange step
-        self.optimizer.step()
+        self.optimizer.step()                    # the one exchange step (RCCL all-reduce, mean) + sn_adam_step
         return out
+
+    def replica_checksum(self):
+        """fp64 sum and sum of squares of the flat parameter buffer: equal on every rank iff the replicas are identical
+        (what the bench's multi-GPU training leg asserts after a few steps)."""
+        flat = self.optimizer.flat.double() if hasattr(self, "optimizer") else \
+            torch.cat([p.detach().reshape(-1) for m in self.models for p in m.parameters()]).double()
+        return torch.stack([flat.sum(), (flat * flat).sum()])

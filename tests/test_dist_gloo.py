@@ -36,6 +36,22 @@ def _worker(rank, world, port, q):
         local = torch.cat(local)
         assert torch.equal(flat.flat, local)                 # views alias the flat buffer
         red = flat.all_reduce_mean().clone()
+        # zero_grad(set_to_none=True) detaches the views; autograd then allocates fresh .grad tensors.  The
+        # exchange must still see them (sync_views copies the strays back and re-attaches) instead of a stale flat buffer.
+        for m in models:
+            m.zero_grad(set_to_none=True)
+        assert all(p.grad is None for p in flat.params)
+        off = 0
+        for i, p in enumerate(flat.params):
+            if i != 3:                                       # one parameter unused this step: stays None -> zeros
+                p.grad = local[off:off + p.numel()].view_as(p).clone() * 2
+            off += p.numel()
+        red2 = flat.all_reduce_mean().clone()
+        assert all(flat._is_view(p.grad, i) for i, p in enumerate(flat.params))
+        o3 = flat._offsets[3]
+        assert (red2[o3:o3 + flat.params[3].numel()] == 0).all()
+        local2 = local * 2
+        local2[o3:o3 + flat.params[3].numel()] = 0
         # rays: contiguous shards, every ray exactly once, no collective on the data path
         rays = torch.arange(1003 * 8, dtype=torch.float32).reshape(1003, 8)
         mine = shard_rays(rays)
@@ -44,7 +60,8 @@ def _worker(rank, world, port, q):
         full = gather_rows(mine[:, :3].contiguous(), 1003)
         if rank == 0:
             assert torch.equal(full, rays[:, :3])
-        q.put((rank, w0.double().sum().item(), local.double().numpy(), red.double().numpy()))
+        q.put((rank, w0.double().sum().item(), local.double().numpy(), red.double().numpy(), local2.double().numpy(),
+               red2.double().numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -62,8 +79,10 @@ def test_flat_allreduce_and_sharding_world2():
         assert p.exitcode == 0
     assert res[0][1] == res[1][1]                            # broadcast made the replicas identical
     mean = (res[0][2] + res[1][2]) / 2
+    mean2 = (res[0][4] + res[1][4]) / 2
     for r in res:
         assert np.allclose(r[3], mean, rtol=0, atol=1e-6)    # every rank holds the mean gradient
+        assert np.allclose(r[5], mean2, rtol=0, atol=1e-6)   # ... also after the views had been detached
 
 
 def test_shard_bounds_cover_everything():

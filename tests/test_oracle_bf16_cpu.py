@@ -1,0 +1,46 @@
+"""CPU: the bf16-emulation hooks of the oracle (test infrastructure for the reduced-precision GPU tests) and the ray
+generators of the non-lego BASELINE configs."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+
+
+def test_bf16_round_is_round_to_nearest_even():
+    torch = pytest.importorskip("torch")
+    r = np.random.RandomState(0)
+    a = np.concatenate([r.standard_normal(50000).astype(np.float32) * 10.0 ** r.randint(-20, 20, 50000),
+                        np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, 3.3895314e38, np.inf, -np.inf], np.float32)])
+    ref = torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    assert np.array_equal(O.bf16_round(a), ref)
+    assert np.isnan(O.bf16_round(np.array([np.nan], np.float32))).all()
+
+
+def test_bf16_emulated_forward_and_backward_close_to_fp32():
+    p = O.init_params(0, True)
+    r = np.random.RandomState(1)
+    pts = r.uniform(-2, 2, (512, 3)).astype(np.float32)
+    x = np.concatenate([O.embedding(pts, 10), O.embedding(r.standard_normal((512, 3)).astype(np.float32), 4)], 1)
+    c32, c16 = {}, {}
+    o32 = O.nerf_forward(p, x, cache=c32)
+    with O.bf16_operands():
+        o16 = O.nerf_forward(p, x, cache=c16)
+    assert not np.array_equal(o32, o16)
+    assert np.abs(o32 - o16).max() <= 3e-2 * np.abs(o32).max()
+    assert np.array_equal(O.nerf_forward(p, x), o32)                      # the hook is restored on exit
+    g = r.standard_normal((512, 4)).astype(np.float32)
+    g32 = O.nerf_backward(p, c32, g)
+    g16 = O.nerf_backward(p, c32, g, operand_round=O.bf16_round)
+    for k, v in g32.items():
+        e = np.linalg.norm(g16[k] - v) / np.linalg.norm(v)
+        assert 0 < e < 2e-2, (k, e)
+
+
+def test_patch_ray_generators_match_config_sizes():
+    ll, dt = O.llff_patch_rays(0), O.dtu_patch_rays(0)
+    assert ll.shape == (5292, 8) and dt.shape == (3920, 8)                # BASELINE configs 3, 4 (SURVEY §8a sizes)
+    assert np.allclose(ll[:, 6], 1.2) and np.allclose(ll[:, 7], 8.0)
+    assert np.allclose(dt[:, 6], 2.125) and np.allclose(dt[:, 7], 4.525)
+    full = O.get_rays(8, 10, 7.0, np.concatenate([np.eye(3), np.zeros((3, 1))], 1), 1.0, 2.0).reshape(8, 10, 8)
+    pr = O.patch_rays(8, 10, 7.0, np.concatenate([np.eye(3), np.zeros((3, 1))], 1), 1.0, 2.0, 1, 2, 3, 2, 3, 2)
+    assert np.array_equal(pr.reshape(2, 3, 8), full[2:6:2, 1:10:3])
