@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- rendered rays/s of the render_rays hot path on MI355X (BASELINE.json metric).
 
-Workload (BASELINE configs[1]): nerf_synthetic/lego-shaped 400x400 frame = 160 000 synthetic pin-hole rays,
-N_samples=64, N_importance=64, fp32, eval mode (perturb=0, noise_std=0, white_back=True), random-init
-("teacher") NeRF weights.  One step = one full pass of the hot path (coarse MLP -> compositing -> sample_pdf ->
-fine MLP -> compositing) over that frame, inputs resident in HBM.  N>1: every rank renders its own frame
-(rays shard across ranks, no data-path collective) -> weak scaling.
+Headline workload (BASELINE configs[1]): nerf_synthetic/lego-shaped 400x400 frame = 160 000 synthetic pin-hole rays,
+N_samples=64, N_importance=64, fp32 (the reference's own precision), eval mode (perturb=0, noise_std=0, white_back=True),
+random-init ("teacher") NeRF weights.  One step = one full pass of the hot path (coarse MLP -> compositing -> sample_pdf ->
+fine MLP -> compositing) over that frame, inputs resident in HBM.  N>1: every rank renders its own frame (rays shard across
+ranks, no data-path collective) -> weak scaling.
 
-Prints ONE JSON line (rank 0) following the driver contract, plus `roofline` (dominant kernel = fused MLP,
-MFMA-bound) and `cpu_baseline` (the numpy oracle on the host cores, bounded sample, N=1 only).
+Prints ONE JSON line (rank 0) following the driver contract, plus `roofline` (dominant kernel = fused MLP fine pass,
+MFMA-bound, timed with HIP events on the launch stream) and `cpu_baseline` (the reference's op sequence as stock torch
+ops on the host cores, bounded sample, N=1 only).  Secondary records, all measured OUTSIDE the timed region of the headline
+number and each with its own roofline:
+  records.bf16               the same frame with bf16-operand MFMAs (north_star's contraction precision, configs 3/5)
+  records.config5_bf16/fp32  BASELINE configs[4] shape on one GPU: 800x800, 64+128 samples
+  train_step / train_step_bf16   fwd+bwd of one 4096-ray patch batch (perturb=1, noise_std=1)
+  train_dp                   the data-parallel training leg: per-rank 4096-ray patch -> backward -> ONE all-reduce of the
+                             flat gradient buffer (RCCL when N>1) -> fused Adam; replicas asserted identical
 """
 import argparse
 import json
@@ -23,8 +30,145 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FLOP_PER_POINT = 1186816            # SURVEY §8d / BASELINE.md §2 (un-padded MACs x2)
-FLOP_PER_POINT_SIGMA_ONLY = 2 * (63 * 256 + 3 * 256 * 256 + 319 * 256 + 3 * 256 * 256 + 256)
+FLOP_PER_POINT_TRAIN = 3489024      # forward + backward
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def build_models(O, dev, dtype, train=False):
+    import sinnerf_amd
+    models, params = [], []
+    for seed in (0, 1):
+        p = O.init_params(seed, teacher=True)
+        m = sinnerf_amd.NeRF(use_new_activation=True, compute_dtype=dtype)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+        models.append((m.to(dev).train() if train else m.to(dev).eval())); params.append(p)
+    return models, params
+
+
+def time_render(models, emb, rays, NS, NI, steps, warmup, barrier=None):
+    """`steps` eval renders of `rays`; returns (seconds for all steps, fine-launch ms, coarse-launch ms) with the MLP launches
+    timed by HIP events on the launch stream (rendering.PROFILE)."""
+    from sinnerf_amd import rendering
+    n_rays = rays.shape[0]
+
+    def step():
+        with torch.no_grad():
+            return rendering.render_rays(models, emb, rays, NS, False, 0, 0, NI, 1024 * 32 * 16, True)
+
+    for _ in range(warmup):
+        step()
+    rendering.PROFILE = []
+    (barrier or torch.cuda.synchronize)()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    (barrier or torch.cuda.synchronize)()
+    dt = time.perf_counter() - t0
+    prof, rendering.PROFILE = rendering.PROFILE, None
+    assert all(torch.isfinite(v).all() for v in out.values())
+    fine = [e0.elapsed_time(e1) for (n, so, e0, e1) in prof if n == n_rays * (NS + NI)]
+    coarse = [e0.elapsed_time(e1) for (n, so, e0, e1) in prof if n == n_rays * NS]
+    return dt, float(np.mean(fine)), float(np.mean(coarse))
+
+
+def roofline_record(dtype, n_rays, NS, NI, ms_fine, ms_coarse, ms_step, traffic=None, traffic_note=None):
+    flop_fine = FLOP_PER_POINT * n_rays * (NS + NI)
+    achieved = flop_fine / (ms_fine * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[dtype]
+    return {"bound": "mfma",
+            "kernel": "mlp_fwd_%s_kernel (fine pass, %d points/launch)" % ("f32" if dtype == "fp32" else "bf16", n_rays * (NS + NI)),
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "traffic_note": traffic_note or "no PMC summary for this workload",
+            "flop_per_launch": flop_fine, "avg_launch_ms": ms_fine, "coarse_launch_ms": ms_coarse,
+            "mlp_share_of_step": (ms_fine + ms_coarse) / ms_step}
+
+
+def pmc_traffic(n_points, dtype):
+    """HBM bytes of the fine-pass launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, tools/summarize_prof.py); PMC cannot be sampled from inside the process."""
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        if tj.get("points") == n_points and dtype == "fp32":
+            return tj["hbm_bytes"], "bytes/launch from %s (algorithmic %d)" % (tj["source"], tj["algorithmic_bytes"])
+    except Exception:                       # noqa: BLE001
+        pass
+    return None, None
+
+
+def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
+    """fwd+bwd of render_rays on a 4096-ray batch (perturb=1, noise_std=1, MSE coarse+fine), gradients only."""
+    import sinnerf_amd
+    from sinnerf_amd import rendering
+    models, _ = build_models(O, dev, dtype, train=True)
+    emb = [sinnerf_amd.Embedding(3, 10), sinnerf_amd.Embedding(3, 4)]
+    n = rays.shape[0]
+    tr = rays[:: max(1, n // 4096)][:4096].contiguous()
+    tgt = torch.rand((tr.shape[0], 3), device=dev)
+
+    def tstep():
+        for m in models:
+            m.zero_grad(set_to_none=True)
+        r = rendering.render_rays(models, emb, tr, NS, False, 1.0, 1.0, NI, 32768, True)
+        (((r["rgb_fine"] - tgt) ** 2).mean() + ((r["rgb_coarse"] - tgt) ** 2).mean()).backward()
+    tstep(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        tstep()
+    torch.cuda.synchronize()
+    tdt = (time.perf_counter() - t1) / reps
+    pts = tr.shape[0] * (NS + NS + NI)
+    tflop = FLOP_PER_POINT_TRAIN * pts / tdt / 1e12
+    return {"rays": tr.shape[0], "ms": tdt * 1e3, "rays_per_s": tr.shape[0] / tdt, "bound": "mfma", "achieved_tflops": tflop,
+            "peak_tflops": PEAK_TFLOPS[dtype], "frac_of_mfma_peak": tflop / PEAK_TFLOPS[dtype],
+            **({"frac_of_fp32_mfma_peak": tflop / PEAK_TFLOPS["fp32"]} if dtype == "fp32" else {})}
+
+
+def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2):
+    """The multi-GPU training path of SURVEY §8e: replicas (broadcast at start), every rank draws its OWN 4096-ray patch,
+    fwd + loss + bwd, ONE all-reduce (mean) of the flat 1 191 688-float gradient buffer over RCCL, fused Adam on the flat
+    parameter buffer (FlatAdam / sn_adam_step).  Returns per-rank step time (max over ranks), the all-reduce time from HIP
+    events around the collective, and asserts the replicas are still bit-identical afterwards."""
+    import torch.distributed as dist
+    from sinnerf_amd.system import SinNeRFSystem
+    torch.manual_seed(1234 + rank)                               # replicas start DIFFERENT; setup_distributed() fixes that
+    sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=True).to(dev)
+    flat = sysm.setup_distributed()
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=100 + rank)[::39][:4096]).to(dev)      # this rank's patch
+    batch = {"rays": rays, "rgbs": torch.rand((rays.shape[0], 3), device=dev)}
+    for _ in range(warmup):
+        sysm.train_step(batch)
+    flat.profile = []
+    if world > 1:
+        dist.barrier(device_ids=[dev.index]) if dist.get_backend() == "nccl" else dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = sysm.train_step(batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ar_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in flat.profile]
+    flat.profile = None
+    chk = sysm.replica_checksum()
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    identical, n_seen = True, 1
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        identical = all(torch.equal(c, allc[0]) for c in allc)
+        n_seen = dist.get_world_size()
+    assert identical, "replicas diverged: the gradient all-reduce / optimizer step is not replica-consistent"
+    assert torch.isfinite(out["loss"]).item()
+    step_s = float(t.item()) / steps
+    pts = 4096 * 192
+    tflop = FLOP_PER_POINT_TRAIN * pts / step_s / 1e12
+    return {"rays_per_rank_per_step": int(rays.shape[0]), "steps": steps, "dtype": dtype, "ms_per_step": step_s * 1e3,
+            "train_rays_per_s_total": world * rays.shape[0] / step_s, "per_rank_tflops": tflop,
+            "frac_of_mfma_peak": tflop / PEAK_TFLOPS[dtype],
+            "all_reduce_us": float(np.mean(ar_us)) if ar_us else 0.0, "all_reduce_bytes": int(flat.flat.numel() * 4),
+            "all_reduce_backend": (dist.get_backend() if world > 1 else "none (world 1)"),
+            "n_ranks_seen": n_seen, "replicas_identical_after": steps + warmup,
+            "optimizer": "FlatAdam (sn_adam_step, one launch)", "loss": float(out["loss"].detach())}
 
 
 def main():
@@ -36,7 +180,9 @@ def main():
     ap.add_argument("--hw", type=int, nargs=2, default=[400, 400])
     ap.add_argument("--n-importance", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline number + roofline only (used by the rocprof passes)")
     ap.add_argument("--cpu-rays", type=int, default=4096)
+    ap.add_argument("--dist-backend", default="nccl", help="developer option: 'gloo' lets N ranks share one GPU for testing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -44,77 +190,43 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    if args.dist_backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")          # RCCL
+        dist.init_process_group(args.dist_backend)          # "nccl" = RCCL
 
     import sinnerf_amd
-    from sinnerf_amd import rendering
     from oracle import oracle_np as O          # inputs generator + cpu_baseline leg only
 
     H, W = args.hw
-    models, params = [], []
-    for seed in (0, 1):
-        p = O.init_params(seed, teacher=True)
-        m = sinnerf_amd.NeRF(use_new_activation=True, compute_dtype=args.dtype)
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
-        models.append(m.to(dev).eval()); params.append(p)
+    models, params = build_models(O, dev, args.dtype)
     emb = [sinnerf_amd.Embedding(3, 10), sinnerf_amd.Embedding(3, 4)]
     rays_np = O.lego_rays(H, W, seed=rank)
     rays = torch.from_numpy(rays_np).to(dev)
     n_rays = rays.shape[0]
     NS, NI = 64, args.n_importance
 
-    def step():
-        with torch.no_grad():
-            return rendering.render_rays(models, emb, rays, NS, False, 0, 0, NI, 1024 * 32 * 16, True)
-
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if args.dist_backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    rendering.PROFILE = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof, rendering.PROFILE = rendering.PROFILE, None
+    dt, ms_fine, ms_coarse = time_render(models, emb, rays, NS, NI, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert all(torch.isfinite(v).all() for v in out.values())
 
+    res = None
     if rank == 0:
         total_rays = n_rays * world * args.steps
         value = total_rays / dt
-        # dominant kernel: the fused MLP launch over the fine samples (2/3 of all points)
-        fine = [(n, e0.elapsed_time(e1)) for (n, so, e0, e1) in prof if n == n_rays * (NS + NI)]
-        coarse = [(n, e0.elapsed_time(e1)) for (n, so, e0, e1) in prof if n == n_rays * NS]
-        ms_fine = float(np.mean([t for _, t in fine]))
-        ms_coarse = float(np.mean([t for _, t in coarse]))
-        flop_fine = FLOP_PER_POINT * n_rays * (NS + NI)
-        achieved = flop_fine / (ms_fine * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.dtype]
-        # HBM bytes of the same launch from the rocprofv3 PMC passes of this command (FETCH_SIZE x2 gfx950 correction +
-        # WRITE_SIZE, tools/summarize_prof.py); PMC cannot be sampled from inside the process, so the committed summary
-        # is quoted when it matches this workload, else null.
-        traffic, traffic_note = None, "no PMC summary for this workload"
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-            if tj.get("points") == n_rays * (NS + NI) and args.dtype == "fp32":
-                traffic = tj["hbm_bytes"]
-                traffic_note = "bytes/launch from %s (algorithmic %d)" % (tj["source"], tj["algorithmic_bytes"])
-        except Exception:
-            pass
+        traffic, traffic_note = pmc_traffic(n_rays * (NS + NI), args.dtype)
         res = {
             "metric": "rendered rays/sec (64+%d samples), lego %dx%d" % (NI, W, H),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -123,76 +235,122 @@ def main():
             "config": {"workload": "nerf_synthetic/lego-shaped %dx%d frame (%d rays/GPU), N_samples=64, N_importance=%d, "
                                    "eval render (perturb=0, noise_std=0, white_back), random-init teacher weights"
                                    % (W, H, n_rays, NI),
-                       "rays_per_step_per_gpu": n_rays, "points_per_ray": NS + NS + NI, "parallelism": "rays sharded x%d, no collective" % world},
-            "roofline": {"bound": "mfma", "kernel": "mlp_fwd_%s_kernel (fine pass, %d points/launch)" % ("f32" if args.dtype == "fp32" else "bf16", n_rays * (NS + NI)),
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "traffic_note": traffic_note,
-                         "flop_per_launch": flop_fine, "avg_launch_ms": ms_fine,
-                         "coarse_launch_ms": ms_coarse,
-                         "mlp_share_of_step": (ms_fine + ms_coarse) / (dt / args.steps * 1e3)},
-            "roofline_rays_per_s_per_gpu": peak * 1e12 / (FLOP_PER_POINT * (NS + NS + NI)),
+                       "rays_per_step_per_gpu": n_rays, "points_per_ray": NS + NS + NI,
+                       "parallelism": "rays sharded x%d, no collective" % world},
+            "roofline": roofline_record(args.dtype, n_rays, NS, NI, ms_fine, ms_coarse, dt / args.steps * 1e3, traffic, traffic_note),
+            "roofline_rays_per_s_per_gpu": PEAK_TFLOPS[args.dtype] * 1e12 / (FLOP_PER_POINT * (NS + NS + NI)),
         }
-        if world == 1:
-            # secondary figure: one optimisation-shaped step (fwd+bwd of render_rays, 4096 rays, perturb=1, noise_std=1).
-            # fp32: every kernel is MFMA-bound (fraction of the fp32 peak).  bf16 = mixed precision (bf16-operand forward,
-            # chain and weight gradients over bf16 activations / gradients in HBM, ~26 KB per sample point: 5.6 written by
-            # the forward, 10.25 moved by the chain, ~10.5 read by dW).
-            try:
-                for m in models:
-                    m.train()
-                tr = rays[:: n_rays // 4096][:4096].contiguous()
-                tgt = torch.rand((4096, 3), device=dev)
 
-                def tstep():
-                    for m in models:
-                        m.zero_grad(set_to_none=True)
-                    r = rendering.render_rays(models, emb, tr, NS, False, 1.0, 1.0, NI, 32768, True)
-                    (((r["rgb_fine"] - tgt) ** 2).mean() + ((r["rgb_coarse"] - tgt) ** 2).mean()).backward()
-                tstep(); torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    tstep()
-                torch.cuda.synchronize()
-                tdt = (time.perf_counter() - t1) / 3
-                pts = 4096 * (NS + NS + NI)
-                res["train_step"] = {"rays": 4096, "ms": tdt * 1e3, "rays_per_s": 4096 / tdt}
-                if args.dtype == "fp32":
-                    tflop = 3489024 * pts / tdt / 1e12
-                    res["train_step"].update({"bound": "mfma", "achieved_tflops": tflop, "frac_of_fp32_mfma_peak": tflop / peak})
-                else:
-                    tbs = 26000.0 * pts / tdt / 1e12
-                    res["train_step"].update({"bound": "mixed (hbm / issue)", "approx_hbm_tb_per_s": tbs, "frac_of_8_tb_per_s": tbs / 8.0})
-            except Exception as e:                      # noqa: BLE001
-                res["train_step"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            ncpu = os.cpu_count() or 1
-            sample = rays_np[:: max(1, n_rays // args.cpu_rays)][:args.cpu_rays]
-            t0 = time.perf_counter()
-            O.render_rays(params, sample, NS, False, 0, 0, NI, 1024 * 32, True, False)
-            cdt = time.perf_counter() - t0
-            res["cpu_baseline"] = {"value": sample.shape[0] / cdt, "unit": "rays/s", "cores": ncpu, "kind": "port",
-                                   "sample": "%d rays of the same frame, numpy/OpenBLAS oracle (oracle/oracle_np.py), "
-                                             "%.1f s" % (sample.shape[0], cdt)}
-        if world == 1 and not args.no_cpu_baseline:
-            # the same algorithm as stock PyTorch-ROCm eager ops on this GPU (oracle/torch_ref.py, fp32, no_grad): the
-            # "reference on the MI355X" figure SURVEY §8d asks for beside the CPU baseline.  Reported, never the target.
+    # ---- the data-parallel training leg (every rank takes part; it is the only place a collective runs) ----------------
+    if not args.no_extra:
+        try:
+            leg = train_dp_leg(O, dev, "bf16", rank, world, steps=max(3, min(args.steps, 10)))
+            leg32 = train_dp_leg(O, dev, "fp32", rank, world, steps=3) if world == 1 else None
+        except AssertionError:
+            raise
+        except Exception as e:                      # noqa: BLE001
+            leg, leg32 = {"error": repr(e)}, None
+        if rank == 0:
+            res["train_dp"] = leg
+            if leg32 is not None:
+                res["train_dp_fp32"] = leg32
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        # ---- secondary records: other precisions / configs, each with its own roofline (never the headline `value`) ----
+        records = {}
+        try:
+            other = "bf16" if args.dtype == "fp32" else "fp32"
+            mo, _ = build_models(O, dev, other)
+            d2, f2, c2 = time_render(mo, emb, rays, NS, NI, 3, 1)
+            records[other] = {"value": n_rays * 3 / d2, "unit": "rays/s", "ms_per_step": d2 / 3 * 1e3,
+                              "workload": "same frame, %s-operand MFMAs (fp32 accumulate)" % other,
+                              "roofline": roofline_record(other, n_rays, NS, NI, f2, c2, d2 / 3 * 1e3),
+                              "roofline_rays_per_s_per_gpu": PEAK_TFLOPS[other] * 1e12 / (FLOP_PER_POINT * (NS + NS + NI))}
+            if (H, W, NI) == (400, 400, 64):
+                big = torch.from_numpy(O.lego_rays(800, 800, seed=0)).to(dev)          # BASELINE configs[4] shape, one GPU
+                for dt_name, k in (("bf16", 2), ("fp32", 1)):
+                    mb, _ = build_models(O, dev, dt_name)
+                    d5, f5, c5 = time_render(mb, emb, big, 64, 128, k, 1)
+                    records["config5_" + dt_name] = {
+                        "value": big.shape[0] * k / d5, "unit": "rays/s", "ms_per_step": d5 / k * 1e3,
+                        "workload": "lego 800x800 frame (640 000 rays), 64+128 samples, %s, one GPU" % dt_name,
+                        "roofline": roofline_record(dt_name, big.shape[0], 64, 128, f5, c5, d5 / k * 1e3),
+                        "roofline_rays_per_s_per_gpu": PEAK_TFLOPS[dt_name] * 1e12 / (FLOP_PER_POINT * 256)}
+                del big
+        except Exception as e:                      # noqa: BLE001
+            records["error"] = repr(e)
+        res["records"] = records
+        for key, dt_name in (("train_step", "fp32"), ("train_step_bf16", "bf16")):
             try:
-                from oracle import torch_ref as T
-                tp = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p in params]
-                er = rays[:: max(1, n_rays // 16384)][:16384].contiguous()
-                with torch.no_grad():
-                    T.render(tp, er[:1024], NS, NI, True)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for i in range(0, er.shape[0], 4096):
-                        T.render(tp, er[i:i + 4096], NS, NI, True)
-                    torch.cuda.synchronize()
-                edt = time.perf_counter() - t1
-                res["torch_eager_gpu_baseline"] = {"value": er.shape[0] / edt, "unit": "rays/s", "kind": "port",
-                                                   "sample": "%d rays of the same frame in chunks of 4096, stock torch fp32 ops on the same MI355X" % er.shape[0],
-                                                   "speedup_of_value": value / (er.shape[0] / edt)}
-            except Exception as e:                      # noqa: BLE001
-                res["torch_eager_gpu_baseline"] = {"error": repr(e)}
+                res[key] = train_step_record(O, dev, dt_name, rays, NS, NI)
+            except Exception as e:                  # noqa: BLE001
+                res[key] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the reference's op sequence (models/rendering.py:126-335 + models/nerf.py) as stock torch ops on
+        # the reference's own runtime -- torch CPU, all host cores -- on a bounded sample of the same frame (oracle/torch_ref.py;
+        # /root/reference itself cannot travel to the GPU box).  The numpy restatement is kept as a secondary figure.
+        ncpu = os.cpu_count() or 1
+        sample = np.ascontiguousarray(rays_np[:: max(1, n_rays // args.cpu_rays)][:args.cpu_rays])
+        from oracle import torch_ref as T
+        tp = [{k: torch.from_numpy(v) for k, v in p.items()} for p in params]
+        srays = torch.from_numpy(sample)
+        # thread count: torch's intra-op pool with ALL cores of a 256-core host is 10x SLOWER than with a few dozen on this
+        # op sequence (measured: 26 rays/s at 256 threads) -- so the count is calibrated on a 256-ray probe and the best one
+        # is used and reported as `cores`
+        cal = {}
+        with torch.no_grad():
+            for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
+                torch.set_num_threads(nt)
+                T.render(tp, srays[:64], NS, NI, True)                                   # warm the pool at this size
+                t0 = time.perf_counter()
+                T.render(tp, srays[:256], NS, NI, True)
+                cal[nt] = 256 / (time.perf_counter() - t0)
+                if time.perf_counter() - t0 > 8.0:
+                    break
+            nthreads = max(cal, key=cal.get)
+            torch.set_num_threads(nthreads)
+            nb = min(sample.shape[0], max(1024, int(cal[nthreads] * 15) // 1024 * 1024))  # ~15 s of CPU work
+            T.render(tp, srays[:256], NS, NI, True)
+            t0 = time.perf_counter()
+            for i in range(0, nb, 1024):                                                 # eval.py-style ray chunks
+                T.render(tp, srays[i:i + 1024], NS, NI, True)
+            cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": nb / cdt, "unit": "rays/s", "cores": nthreads, "host_cores": ncpu, "kind": "port",
+                               "sample": "%d rays of the same frame in chunks of 1024, stock torch CPU ops with %d threads "
+                                         "(oracle/torch_ref.py = the reference's op sequence), %.1f s" % (nb, nthreads, cdt),
+                               "thread_calibration_rays_per_s": {str(k): v for k, v in cal.items()},
+                               "note": "survey-time probe of the UNMODIFIED reference render_rays on this container's 8 host "
+                                       "cores: ~1.1 k rays/s (SURVEY.md §6); the reference itself is not present on the GPU box"}
+        try:
+            ns = sample[:1024]
+            t0 = time.perf_counter()
+            O.render_rays(params, ns, NS, False, 0, 0, NI, 1024 * 32, True, False)
+            ndt = time.perf_counter() - t0
+            res["cpu_baseline"]["numpy_oracle_rays_per_s"] = ns.shape[0] / ndt
+        except Exception as e:                      # noqa: BLE001
+            res["cpu_baseline"]["numpy_oracle_rays_per_s"] = repr(e)
+        # the same op sequence as stock PyTorch-ROCm eager ops on this GPU: the "reference on the MI355X" figure SURVEY §8d
+        # asks for beside the CPU baseline.  Reported, never the target.
+        try:
+            tg = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p in params]
+            er = rays[:: max(1, n_rays // 16384)][:16384].contiguous()
+            with torch.no_grad():
+                T.render(tg, er[:1024], NS, NI, True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(0, er.shape[0], 4096):
+                    T.render(tg, er[i:i + 4096], NS, NI, True)
+                torch.cuda.synchronize()
+            edt = time.perf_counter() - t1
+            res["torch_eager_gpu_baseline"] = {"value": er.shape[0] / edt, "unit": "rays/s", "kind": "port",
+                                               "sample": "%d rays of the same frame in chunks of 4096, stock torch fp32 ops on the same MI355X" % er.shape[0],
+                                               "speedup_of_value": res["value"] / (er.shape[0] / edt)}
+            if "bf16" in res.get("records", {}):
+                res["torch_eager_gpu_baseline"]["speedup_of_bf16_record"] = res["records"]["bf16"]["value"] / (er.shape[0] / edt)
+        except Exception as e:                      # noqa: BLE001
+            res["torch_eager_gpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

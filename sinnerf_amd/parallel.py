@@ -118,8 +118,15 @@ class FlatGradBuffer:
         """The single exchange step of a training iteration: sum over ranks, then scale by 1/world (DDP semantics)."""
         self.sync_views()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            prof = getattr(self, "profile", None)        # bench.py: a list collects (start, end) events around the collective
+            if prof is not None and self.flat.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.mul_(1.0 / dist.get_world_size(group))
+            if prof is not None and self.flat.is_cuda:
+                e1.record()
+                prof.append((e0, e1))
         return self.flat
 
 

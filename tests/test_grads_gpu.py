@@ -91,7 +91,9 @@ def test_render_rays_gradients_golden(name):
     loss = sum((res[k] * torch.from_numpy(v).to(dev())).sum() for k, v in coef.items())
     assert abs(loss.item() - float(z["loss"])) <= 2e-4 * max(1.0, abs(float(z["loss"])))
     loss.backward()
-    check_grads(z, [model_grads(mc), model_grads(mf)], rel_coarse=1e-4, rel_fine=1e-2)
+    errs = check_grads(z, [model_grads(mc), model_grads(mf)], rel_coarse=1e-4, rel_fine=5e-3)
+    print(name, "max coarse", max(e for (t, _), (e, _) in errs.items() if t == "coarse"),
+          "max fine", max(e for (t, _), (e, _) in errs.items() if t == "fine"))
 
 
 def test_detach_coarse_and_frozen_params():
@@ -212,8 +214,8 @@ def test_bf16_forward_training_gradients_close_to_fp32():
 
 
 def test_bf16_forward_training_trajectory():
-    """The 25-step Adam run of the fp32 trajectory test, with the bf16-forward training path: loss within 5 % of the
-    stock-PyTorch fp32 run at every step, held-out PSNR within 0.3 dB."""
+    """The 25-step Adam run of the fp32 trajectory test, with the bf16-forward training path: loss within 2 % of the
+    stock-PyTorch fp32 run at every step, held-out PSNR within 0.05 dB (the north_star bar for reduced precision)."""
     import sinnerf_amd
     from sinnerf_amd.losses import render_loss
     from oracle import torch_ref as T
@@ -257,9 +259,10 @@ def test_bf16_forward_training_trajectory():
     with torch.no_grad():
         ref_held = T.render(params, held, 64, 64, True)["rgb_fine"]
     ours, refl = np.asarray(ours), np.asarray(refl)
-    assert (np.abs(ours - refl) <= 5e-2 * refl).all(), np.abs(ours / refl - 1).max()
     psnr = lambda a: float(-10 * torch.log10(torch.mean((a - tgt_held) ** 2)))
-    assert abs(psnr(ours_held) - psnr(ref_held)) <= 0.3, (psnr(ours_held), psnr(ref_held))
+    print("bf16 trajectory: max loss dev", np.abs(ours / refl - 1).max(), "held-out PSNR", psnr(ours_held), psnr(ref_held))
+    assert (np.abs(ours - refl) <= 2e-2 * refl).all(), np.abs(ours / refl - 1).max()      # measured 0.8 %
+    assert abs(psnr(ours_held) - psnr(ref_held)) <= 0.05, (psnr(ours_held), psnr(ref_held))   # north_star bar; measured 0.001 dB
 
 
 def test_bf16_backward_chain_close_to_fp32_chain():

@@ -179,7 +179,38 @@ def test_sample_pdf_merge_sorted_and_complete():
         assert np.array_equal(zm, np.sort(np.concatenate([zc, zf], -1), -1))       # a permutation of the inputs
         uu = u if rand_u else O.linspace01(NI)[None].repeat(n, 0)
         ok = well_conditioned(mid, w[:, 1:-1], uu)
+        assert ok.mean() >= 0.97, ok.mean()                                        # the exclusion stays a small minority
         assert (np.abs(zf - zf_ref) <= sample_pdf_tol(mid, w[:, 1:-1], uu))[ok].all()
+
+
+@pytest.mark.parametrize("name", ["render_lego_eval_teacher", "render_llff_eval_128", "render_lego_train_teacher"])
+def test_sample_pdf_on_real_render_cases_exclusion_fraction(name):
+    """the knot-exclusion of the sample_pdf comparisons (helpers.well_conditioned) must stay a small,
+    ASSERTED fraction on the real render cases too, not only on the synthetic fixture: coarse weights of the golden render
+    cases (from the reference), importance samples from the HIP sampler vs the oracle on >= 97 % of the entries, every
+    sample inside its ray's bin range."""
+    from sinnerf_amd import _lib
+    rays, meta, rng, ref = load_case(name)
+    n, S, NI = rays.shape[0], meta["N_samples"], meta["N_importance"]
+    zc = O.coarse_z_vals(rays, S, bool(meta["use_disp"]), meta["perturb"], rng.get("perturb"))
+    w = ref["opacity_coarse"]
+    det = meta["perturb"] == 0
+    u = None if det else rng["u"]
+    mid = (np.float32(0.5) * (zc[:, :-1] + zc[:, 1:])).astype(np.float32)
+    zf_ref = O.sample_pdf(mid, w[:, 1:-1], NI, det=det, u=u)
+    zc_d, w_d = torch.from_numpy(zc).to(dev()), torch.from_numpy(np.ascontiguousarray(w)).to(dev())
+    u_d = None if det else torch.from_numpy(u).to(dev())
+    zf = torch.empty((n, NI), device=dev()); zm = torch.empty((n, S + NI), device=dev())
+    _lib.check(_lib.lib.sn_sample_pdf(_lib.ptr(zc_d), _lib.ptr(w_d), _lib.ptr(u_d), n, S, NI, _lib.ptr(zf), _lib.ptr(zm), None),
+               "sn_sample_pdf")
+    torch.cuda.synchronize()
+    zf = zf.cpu().numpy()
+    uu = O.linspace01(NI)[None].repeat(n, 0) if det else u
+    ok = well_conditioned(mid, w[:, 1:-1], uu)
+    print(name, "excluded fraction", 1 - ok.mean())
+    assert ok.mean() >= 0.97, (name, ok.mean())
+    assert (np.abs(zf - zf_ref) <= sample_pdf_tol(mid, w[:, 1:-1], uu))[ok].all()
+    assert (zf >= mid[:, :1] - 1e-6).all() and (zf <= mid[:, -1:] + 1e-6).all()      # the rest is bounded by the bin range
 
 
 # ------------------------------------------------------------------------------------- whole path
