@@ -30,7 +30,10 @@ extern "C" {
 #define SN_E_UNSUPPORTED (-4)
 #define SN_E_BADSHAPE (-5)
 
-/* sn_mlp_forward / sn_mlp_forward_embedded `flags`: reserved, pass 0. */
+/* sn_mlp_forward `flags` (sn_mlp_forward_embedded: reserved, pass 0):
+ * bit 1: dtype SN_DTYPE_BF16 only -- run the compiler-scheduled kernel (csrc/sn_mlp_fwd_bf16.hip) instead of the
+ * hand-scheduled one (csrc/sn_mlp_fwd_bf16_v3.hip); same arithmetic, kept for A/B timing and as the sigma-only / training form. */
+#define SN_FLAG_BF16_COMPILER_SCHEDULED 2
 
 int sn_abi_version(void);
 const char* sn_error_string(int code);

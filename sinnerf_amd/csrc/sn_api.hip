@@ -25,6 +25,8 @@ int sn_render_loss_launch(const float* rgb_c, const float* rgb_f, const float* d
 int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
                                int state_bf16, hipStream_t stream);
+int sn_mlp_forward_bf16_v3_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
+                                  float* out, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
                                  const float* g_depth, const float* g_w, float* g_raw, hipStream_t stream);
@@ -141,6 +143,8 @@ int sn_sample_coarse(const float* rays, long n_rays, int n_samples, int use_disp
 int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                    int sigma_only, int flags, float* out, void* stream) {
   if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  if (dtype == SN_DTYPE_BF16 && !sigma_only && !(flags & SN_FLAG_BF16_COMPILER_SCHEDULED))     // the hand-scheduled kernel
+    return sn_mlp_forward_bf16_v3_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, out, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16)
     return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out, nullptr,
                                       nullptr, 0, 0, (hipStream_t)stream);

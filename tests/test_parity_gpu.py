@@ -376,3 +376,19 @@ def test_empty_batch_and_unsupported_sizes():
     with pytest.raises(NotImplementedError):
         sinnerf_amd.render_rays([mc, mf], [sinnerf_amd.Embedding(3, 6), sinnerf_amd.Embedding(3, 4)],
                                 torch.rand((4, 8), device=dev()), 64)
+
+
+def test_bf16_hand_scheduled_kernel_equals_compiler_scheduled():
+    """csrc/sn_mlp_fwd_bf16_v3.hip (generated, hand-scheduled trunk; 7-slot weight ring) against csrc/sn_mlp_fwd_bf16.hip
+    (SN_FLAG_BF16_COMPILER_SCHEDULED): same roundings in the same order -> identical bits, on a ragged multi-tile launch
+    (more point tiles than one workgroup pass, so the weight stream wraps around between tiles)."""
+    from sinnerf_amd import rendering
+    model, _ = make_model(1, True, dtype="bf16")
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::7][:20000]).to(dev())       # 20000 x 37 points: 2891 tiles of 256
+    z = torch.sort(torch.rand((rays.shape[0], 37), device=dev()) * 4 + 2, -1)[0].contiguous()
+    with torch.no_grad():
+        a = rendering._mlp(model, rays, z, False, 0)
+        b = rendering._mlp(model, rays, z, False, 2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), (a - b).abs().max().item()
