@@ -119,6 +119,22 @@ int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, co
  * (row-major, leading dimension ldc), bias the partial column sums of a; the caller sums the partials of a problem. */
 int sn_dw_gemm(const void* tasks, int n_tasks, void* stream);
 
+/* ---- ALL weight / bias gradients of one NeRF from the stored training state, as two launches with nothing built on the
+ * host (capturable in a HIP graph): the 14 contractions above (K-split over ~one workgroup per CU by a per-mode cost model,
+ * described to the kernel BY VALUE in its arguments), then one kernel that sums the K-split partials in a fixed order
+ * (deterministic, no atomics) and writes the results in the parameters' own shapes -- what autograd hands to
+ * nn.Linear.weight.grad / .bias.grad for models/nerf.py:66-103 (the cat of the skip / direction inputs, nerf.py:133,142,
+ * becomes two column ranges of the same gradient).
+ *   acts, emb: as written by sn_mlp_forward_train; g_acts: as written by sn_mlp_backward_chain (pad rows zero);
+ *   slot_rows: a multiple of 16; dtype: SN_DTYPE_F32 (fp32 MFMAs), SN_DTYPE_BF16 (bf16 operands, fp32 state) or
+ *   SN_DTYPE_BF16_STATE (acts / g_acts stored as bf16);
+ *   workspace: sn_weight_grads_workspace_bytes(slot_rows, dtype) bytes of DEVICE scratch (the K-split partials);
+ *   grads: HOST array of SN_N_RAW_TENSORS device pointers in the order of sn_pack_weights' `raw` (NULL = not wanted);
+ *   accumulate != 0: grads[i] += result (autograd's accumulation into an existing .grad), else grads[i] = result.        */
+long sn_weight_grads_workspace_bytes(long slot_rows, int dtype);
+int sn_weight_grads(const void* acts, const float* emb, const void* g_acts, long slot_rows, int dtype, void* workspace,
+                    float* const* grads_host_array_of_device_ptrs, int accumulate, void* stream);
+
 /* ---- backward of models/rendering.py:215-246 w.r.t. raw=[rgb,sigma]; g_rgb (n_rays,3), g_depth (n_rays),
  * g_weights (n_rays,n_samples) are upstream gradients (any may be NULL = zeros); g_raw (n_rays,n_samples,4).  */
 int sn_composite_backward(const float* raw, const float* z_vals, const float* rays, const float* noise, float noise_std,

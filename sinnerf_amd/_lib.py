@@ -43,6 +43,8 @@ SIGNATURES = {
     "sn_mlp_forward_train_embedded": (_int, [c_vp, _int, c_fp, _long, _int, c_fp, c_fp, _long, c_vp]),
     "sn_mlp_backward_chain": (_int, [c_vp, _int, c_fp, c_fp, c_fp, _long, _long, c_fp, c_fp, c_vp]),
     "sn_dw_gemm": (_int, [c_vp, _int, c_vp]),
+    "sn_weight_grads_workspace_bytes": (_long, [_long, _int]),
+    "sn_weight_grads": (_int, [c_vp, c_fp, c_vp, _long, _int, c_vp, ctypes.POINTER(c_vp), _int, c_vp]),
     "sn_generate_rays": (_int, [c_fp, _int, _int, _float, _float, _float, _int, _int, _int, _int, _int, _int, c_fp, c_vp]),
     "sn_adam_step": (_int, [c_fp, c_fp, c_fp, c_fp, _long, _float, _float, _float, _float, _float, _int, c_vp]),
     "sn_render_loss_workspace_bytes": (_long, []),

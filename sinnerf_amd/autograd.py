@@ -16,106 +16,56 @@ from . import _lib
 from .nerf import dtype_code
 
 
-_VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64), 4: (32, 256), 5: (32, 128)}
-# cost of one point of a K-range on one CU, in cycles: max(MFMA issue time of the wave block, tile bytes / ~8 B/clk of
-# per-CU streaming bandwidth) -- the narrow problems are DMA-bound, not MFMA-bound (measured: splitting by FLOPs alone left
-# the 32x128 problem streaming 168 MB through a single CU, 2.5x the kernel time of the balanced split)
-_VARIANT_COST = {0: 512, 1: 161, 2: 260, 3: 95, 4: 101, 5: 59}      # measured per-point times (tools/dw_time.py), variant 0 = 512
-# bf16-operand mode: 8x less MFMA time, every variant is bound by its per-CU DMA stream -- measured per-point times again
-_VARIANT_COST_BF16 = {0: 512, 1: 189, 2: 226, 3: 126, 4: 138, 5: 125}
-# ... and with G / the activations stored as bf16 (gather-bound inner loop, half the bytes)
-_VARIANT_COST_BF16_STATE = {0: 512, 1: 313, 2: 325, 3: 203, 4: 224, 5: 192}
-_KB = 16                      # csrc/sn_dw.hip: points per staged chunk
-_TARGET_WGS = 256             # exactly one workgroup per CU per launch
+def _state_code(model, acts):
+    """C-ABI dtype of the stored training state: fp32 MFMAs, bf16 operands on fp32 state, or bf16 operands on bf16 state."""
+    if dtype_code(model.compute_dtype) != _lib.SN_DTYPE_BF16:
+        return _lib.SN_DTYPE_F32
+    return _lib.SN_DTYPE_BF16_STATE if acts.dtype == torch.bfloat16 else _lib.SN_DTYPE_BF16
 
 
-def _dw_tasks(acts, emb, G, bf16=False):
-    """Task table of the single sn_dw_gemm launch: the 13 contractions dW = G^T X of a network, K-split over ~one workgroup
-    per CU in proportion to their cost.  Returns (rows: list of 8-int64 task records, outs: [(key, partial dW, partial db)])."""
-    import numpy as np
-    P = acts.shape[1]                                        # padded to a multiple of 16 (pad rows of G are zero)
+def _sink_of(model, raws, needs):
+    """The gradient sink of ``parallel.FlatGradBuffer`` (``param.grad`` = views of one flat buffer), if it is attached to
+    every parameter that needs a gradient: the finish kernel then accumulates straight into ``.grad`` (what autograd's
+    ``AccumulateGrad`` would do with 24 add launches per network) and backward returns no parameter gradients."""
+    sink = getattr(model, "_grad_sink", None)
+    if sink is None:
+        return None
+    for t, s_, need in zip(raws, sink, needs):
+        if need and (t.grad is None or t.grad.data_ptr() != s_.data_ptr() or t.grad.shape != t.shape):
+            return None
+    return sink
+
+
+def _weight_grads(model, acts, emb, G, needs):
+    """dW_l = g_l^T X_l, db_l = sum_p g_l over all sample points (autograd of the nn.Linear layers, nerf.py:66-103):
+    ``sn_weight_grads`` = ONE launch of the K-split MFMA kernel for the 14 contractions of the network (plan passed by
+    value, nothing built on the host) + one launch that sums the partials in a fixed order and writes the gradients in the
+    parameters' shapes.  Returns the list autograd expects (order of ``NeRF.raw_tensors()``)."""
+    import ctypes
     dev = acts.device
-    # (key, A tensor, A col, lda, B tensor, B col, ldb, variant, want_bias)
-    probs = []
-    for i in range(8):                                       # xyz_encoding_{i+1}
-        if i == 0:
-            probs.append((("w", 0), G[0], 0, 256, emb, 0, 128, 1, True))
-        else:
-            probs.append((("w", i), G[i], 0, 256, acts[i - 1], 0, 256, 0, True))
-            if i == 4:                                       # skip: cat([input_xyz, h4])  nerf.py:133
-                probs.append((("w4e", 4), G[4], 0, 256, emb, 0, 128, 1, False))
-    probs.append((("w", 8), G[8], 0, 256, acts[7], 0, 256, 0, True))          # xyz_encoding_final
-    probs.append((("w", 9), G[9], 0, 256, acts[8], 0, 256, 2, True))          # dir_encoding[:, :256]
-    probs.append((("w9e", 9), G[9], 0, 256, emb, 64, 128, 3, False))          # dir_encoding[:, 256:]
-    # rows 0..2 = g_y of rgb, row 3 = g_y of sigma (zero-padded 32-wide block at G[9][:, 128:160], sn_mlp_bwd.hip)
-    probs.append((("sig", 10), G[9], 128, 256, acts[7], 0, 256, 4, False))    # sigma  (nerf.py:136)
-    probs.append((("rgb", 11), G[9], 128, 256, acts[9], 0, 256, 5, True))     # rgb    (nerf.py:144)
-    cost = (_VARIANT_COST_BF16_STATE if G.dtype == torch.bfloat16 else _VARIANT_COST_BF16) if bf16 else _VARIANT_COST
-    # 0x100: bf16 operands; 0x200: G and the activations are STORED as bf16 (emb stays fp32)
-    state16 = G.dtype == torch.bfloat16
-    assert (not state16) or (bf16 and acts.dtype == torch.bfloat16 and emb.dtype == torch.float32)
-    flags = (0x100 if bf16 else 0) | (0x200 if state16 else 0)
-    work = [cost[p[7]] for p in probs]
-    tot = float(sum(work))
-    max_split = max(1, P // (4 * _KB))
-    # K-splits proportional to the work of a problem, summing to _TARGET_WGS (largest remainders get the slack)
-    ideal = [_TARGET_WGS * w / tot for w in work]
-    splits = [max(1, int(x)) for x in ideal]
-    for j in sorted(range(len(work)), key=lambda j: ideal[j] - int(ideal[j]), reverse=True):
-        if sum(splits) >= _TARGET_WGS:
-            break
-        splits[j] += 1
-    rows, outs = [], []
-    for pr, ns in zip(probs, splits):
-        key, A, ac, lda, B, bc, ldb, var, want_b = pr
-        M, N = _VARIANT_MN[var]
-        ns = int(min(max_split, ns))
-        per = -(-P // ns)
-        per = -(-per // _KB) * _KB
-        ns = -(-P // per)
-        cpart = torch.empty((ns, M, N), dtype=torch.float32, device=dev)
-        bpart = torch.empty((ns, M), dtype=torch.float32, device=dev) if want_b else None
-        outs.append((key, cpart, bpart))
-        a_ptr, b_ptr = A.data_ptr() + ac * A.element_size(), B.data_ptr() + bc * B.element_size()
-        for j in range(ns):
-            rows.append((a_ptr, b_ptr, cpart.data_ptr() + j * M * N * 4,
-                         (bpart.data_ptr() + j * M * 4) if want_b else 0,
-                         j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | ((var | flags) << 32)))
-    return rows, outs
-
-
-def _weight_grads(model, acts, emb, G, g_o, needs):
-    """dW_l = g_l^T X_l, db_l = sum_p g_l over all sample points (autograd of the nn.Linear layers, nerf.py:66-103).
-    All contractions run in ONE launch of the K-split MFMA kernel (sn_dw_gemm, csrc/sn_dw.hip) followed by a deterministic
-    sum of the K-split partials.  Order of the returned list = NeRF.raw_tensors()."""
-    import numpy as np
-    dev = acts.device
-    # mixed precision: bf16-operand contractions (fp32 tiles converted on the fly, fp32 accumulation and partial sums)
-    rows, outs = _dw_tasks(acts, emb, G, bf16=dtype_code(model.compute_dtype) == _lib.SN_DTYPE_BF16)
-    tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
-    _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], _lib.stream_ptr()), "sn_dw_gemm")
-    res = {k: (c.sum(0), b.sum(0) if b is not None else None) for k, c, b in outs}
-
-    grads = []
-
-    def add(gw, gb, k):
-        grads.append(gw if needs[2 * k] else None)
-        grads.append(gb if needs[2 * k + 1] else None)
-
-    for i in range(8):
-        gw, gb = res[("w", i)]
-        if i == 0:
-            gw = gw[:, :63]
-        elif i == 4:
-            gw = torch.cat([res[("w4e", 4)][0][:, :63], gw], 1)
-        add(gw.contiguous(), gb, i)
-    add(*res[("w", 8)], 8)
-    gw, gb = res[("w", 9)]
-    add(torch.cat([gw, res[("w9e", 9)][0][:, :27]], 1), gb, 9)
-    gb4 = res[("rgb", 11)][1]                                # column sums of [g_rgb(3), g_sigma(1), 0...]
-    add(res[("sig", 10)][0][3:4].contiguous(), gb4[3:4].contiguous(), 10)
-    add(res[("rgb", 11)][0][:3].contiguous(), gb4[:3].contiguous(), 11)
-    return grads
+    code = _state_code(model, acts)
+    rows = acts.shape[1]
+    nbytes = _lib.lib.sn_weight_grads_workspace_bytes(rows, code)
+    if nbytes < 0:
+        _lib.check(int(nbytes), "sn_weight_grads_workspace_bytes")
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    raws = model.raw_tensors()
+    sink = _sink_of(model, raws, needs)
+    if sink is not None:
+        outs, accumulate = [s_ if need else None for s_, need in zip(sink, needs)], 1
+    else:
+        flat = torch.empty(sum(t.numel() for t, need in zip(raws, needs) if need), dtype=torch.float32, device=dev)
+        outs, off, accumulate = [], 0, 0
+        for t, need in zip(raws, needs):
+            if need:
+                outs.append(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+            else:
+                outs.append(None)
+    arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[None if o is None else o.data_ptr() for o in outs])
+    _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(emb), _lib.ptr(G), rows, code, _lib.ptr(ws), arr, accumulate,
+                                        _lib.stream_ptr()), "sn_weight_grads")
+    return [None] * len(outs) if sink is not None else outs
 
 
 class _MLPFn(torch.autograd.Function):
@@ -179,7 +129,7 @@ class _MLPFn(torch.autograd.Function):
                                                       _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")
             needs = ctx.needs_input_grad[3:]
-            grads = _weight_grads(model, acts, emb, G, g_o, needs)
+            grads = _weight_grads(model, acts, emb, G, needs)
         return (None, None, None, *grads)
 
 

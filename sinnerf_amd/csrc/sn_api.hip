@@ -13,6 +13,9 @@ int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float* acts, cons
                                       long n_points, long slot_rows, float* G, float* g_out, int state_bf16,
                                       hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
+long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype);
+int sn_weight_grads_launch(const void* acts, const float* emb, const void* G, long slot_rows, int dtype, void* workspace,
+                           float* const* grads, int accumulate, hipStream_t stream);
 int sn_generate_rays_launch(const float* c2w, int H, int W, float focal, float near, float far, int x0, int y0, int sx,
                             int sy, int pw, int ph, float* rays, hipStream_t stream);
 int sn_adam_step_launch(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
@@ -228,6 +231,20 @@ int sn_render_loss(const float* rgb_coarse, const float* rgb_fine, const float* 
 int sn_dw_gemm(const void* tasks, int n_tasks, void* stream) {
   if (!tasks || n_tasks < 0) return SN_E_BADARG;
   return sn_dw_launch(tasks, n_tasks, (hipStream_t)stream);
+}
+
+long sn_weight_grads_workspace_bytes(long slot_rows, int dtype) {
+  if (slot_rows < 16 || slot_rows % 16 != 0) return SN_E_BADSHAPE;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
+  return sn_weight_grads_workspace_bytes_impl(slot_rows, dtype);
+}
+
+int sn_weight_grads(const void* acts, const float* emb, const void* g_acts, long slot_rows, int dtype, void* workspace,
+                    float* const* grads, int accumulate, void* stream) {
+  if (!acts || !emb || !g_acts || !workspace || !grads) return SN_E_BADARG;
+  if (slot_rows < 16 || slot_rows % 16 != 0) return SN_E_BADSHAPE;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
+  return sn_weight_grads_launch(acts, emb, g_acts, slot_rows, dtype, workspace, grads, accumulate ? 1 : 0, (hipStream_t)stream);
 }
 
 int sn_composite_backward(const float* raw, const float* z_vals, const float* rays, const float* noise, float noise_std,

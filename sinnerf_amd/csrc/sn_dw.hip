@@ -256,9 +256,41 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   }
 }
 
-__global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks) {
+// The whole network's contractions described by value (kernel arguments: no host-built table, no H2D copy, capturable in
+// a HIP graph): problem q = one dW = G^T X, split into ns K-ranges of `per` points, tasks [first, first + ns).
+struct Prob {
+  const void* a;
+  const void* b;
+  float* c;                                     // ns partial results, M*N floats apart
+  float* bias;                                  // ns partial column sums, M floats apart, or nullptr
+  int lda, ldb, ldc, variant;
+  int ns, per, first, m;
+};
+constexpr int MAX_PROBS = 14;
+struct Plan {
+  Prob p[MAX_PROBS];
+  long P;                                       // rows (points) of every operand
+  int n_probs, n_tasks;
+};
+
+__global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks, const Plan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Task t = tasks[blockIdx.x];
+  Task t;
+  if (tasks != nullptr) {
+    t = tasks[blockIdx.x];
+  } else {
+    int q = 0;
+#pragma unroll 1
+    for (int i = 1; i < plan.n_probs; ++i) q = ((int)blockIdx.x >= plan.p[i].first) ? i : q;      // scalar loads of the kernarg segment
+    const Prob& pr = plan.p[q];
+    const int j = (int)blockIdx.x - pr.first;
+    t.a = pr.a; t.b = pr.b;
+    t.c = pr.c + (long)j * pr.m * pr.ldc;
+    t.bias = pr.bias ? pr.bias + (long)j * pr.m : nullptr;
+    t.k0 = (long)j * pr.per;
+    t.k1 = t.k0 + pr.per < plan.P ? t.k0 + pr.per : plan.P;
+    t.lda = pr.lda; t.ldb = pr.ldb; t.ldc = pr.ldc; t.variant = pr.variant;
+  }
   const int tid = threadIdx.x;
   if (t.variant & 0x100) {
     const int mode = (t.variant & 0x200) ? 2 : 1;     // 0x200: G and the activations are stored as bf16
@@ -286,14 +318,184 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks)
   }
 }
 
+// ---- finish: deterministic sum of the K-split partials, written straight into the parameter-shaped gradients -------------
+struct Seg {                                    // dst[r][dst_col0 + c] (+)= sum_j src[j*stride + (src_row0 + r)*src_ld + src_col0 + c]
+  float* dst;
+  const float* src;
+  int dst_ld, dst_col0, rows, cols, src_ld, src_row0, src_col0, ns, stride, first;   // first = prefix sum of rows*cols
+};
+constexpr int MAX_SEGS = 32;
+struct Segs {
+  Seg s[MAX_SEGS];
+  int n_segs, total, accumulate, pad;
+};
+
+__global__ void __launch_bounds__(256) dw_finish_kernel(const Segs segs) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= segs.total) return;
+  int q = 0;
+#pragma unroll 1
+  for (int i = 1; i < segs.n_segs; ++i) q = (e >= segs.s[i].first) ? i : q;
+  const Seg& g = segs.s[q];
+  const int l = e - g.first;
+  const int r = l / g.cols, c = l - r * g.cols;
+  const float* src = g.src + (long)(g.src_row0 + r) * g.src_ld + g.src_col0 + c;
+  float acc = 0.0f;
+  for (int j = 0; j < g.ns; ++j) acc += src[(long)j * g.stride];       // fixed order: run-to-run deterministic
+  float* d = g.dst + (long)r * g.dst_ld + g.dst_col0 + c;
+  *d = segs.accumulate ? *d + acc : acc;
+}
+
+// ---- host: the plan of one network (the K-split cost model that used to live in sinnerf_amd/autograd.py) -------------------
+struct VariantInfo { int m, n; };
+static const VariantInfo VARIANTS[6] = {{256, 256}, {256, 64}, {128, 256}, {128, 64}, {32, 256}, {32, 128}};
+// cost of one point of a K-range on one CU (cycles, variant 0 = 512): max(MFMA issue time of the wave block, tile bytes over
+// the per-CU streaming rate) -- measured per mode (tools/dw_time.py): the narrow problems are DMA-bound, and splitting by
+// FLOPs alone left the 32x128 problem streaming 168 MB through a single CU
+static const int COST_F32[6] = {512, 161, 260, 95, 101, 59};
+static const int COST_BF16[6] = {512, 189, 226, 126, 138, 125};          // bf16 operands, fp32 state
+static const int COST_BF16_STATE[6] = {512, 313, 325, 203, 224, 192};    // bf16 operands, bf16 state (gather-bound inner loop)
+constexpr int TARGET_WGS = 256;                 // one workgroup per CU
+
+struct HostPlan {
+  Plan plan;
+  long c_off[MAX_PROBS], b_off[MAX_PROBS];      // workspace byte offsets of the partial buffers (b_off < 0: no bias)
+  long bytes;
+};
+// problems in the order build_plan emits them
+enum { W0 = 0, W1 = 1, W2 = 2, W3 = 3, W4 = 4, W4E = 5, W5 = 6, W6 = 7, W7 = 8, WF = 9, WD = 10, WDE = 11, SIG = 12, RGB = 13 };
+
+// dtype: 0 fp32, 1 bf16 operands / fp32 state, 2 bf16 operands / bf16 state.  Pointers may be null (size query).
+static void build_plan(HostPlan& hp, const char* acts, const char* emb, const char* G, long rows, int dtype) {
+  const long es = dtype == 2 ? 2 : 4;           // element size of acts / G (emb is always fp32)
+  const long slot = rows * 256 * es;
+  const int flags = (dtype >= 1 ? 0x100 : 0) | (dtype == 2 ? 0x200 : 0);
+  const int* cost = dtype == 0 ? COST_F32 : dtype == 1 ? COST_BF16 : COST_BF16_STATE;
+  struct P { const char* a; const char* b; int lda, ldb, var; bool bias; };
+  P pr[MAX_PROBS];
+  int n = 0;
+  auto Gs = [&](int i, int col) { return G + i * slot + col * es; };
+  auto As = [&](int i) { return acts + i * slot; };
+  for (int i = 0; i < 8; ++i) {                                   // xyz_encoding_{i+1}
+    if (i == 0) pr[n++] = {Gs(0, 0), emb, 256, 128, 1, true};
+    else {
+      pr[n++] = {Gs(i, 0), As(i - 1), 256, 256, 0, true};
+      if (i == 4) pr[n++] = {Gs(4, 0), emb, 256, 128, 1, false};  // skip: cat([input_xyz, h4])  nerf.py:133
+    }
+  }
+  pr[n++] = {Gs(8, 0), As(7), 256, 256, 0, true};                 // xyz_encoding_final
+  pr[n++] = {Gs(9, 0), As(8), 256, 256, 2, true};                 // dir_encoding[:, :256]
+  pr[n++] = {Gs(9, 0), emb + 64 * 4, 256, 128, 3, false};         // dir_encoding[:, 256:]
+  pr[n++] = {Gs(9, 128), As(7), 256, 256, 4, false};              // sigma (nerf.py:136): row 3 of the 32-wide head block
+  pr[n++] = {Gs(9, 128), As(9), 256, 256, 5, true};               // rgb (nerf.py:144): rows 0..2; bias = [g_rgb(3), g_sigma(1)]
+  double tot = 0;
+  for (int i = 0; i < n; ++i) tot += cost[pr[i].var];
+  int splits[MAX_PROBS];
+  double frac[MAX_PROBS];
+  int sum = 0;
+  for (int i = 0; i < n; ++i) {
+    const double ideal = TARGET_WGS * cost[pr[i].var] / tot;
+    splits[i] = (int)ideal < 1 ? 1 : (int)ideal;
+    frac[i] = ideal - (int)ideal;
+    sum += splits[i];
+  }
+  bool used[MAX_PROBS] = {};
+  while (sum < TARGET_WGS) {                                      // largest remainders get the slack
+    int best = -1;
+    for (int i = 0; i < n; ++i) if (!used[i] && (best < 0 || frac[i] > frac[best])) best = i;
+    if (best < 0) break;
+    used[best] = true; ++splits[best]; ++sum;
+  }
+  const long max_split = rows / (4 * KB) < 1 ? 1 : rows / (4 * KB);
+  long off = 0;
+  int first = 0;
+  hp.plan.P = rows;
+  hp.plan.n_probs = n;
+  for (int i = 0; i < n; ++i) {
+    long ns = splits[i] < max_split ? splits[i] : max_split;
+    long per = (rows + ns - 1) / ns;
+    per = (per + KB - 1) / KB * KB;
+    ns = (rows + per - 1) / per;
+    const VariantInfo v = VARIANTS[pr[i].var];
+    Prob& q = hp.plan.p[i];
+    q.a = pr[i].a; q.b = pr[i].b; q.c = nullptr; q.bias = nullptr;
+    q.lda = pr[i].lda; q.ldb = pr[i].ldb; q.ldc = v.n; q.variant = pr[i].var | flags;
+    q.ns = (int)ns; q.per = (int)per; q.first = first; q.m = v.m;
+    first += (int)ns;
+    hp.c_off[i] = off; off += ns * v.m * v.n * 4;
+    hp.b_off[i] = pr[i].bias ? off : -1;
+    if (pr[i].bias) off += ns * v.m * 4;
+  }
+  hp.plan.n_tasks = first;
+  hp.bytes = (off + 255) / 256 * 256;
+}
+
 }  // namespace snd
+
+extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype) {
+  snd::HostPlan hp;
+  snd::build_plan(hp, nullptr, nullptr, nullptr, slot_rows, dtype);
+  return hp.bytes;
+}
+
+extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const void* G, long slot_rows, int dtype,
+                                      void* workspace, float* const* grads, int accumulate, hipStream_t stream) {
+  using namespace snd;
+  HostPlan hp;
+  build_plan(hp, (const char*)acts, (const char*)emb, (const char*)G, slot_rows, dtype);
+  char* ws = (char*)workspace;
+  for (int i = 0; i < hp.plan.n_probs; ++i) {
+    hp.plan.p[i].c = (float*)(ws + hp.c_off[i]);
+    hp.plan.p[i].bias = hp.b_off[i] >= 0 ? (float*)(ws + hp.b_off[i]) : nullptr;
+  }
+  SN_ENSURE_DYN_LDS(dw_kernel, DW_LDS_BYTES);
+  hipLaunchKernelGGL(dw_kernel, dim3((unsigned)hp.plan.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, hp.plan);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  Segs sg;
+  int n = 0, total = 0;
+  auto seg = [&](float* dst, int dst_ld, int dst_col0, int rows, int cols, int prob, bool from_bias, int src_row0, int src_col0) {
+    if (dst == nullptr) return;
+    const Prob& q = hp.plan.p[prob];
+    Seg& g = sg.s[n++];
+    g.dst = dst; g.dst_ld = dst_ld; g.dst_col0 = dst_col0; g.rows = rows; g.cols = cols;
+    g.src = from_bias ? q.bias : q.c;
+    g.src_ld = from_bias ? 1 : q.ldc; g.src_row0 = src_row0; g.src_col0 = src_col0;
+    g.ns = q.ns; g.stride = from_bias ? q.m : q.m * q.ldc;
+    g.first = total; total += rows * cols;
+  };
+  const int wl[8] = {W0, W1, W2, W3, W4, W5, W6, W7};
+  for (int i = 0; i < 8; ++i) {
+    if (i == 0) seg(grads[0], 63, 0, 256, 63, W0, false, 0, 0);
+    else if (i == 4) {
+      seg(grads[8], 319, 0, 256, 63, W4E, false, 0, 0);            // cat([input_xyz, h4]): embedded columns first
+      seg(grads[8], 319, 63, 256, 256, W4, false, 0, 0);
+    } else seg(grads[2 * i], 256, 0, 256, 256, wl[i], false, 0, 0);
+    seg(grads[2 * i + 1], 1, 0, 256, 1, wl[i], true, 0, 0);
+  }
+  seg(grads[16], 256, 0, 256, 256, WF, false, 0, 0);
+  seg(grads[17], 1, 0, 256, 1, WF, true, 0, 0);
+  seg(grads[18], 283, 0, 128, 256, WD, false, 0, 0);
+  seg(grads[18], 283, 256, 128, 27, WDE, false, 0, 0);
+  seg(grads[19], 1, 0, 128, 1, WD, true, 0, 0);
+  seg(grads[20], 256, 0, 1, 256, SIG, false, 3, 0);                // sigma.weight (1, 256) = row 3 of the head block
+  seg(grads[21], 1, 0, 1, 1, RGB, true, 3, 0);                     // sigma.bias = column sum of g_sigma
+  seg(grads[22], 128, 0, 3, 128, RGB, false, 0, 0);                // rgb.weight (3, 128)
+  seg(grads[23], 1, 0, 3, 1, RGB, true, 0, 0);
+  if (n == 0) return 0;
+  sg.n_segs = n; sg.total = total; sg.accumulate = accumulate; sg.pad = 0;
+  hipLaunchKernelGGL(dw_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, sg);
+  return (int)hipGetLastError();
+}
 
 extern "C" int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream) {
   using namespace snd;
   if (n_tasks <= 0) return 0;
   static_assert(sizeof(Task) == 64, "Task must be 64 bytes (host packs it as 8 x int64)");
   SN_ENSURE_DYN_LDS(dw_kernel, DW_LDS_BYTES);
+  Plan none;
+  none.n_probs = 0; none.n_tasks = 0; none.P = 0;
   hipLaunchKernelGGL(dw_kernel, dim3((unsigned)n_tasks), dim3(256), DW_LDS_BYTES, stream,
-                     reinterpret_cast<const Task*>(tasks));
+                     reinterpret_cast<const Task*>(tasks), none);
   return (int)hipGetLastError();
 }

@@ -87,6 +87,38 @@ SN_DEV void mma_v(f32x16& acc, const u32x4& a, const u32x4& b) {
 }
 // MFMA (8 passes) -> VALU read of its result: the wait states the compiler would insert for a builtin MFMA
 SN_DEV void mfma_result_fence() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }
+// ShiftedSoftplus (activations.py:33-35) of four dir_encoding outputs + their contribution to the rgb head, on PACKED fp32
+// VALU ops: v = max(x-1, 0) + ln2 * log2(1 + exp2(-|x-1| * log2 e)) (log(1+e) taken directly: its 2^-24 absolute error is far
+// below the bf16 rounding of the layer's inputs), rgb sums kept as (even, odd) pairs.  26 instructions per four values
+// instead of 40 (v_pk_add / v_pk_mul / v_pk_fma; exp, log and max stay scalar) -- this section is pure VALU time between the
+// MFMA phases of the kernel.  The values v are bit-identical with the scalar form; only the rgb sums associate as pairs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+SN_DEV void ssp4_rgb(const float (&x)[4], const f32x4 (&w)[3], f32x2 (&c)[3], float (&v)[4]) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    f32x2 sx = {x[2 * p], x[2 * p + 1]};
+    sx = sx - 1.0f;
+    const f32x2 t = sx * 1.44269504088896340736f;
+    f32x2 e, l, m;
+    e.x = __builtin_amdgcn_exp2f(-__builtin_fabsf(t.x));
+    e.y = __builtin_amdgcn_exp2f(-__builtin_fabsf(t.y));
+    const f32x2 u = e + 1.0f;
+    l.x = __builtin_amdgcn_logf(u.x);
+    l.y = __builtin_amdgcn_logf(u.y);
+    m.x = __builtin_fmaxf(sx.x, 0.0f);
+    m.y = __builtin_fmaxf(sx.y, 0.0f);
+    const f32x2 ln2 = {0.69314718055994530942f, 0.69314718055994530942f};
+    const f32x2 vv = __builtin_elementwise_fma(l, ln2, m);
+    v[2 * p] = vv.x;
+    v[2 * p + 1] = vv.y;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f32x2 wk = {w[k][2 * p], w[k][2 * p + 1]};
+      c[k] = __builtin_elementwise_fma(wk, vv, c[k]);
+    }
+  }
+}
+SN_DEV float hsum(f32x2 a) { return a.x + a.y; }
 constexpr int act_reg(int set, int kstep, int pt) { return set * 128 + (kstep * PT + pt) * 4; }
 
 // One slab: NK0 + NK1 k-steps (two K segments), barrier after k-step GB.

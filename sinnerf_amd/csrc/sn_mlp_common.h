@@ -86,4 +86,50 @@ SN_DEV void embed_dir(float x, float y, float z, int h, float* de) {
   de[15] = 0.0f;
 }
 
+
+// bf16-operand kernels: the embedding is rounded to bf16 (8 mantissa bits) before any use, so only the LOWEST band of each
+// lane half needs the exact range reduction; the higher bands follow by angle doubling (sin 2a = 2 s c, cos 2a = 1 - 2 s^2):
+// 3 instructions per band instead of ~28.  The absolute error grows 2-4x per step (the error in s^2 + c^2 = 1 is amplified
+// too): 4 doublings of a ~2e-7 start stay below 1.5e-5 (fp32 emulation over 2e5 arguments), two orders of magnitude inside
+// half a bf16 ulp (2e-3 relative) -- a top-band value flips its bf16 rounding less than once in a hundred, lower bands
+// correspondingly less, comparable with what the fp32 accumulation order already does.  The fp32 kernels keep the exact path.
+SN_DEV void sincos_double(float s, float c, float& s2, float& c2) {
+  const float ts = s + s;
+  s2 = ts * c;
+  c2 = __builtin_fmaf(-ts, s, 1.0f);
+}
+SN_DEV void embed_xyz_dbl(float x, float y, float z, int h, float* xe) {
+  const Rev2 px = to_revolutions(x), py = to_revolutions(y), pz = to_revolutions(z);
+  const float hs = h ? 32.0f : 1.0f;            // bands 5..9 on the upper lane half
+  sincos_rev(px, hs, xe[0], xe[1]);
+  sincos_rev(py, hs, xe[2], xe[3]);
+  sincos_rev(pz, hs, xe[4], xe[5]);
+#pragma unroll
+  for (int p = 3; p < 15; ++p) sincos_double(xe[2 * (p - 3)], xe[2 * (p - 3) + 1], xe[2 * p], xe[2 * p + 1]);
+  xe[30] = h ? z : x;
+  xe[31] = h ? 0.0f : y;
+}
+SN_DEV void embed_dir_dbl(float x, float y, float z, int h, float* de) {
+  const Rev2 px = to_revolutions(x), py = to_revolutions(y), pz = to_revolutions(z);
+  const float hs = h ? 4.0f : 1.0f;             // bands 2,3 on the upper lane half
+  sincos_rev(px, hs, de[0], de[1]);
+  sincos_rev(py, hs, de[2], de[3]);
+  sincos_rev(pz, hs, de[4], de[5]);
+#pragma unroll
+  for (int p = 3; p < 6; ++p) sincos_double(de[2 * (p - 3)], de[2 * (p - 3) + 1], de[2 * p], de[2 * p + 1]);
+  de[12] = h ? z : x;
+  de[13] = h ? 0.0f : y;
+  de[14] = 0.0f;
+  de[15] = 0.0f;
+}
+#ifndef SN_EMBED_DBL
+#define SN_EMBED_DBL 1
+#endif
+SN_DEV void embed_xyz_bf16(float x, float y, float z, int h, float* xe) {
+  if (SN_EMBED_DBL) embed_xyz_dbl(x, y, z, h, xe); else embed_xyz(x, y, z, h, xe);
+}
+SN_DEV void embed_dir_bf16(float x, float y, float z, int h, float* de) {
+  if (SN_EMBED_DBL) embed_dir_dbl(x, y, z, h, de); else embed_dir(x, y, z, h, de);
+}
+
 }  // namespace snk

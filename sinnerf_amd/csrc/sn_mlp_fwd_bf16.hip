@@ -121,7 +121,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         const float x = __fadd_rn(rp[0], __fmul_rn(rp[3], zz));
         const float y = __fadd_rn(rp[1], __fmul_rn(rp[4], zz));
         const float z = __fadd_rn(rp[2], __fmul_rn(rp[5], zz));
-        embed_xyz(x, y, z, ht, f);
+        embed_xyz_bf16(x, y, z, ht, f);
       } else {
         const float* row = in0 + p[pt] * (long)S;
         int hh = h;
@@ -336,7 +336,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       float f[16];
       if (INPUT_MODE == 0) {
         const float* rp = in0 + (p[pt] / S) * 8;
-        embed_dir(rp[3], rp[4], rp[5], ht, f);
+        embed_dir_bf16(rp[3], rp[4], rp[5], ht, f);
       } else {
         const float* row = in0 + p[pt] * (long)S;
         int hh = h;
@@ -363,12 +363,10 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       asm volatile("" : "+v"(de[0 * PT + pt]), "+v"(de[1 * PT + pt]));
       __builtin_amdgcn_sched_barrier(0);
     }
-    float c3[PT][3];
+    f32x2 c3[PT][3];                                            // rgb head partial sums, (even, odd) pairs: ssp4_rgb
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) c3[pt][0] = c3[pt][1] = c3[pt][2] = 0.0f;
-    // ShiftedSoftplus (activations.py:33-35) = max(x-1,0) + log1p(exp(-|x-1|)) on hardware exp2/log2.  log(1+e) is taken
-    // directly: its absolute error (2^-24, the bits 1+e drops) is far below the bf16 rounding of the layer's inputs, so
-    // the relative-accuracy correction of the fp32 kernel is not spent here.  Four values at a time (register pressure).
+    for (int pt = 0; pt < PT; ++pt) c3[pt][0] = c3[pt][1] = c3[pt][2] = f32x2{0.0f, 0.0f};
+    // ShiftedSoftplus + rgb head contribution: ssp4_rgb (sn_mlp_bf16.h), four values at a time (register pressure).
     auto ssp_tile = [&](auto, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -384,14 +382,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           // the chunk's inputs and the running sums pass through one volatile asm: chunks execute strictly in order
           asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(c3[pt][0]), "+v"(c3[pt][1]), "+v"(c3[pt][2]));
           float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float sx = x[i] - 1.0f;
-            const float e = __builtin_amdgcn_exp2f(-fabsf(sx) * 1.44269504088896340736f);
-            v[i] = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), 0.69314718055994530942f, fmaxf(sx, 0.0f));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) c3[pt][c] = __builtin_fmaf(w[c][i], v[i], c3[pt][c]);
-          }
+          ssp4_rgb(x, w, c3[pt], v);
           stage(pt, q, v);
           if (STORE == 2) stage16(pt, q, pack2(v[0], v[1]), pack2(v[2], v[3]));
         }
@@ -412,7 +403,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       float o3[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        o3[c] = widened_sigmoid(c3[pt][c] + __shfl_xor(c3[pt][c], 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c]);
+        o3[c] = widened_sigmoid(hsum(c3[pt][c]) + __shfl_xor(hsum(c3[pt][c]), 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c]);
       if (valid[pt] && h == 0) {
         float4 o;
         o.x = o3[0]; o.y = o3[1]; o.z = o3[2]; o.w = sigma[pt];

@@ -51,7 +51,8 @@ def gather_rows(local, n_total, dst=0):
 class FlatGradBuffer:
     """One flat fp32 gradient buffer for a list of modules; ``param.grad`` are views into it."""
 
-    def __init__(self, modules):
+    def __init__(self, modules, sink=True):
+        modules = list(modules)
         self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -63,6 +64,15 @@ class FlatGradBuffer:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        # Gradient sink: the weight-gradient finish kernel of a NeRF whose parameters all live here accumulates straight into
+        # these views (sn_weight_grads(accumulate=1), sinnerf_amd/autograd.py) instead of returning 24 tensors per network
+        # for autograd's AccumulateGrad to add one launch at a time.  Per-parameter autograd hooks do not fire in that mode
+        # (this class replaces DDP's hook-driven bucketing by one explicit all-reduce, so none are needed); it is taken only
+        # while every .grad still IS its view (sinnerf_amd.autograd._sink_of).
+        if sink:
+            for m in modules:
+                if hasattr(m, "raw_tensors") and all(t.requires_grad for t in m.raw_tensors()):
+                    m._grad_sink = [t.grad for t in m.raw_tensors()]
 
     def zero(self):
         """Replaces ``optimizer.zero_grad()``: one memset, views stay attached."""

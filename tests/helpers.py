@@ -80,3 +80,76 @@ def sample_pdf_tol(bins, weights, u, eps=1e-5, cdf_noise=4e-7, floor=2e-6):
     denom = np.take_along_axis(cdf, above, 1) - np.take_along_axis(cdf, below, 1)
     width = np.take_along_axis(bins.astype(np.float64), above, 1) - np.take_along_axis(bins.astype(np.float64), below, 1)
     return floor + cdf_noise / np.maximum(denom, eps) * np.abs(width)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# raw sn_dw_gemm task tables (test / tool infrastructure)
+_VARIANT_MN = {0: (256, 256), 1: (256, 64), 2: (128, 256), 3: (128, 64), 4: (32, 256), 5: (32, 128)}
+# cost of one point of a K-range on one CU, in cycles: max(MFMA issue time of the wave block, tile bytes / ~8 B/clk of
+# per-CU streaming bandwidth) -- the narrow problems are DMA-bound, not MFMA-bound (measured: splitting by FLOPs alone left
+# the 32x128 problem streaming 168 MB through a single CU, 2.5x the kernel time of the balanced split)
+_VARIANT_COST = {0: 512, 1: 161, 2: 260, 3: 95, 4: 101, 5: 59}      # measured per-point times (tools/dw_time.py), variant 0 = 512
+# bf16-operand mode: 8x less MFMA time, every variant is bound by its per-CU DMA stream -- measured per-point times again
+_VARIANT_COST_BF16 = {0: 512, 1: 189, 2: 226, 3: 126, 4: 138, 5: 125}
+# ... and with G / the activations stored as bf16 (gather-bound inner loop, half the bytes)
+_VARIANT_COST_BF16_STATE = {0: 512, 1: 313, 2: 325, 3: 203, 4: 224, 5: 192}
+_KB = 16                      # csrc/sn_dw.hip: points per staged chunk
+_TARGET_WGS = 256             # exactly one workgroup per CU per launch
+
+
+def dw_tasks(acts, emb, G, bf16=False):
+    """Host-built task table for the raw ``sn_dw_gemm`` entry (the low-level ABI the weight-gradient tests and tools/dw_time.py
+    exercise; the product path uses ``sn_weight_grads``, whose plan is built inside the library): the 14 contractions
+    dW = G^T X of a network, K-split over ~one workgroup per CU in proportion to their cost.
+    Returns (rows: list of 8-int64 task records, outs: [(key, partial dW, partial db)])."""
+    import numpy as np
+    import torch
+    P = acts.shape[1]                                        # padded to a multiple of 16 (pad rows of G are zero)
+    dev = acts.device
+    # (key, A tensor, A col, lda, B tensor, B col, ldb, variant, want_bias)
+    probs = []
+    for i in range(8):                                       # xyz_encoding_{i+1}
+        if i == 0:
+            probs.append((("w", 0), G[0], 0, 256, emb, 0, 128, 1, True))
+        else:
+            probs.append((("w", i), G[i], 0, 256, acts[i - 1], 0, 256, 0, True))
+            if i == 4:                                       # skip: cat([input_xyz, h4])  nerf.py:133
+                probs.append((("w4e", 4), G[4], 0, 256, emb, 0, 128, 1, False))
+    probs.append((("w", 8), G[8], 0, 256, acts[7], 0, 256, 0, True))          # xyz_encoding_final
+    probs.append((("w", 9), G[9], 0, 256, acts[8], 0, 256, 2, True))          # dir_encoding[:, :256]
+    probs.append((("w9e", 9), G[9], 0, 256, emb, 64, 128, 3, False))          # dir_encoding[:, 256:]
+    # rows 0..2 = g_y of rgb, row 3 = g_y of sigma (zero-padded 32-wide block at G[9][:, 128:160], sn_mlp_bwd.hip)
+    probs.append((("sig", 10), G[9], 128, 256, acts[7], 0, 256, 4, False))    # sigma  (nerf.py:136)
+    probs.append((("rgb", 11), G[9], 128, 256, acts[9], 0, 256, 5, True))     # rgb    (nerf.py:144)
+    cost = (_VARIANT_COST_BF16_STATE if G.dtype == torch.bfloat16 else _VARIANT_COST_BF16) if bf16 else _VARIANT_COST
+    # 0x100: bf16 operands; 0x200: G and the activations are STORED as bf16 (emb stays fp32)
+    state16 = G.dtype == torch.bfloat16
+    assert (not state16) or (bf16 and acts.dtype == torch.bfloat16 and emb.dtype == torch.float32)
+    flags = (0x100 if bf16 else 0) | (0x200 if state16 else 0)
+    work = [cost[p[7]] for p in probs]
+    tot = float(sum(work))
+    max_split = max(1, P // (4 * _KB))
+    # K-splits proportional to the work of a problem, summing to _TARGET_WGS (largest remainders get the slack)
+    ideal = [_TARGET_WGS * w / tot for w in work]
+    splits = [max(1, int(x)) for x in ideal]
+    for j in sorted(range(len(work)), key=lambda j: ideal[j] - int(ideal[j]), reverse=True):
+        if sum(splits) >= _TARGET_WGS:
+            break
+        splits[j] += 1
+    rows, outs = [], []
+    for pr, ns in zip(probs, splits):
+        key, A, ac, lda, B, bc, ldb, var, want_b = pr
+        M, N = _VARIANT_MN[var]
+        ns = int(min(max_split, ns))
+        per = -(-P // ns)
+        per = -(-per // _KB) * _KB
+        ns = -(-P // per)
+        cpart = torch.empty((ns, M, N), dtype=torch.float32, device=dev)
+        bpart = torch.empty((ns, M), dtype=torch.float32, device=dev) if want_b else None
+        outs.append((key, cpart, bpart))
+        a_ptr, b_ptr = A.data_ptr() + ac * A.element_size(), B.data_ptr() + bc * B.element_size()
+        for j in range(ns):
+            rows.append((a_ptr, b_ptr, cpart.data_ptr() + j * M * N * 4,
+                         (bpart.data_ptr() + j * M * 4) if want_b else 0,
+                         j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | ((var | flags) << 32)))
+    return rows, outs

@@ -313,7 +313,9 @@ def test_bf16_backward_chain_close_to_fp32_chain():
     for slot in range(10):
         w = 128 if slot == 9 else 256
         assert np.linalg.norm(a32[slot, :, :w] - a16[slot, :, :w]) / np.linalg.norm(a32[slot, :, :w]) < 2e-2, slot
-    assert np.abs(emb16.cpu().numpy()[:P] - emb.cpu().numpy()[:P]).max() <= 1e-6
+    # the bf16 kernels build the higher frequency bands by angle doubling (csrc/sn_mlp_common.h: <= 1.5e-5 absolute, far
+    # inside half a bf16 ulp); the fp32 kernels keep the exact range reduction
+    assert np.abs(emb16.cpu().numpy()[:P] - emb.cpu().numpy()[:P]).max() <= 2e-5
     # reference for the bf16-state chain: the fp32-state bf16 chain on the SAME activations held in fp32 (a different
     # forward has different ReLU masks near zero, which is not what is being tested here)
     Gr = torch.full((10, rows, 256), float("nan"), device=d); Gr[:, P:] = 0
@@ -342,14 +344,15 @@ def test_bf16_weight_gradient_launch_close_to_fp32():
     """sn_dw_gemm with bf16 operands (variant | 0x100) against the fp32 launch on the same random matrices, every problem
     of a network including the narrow rgb / sigma ones: relative Frobenius error < 5e-3 (bf16 rounding of the operands,
     fp32 accumulation), bias gradients (fp32 column sums in both) within 1e-5."""
-    from sinnerf_amd import _lib, autograd as A
+    from sinnerf_amd import _lib
+    from tests.helpers import dw_tasks
     d = dev()
     P = 4096
     torch.manual_seed(0)
     acts = torch.randn((10, P, 256), device=d); G = torch.randn((10, P, 256), device=d); emb = torch.randn((P, 128), device=d)
     res = {}
     for bf in (False, True):
-        rows, outs = A._dw_tasks(acts, emb, G, bf16=bf)
+        rows, outs = dw_tasks(acts, emb, G, bf16=bf)
         tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(d)
         _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], None), "dw")
         torch.cuda.synchronize()
@@ -365,7 +368,8 @@ def test_bf16_weight_gradient_launch_close_to_fp32():
 def test_weight_gradient_launch_from_bf16_stored_state():
     """sn_dw_gemm reading G and the activations stored as bf16 (variant | 0x300) = the bf16-operand launch on the same
     values held in fp32: identical operands, so the results agree to fp32 summation noise."""
-    from sinnerf_amd import _lib, autograd as A
+    from sinnerf_amd import _lib
+    from tests.helpers import dw_tasks
     d = dev()
     P = 4096
     torch.manual_seed(1)
@@ -373,7 +377,7 @@ def test_weight_gradient_launch_from_bf16_stored_state():
     emb = torch.randn((P, 128), device=d)
     res = {}
     for name, (a, g) in (("fp32-held", (acts16.float(), G16.float())), ("bf16-held", (acts16, G16))):
-        rows, outs = A._dw_tasks(a, emb, g, bf16=True)
+        rows, outs = dw_tasks(a, emb, g, bf16=True)
         tasks = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(d)
         _lib.check(_lib.lib.sn_dw_gemm(_lib.ptr(tasks), tasks.shape[0], None), "dw")
         torch.cuda.synchronize()

@@ -142,3 +142,99 @@ def test_losses_empty_batch_and_device_guard():
     assert torch.isnan(total)                                  # the reference's mean over an empty batch: NaN, no raise
     a, b = torch.rand((100, 3), device=dev()), torch.rand((100, 3), device=dev())
     assert abs(float(psnr(a, b)) - O.psnr(a.cpu().numpy(), b.cpu().numpy())) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------- fused weight-gradient entry
+_RAW_SHAPES = [(256, 63), (256,)] + [(256, 256), (256,)] * 3 + [(256, 319), (256,)] + [(256, 256), (256,)] * 3 + \
+              [(256, 256), (256,), (128, 283), (128,), (1, 256), (1,), (3, 128), (3,)]
+
+
+def _weight_grads_reference(acts, emb, G):
+    """fp64 contractions dW = G^T X / db = sum G in the parameters' shapes (autograd of models/nerf.py:66-103)."""
+    A, E, Gd = acts.double(), emb.double(), G.double()
+    out = []
+    for i in range(8):
+        x = E[:, :63] if i == 0 else A[i - 1]
+        if i == 4:
+            x = torch.cat([E[:, :63], A[3]], 1)                               # nerf.py:133
+        out += [Gd[i].T @ x, Gd[i].sum(0)]
+    out += [Gd[8].T @ A[7], Gd[8].sum(0)]
+    gd = Gd[9][:, :128]
+    out += [gd.T @ torch.cat([A[8], E[:, 64:91]], 1), gd.sum(0)]              # nerf.py:142
+    gh = Gd[9][:, 128:132]                                                    # [g_rgb(3), g_sigma(1)]
+    out += [gh[:, 3:4].T @ A[7], gh[:, 3:4].sum(0), gh[:, :3].T @ A[9][:, :128], gh[:, :3].sum(0)]
+    return out
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16_state"])
+def test_weight_grads_entry_vs_fp64_contractions(mode):
+    """sn_weight_grads (plan by value + K-split MFMA launch + one finish launch) against fp64 matmuls of the operands the
+    kernel consumes (bf16 modes: rounded to bf16 first), every parameter of a network in its own shape; accumulate=1 adds."""
+    import ctypes
+    from sinnerf_amd import _lib
+    d = dev()
+    rows = 4096 + 48                                                          # not a multiple of the K-split size
+    torch.manual_seed(3)
+    acts = torch.randn((10, rows, 256), device=d); G = torch.randn((10, rows, 256), device=d) * 0.1
+    emb = torch.randn((rows, 128), device=d)
+    acts[9, :, 128:] = 0
+    G[9, :, 132:160] = 0                                                      # the head block carries 4 live columns (sn_mlp_bwd.hip)
+    code = {"fp32": 0, "bf16": 1, "bf16_state": 2}[mode]
+    if mode == "bf16_state":
+        acts, G = acts.bfloat16(), G.bfloat16()
+    rnd = (lambda t: t) if mode == "fp32" else (lambda t: t.bfloat16().float())
+    ref = _weight_grads_reference(rnd(acts.float()), rnd(emb), rnd(G.float()))
+    # bias gradients are fp32 column sums of the STORED values in every mode
+    refb = _weight_grads_reference(acts.float(), emb, G.float())
+    nbytes = _lib.lib.sn_weight_grads_workspace_bytes(rows, code)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+    outs = [torch.full(s, float("nan"), device=d) for s in _RAW_SHAPES]
+    arr = (ctypes.c_void_p * 24)(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(emb), _lib.ptr(G), rows, code, _lib.ptr(ws), arr, 0, None), "wg")
+    torch.cuda.synchronize()
+    first = [o.clone() for o in outs]
+    for i, (o, r, rb) in enumerate(zip(outs, ref, refb)):
+        want = (rb if i % 2 else r).reshape(o.shape)
+        assert torch.isfinite(o).all(), i
+        err = ((o.double() - want).norm() / want.norm()).item()
+        assert err < (2e-6 if mode == "fp32" or i % 2 else 2e-5), (mode, i, err)
+    _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(emb), _lib.ptr(G), rows, code, _lib.ptr(ws), arr, 1, None), "wg")
+    torch.cuda.synchronize()
+    for i, (o, f) in enumerate(zip(outs, first)):
+        assert torch.equal(o, f + f), i                                       # deterministic partial sums, accumulated once
+    # NULL entries are skipped
+    arr2 = (ctypes.c_void_p * 24)(*[None if i % 3 else o.data_ptr() for i, o in enumerate(outs)])
+    _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(emb), _lib.ptr(G), rows, code, _lib.ptr(ws), arr2, 0, None), "wg")
+    torch.cuda.synchronize()
+    for i, (o, f) in enumerate(zip(outs, first)):
+        assert torch.equal(o, f + f if i % 3 else f), i
+    assert _lib.lib.sn_weight_grads_workspace_bytes(100, code) == -5          # SN_E_BADSHAPE
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gradient_sink_equals_autograd_accumulation(dtype):
+    """FlatGradBuffer's sink (finish kernel accumulates into the flat buffer, backward returns no parameter gradients)
+    against the plain autograd route (24 tensors per network returned, AccumulateGrad adds them): same gradients, also when
+    two backward passes accumulate."""
+    from sinnerf_amd.system import SinNeRFSystem
+    d = dev()
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::311][:384]).to(d)
+    rgbs = torch.rand((rays.shape[0], 3), device=d)
+    flats = {}
+    for sink in (True, False):
+        torch.manual_seed(0)
+        sysm = SinNeRFSystem(N_importance=64, perturb=1.0, noise_std=1.0, compute_dtype=dtype).to(d)
+        sysm.configure_optimizers()
+        if not sink:
+            for m in sysm.models:
+                del m._grad_sink
+        sysm.optimizer.zero_grad()
+        for rep in range(2):
+            torch.manual_seed(10 + rep)
+            sysm.training_step({"rays": rays, "rgbs": rgbs})["loss"].backward()
+        assert sysm._flat.sync_views() == 0                                   # the views stayed attached in both modes
+        flats[sink] = sysm._flat.flat.clone()
+    assert torch.isfinite(flats[True]).all() and flats[True].abs().max() > 0
+    err = (flats[True] - flats[False]).norm() / flats[False].norm()
+    assert err < 1e-6, err

@@ -27,7 +27,7 @@ Register plan inside the statement (physical registers, all declared as clobbers
   v[192:207]  bias of the slab in flight (C operand of k-step 0)
   v[208:235]  A-fragment ring (prefetch + 2 entries x 4, at most 7)
   v[236:237]  LDS addresses of ring slots 3..5 and 6 (16-bit ds_read offsets reach three 20 KB slots)
-  v[240:247]  epilogue temporaries
+  v[240:247]  epilogue temporaries (tmp_pairs of them in rotation)
   v[248:255]  sigma-head weights of the layer-8 epilogue (2 x 4, double-buffered)
   a[0:127], a[128:255]  the two activation sets (as before)
 
@@ -43,7 +43,9 @@ KNOBS = dict(prefetch=4,        # A-fragment prefetch distance in k-steps (ring 
              bar_gap=3,         # the barrier sits after this MFMA of a slab
              setprio=0,
              dma_exec=0,        # experiment: 1 = every DMA runs with EXEC = %[em] (a mask the kernel supplies), WRONG results
-             dma_thin=1)        # experiment: issue only every dma_thin-th piece (WRONG results)
+             dma_thin=1,        # experiment: issue only every dma_thin-th piece (WRONG results)
+             tmp_pairs=2)       # epilogue temporaries: pairs of v[240:247] used in rotation (2 = v[240:243]; the registers a
+                                # shorter rotation does not name go back to the compiler, see the clobber list)
 
 V_FIRST = 128                                  # first physical VGPR the statement owns (clobbers v[V_FIRST:255])
 ACC = lambda st, pt: 128 + st * 32 + pt * 16   # v[128:191]
@@ -287,7 +289,7 @@ def gen(knobs):
         for i in range(4):
             for pt in range(2):
                 a = ACC(st, pt) + 4 * i
-                t0, t1 = TMP0 + 2 * ((2 * i + pt) % 4), TMP0 + 2 * ((2 * i + pt) % 4) + 1
+                t0, t1 = TMP0 + 2 * ((2 * i + pt) % K["tmp_pairs"]), TMP0 + 2 * ((2 * i + pt) % K["tmp_pairs"]) + 1
                 q = 2 * i
                 r0 = act_reg(W, 2 * t + (q >> 2), pt) + (q & 3)
                 ins = []
@@ -473,7 +475,21 @@ def main():
         for line in g.out:
             f.write('  "%s\\n\\t" \\\n' % line)
         f.write('  ""\n')
-        f.write("#define SN_BF16_TRUNK_CLOBBERS " + ", ".join('"v%d"' % r for r in range(V_FIRST, 256)) + ', "memory", "scc"\n')
+        # the statement overwrites the WHOLE hand-managed AGPR file: declared, so that the compiler can never park a value in an
+        # AGPR across it (under register pressure it otherwise hoists loop invariants into a0.., which the next tile reads back
+        # after this statement has overwritten them -- tools/check_agpr.py flags any compiler-allocated AGPR for the same reason)
+        # VGPRs: exactly the physical registers the emitted text names (a shorter fragment ring etc. hands registers back to
+        # the compiler, which has to keep everything that lives across the statement in what is left of v0..v255)
+        import re
+        used = set()
+        for line in g.out:
+            for m in re.finditer(r"\bv\[(\d+):(\d+)\]", line):
+                used.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            for m in re.finditer(r"\bv(\d+)\b", line):
+                used.add(int(m.group(1)))
+        assert used and min(used) >= V_FIRST, "the statement only names registers of its own range"
+        f.write("#define SN_BF16_TRUNK_CLOBBERS " + ", ".join('"v%d"' % r for r in sorted(used)) + ", "
+                + ", ".join('"a%d"' % r for r in range(256)) + ', "memory", "scc"\n')
     print("trunk: %d MFMAs, %d other (%.2f / MFMA), nops %d, waits %d, forced %d"
           % (g.mfma_count, n_other, n_other / g.mfma_count, g.stats["nop"], g.stats["wait"], g.stats["forced"]))
 

@@ -70,7 +70,7 @@ G = torch.empty((10, acts.shape[1], 256), device=dev); g_o = torch.empty((P, 4),
 from sinnerf_amd import _lib                           # noqa: E402
 ms_chain, _ = timed(lambda: _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m.packed_bwd()), 0, _lib.ptr(acts), _lib.ptr(outt),
                                                                       _lib.ptr(g), P, acts.shape[1], _lib.ptr(G), _lib.ptr(g_o), None), "chain"))
-ms_dw, _ = timed(lambda: A._weight_grads(m, acts, embt, G, g_o, [True] * 24))
+ms_dw, _ = timed(lambda: A._weight_grads(m, acts, embt, G, [True] * 24))
 with torch.no_grad():
     ms_inf, _ = timed(lambda: sinnerf_amd.rendering._mlp(m, rays, z, False))
 fl = lambda f: f * P / 1e9
@@ -96,7 +96,7 @@ acts_b, emb_b, out_b = raw_b.grad_fn.saved_tensors
 G_b = torch.zeros((10, acts_b.shape[1], 256), dtype=acts_b.dtype, device=dev)
 ms_chain_b, _ = timed(lambda: _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(mb[1].packed_bwd("bf16")), 2, _lib.ptr(acts_b), _lib.ptr(out_b),
                                                                         _lib.ptr(g), P, acts_b.shape[1], _lib.ptr(G_b), _lib.ptr(g_o), None), "chain"))
-ms_dw_b, _ = timed(lambda: A._weight_grads(mb[1], acts_b, emb_b, G_b, g_o, [True] * 24))
+ms_dw_b, _ = timed(lambda: A._weight_grads(mb[1], acts_b, emb_b, G_b, [True] * 24))
 out["bf16_training"] = {"ms_per_step": dtb * 1e3, "train_rays_per_s": N / dtb, "fine_fwd_train_ms": ms_fwd_b,
                         "fine_bwd_chain_ms": ms_chain_b, "fine_dW_ms": ms_dw_b}
 os.makedirs("gpurun_out", exist_ok=True)
