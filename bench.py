@@ -123,7 +123,7 @@ def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
             **({"frac_of_fp32_mfma_peak": tflop / PEAK_TFLOPS["fp32"]} if dtype == "fp32" else {})}
 
 
-def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2):
+def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2, graph=False):
     """The multi-GPU training path of SURVEY §8e: replicas (broadcast at start), every rank draws its OWN 4096-ray patch,
     fwd + loss + bwd, ONE all-reduce (mean) of the flat 1 191 688-float gradient buffer over RCCL, fused Adam on the flat
     parameter buffer (FlatAdam / sn_adam_step).  Returns per-rank step time (max over ranks), the all-reduce time from HIP
@@ -136,14 +136,14 @@ def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2):
     rays = torch.from_numpy(O.lego_rays(400, 400, seed=100 + rank)[::39][:4096]).to(dev)      # this rank's patch
     batch = {"rays": rays, "rgbs": torch.rand((rays.shape[0], 3), device=dev)}
     for _ in range(warmup):
-        sysm.train_step(batch)
+        sysm.train_step(batch, graph=graph)
     flat.profile = []
     if world > 1:
         dist.barrier(device_ids=[dev.index]) if dist.get_backend() == "nccl" else dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = sysm.train_step(batch)
+        out = sysm.train_step(batch, graph=graph)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ar_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in flat.profile]
@@ -168,7 +168,9 @@ def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2):
             "all_reduce_us": float(np.mean(ar_us)) if ar_us else 0.0, "all_reduce_bytes": int(flat.flat.numel() * 4),
             "all_reduce_backend": (dist.get_backend() if world > 1 else "none (world 1)"),
             "n_ranks_seen": n_seen, "replicas_identical_after": steps + warmup,
-            "optimizer": "FlatAdam (sn_adam_step, one launch)", "loss": float(out["loss"].detach())}
+            "optimizer": "FlatAdam (sn_adam_step, one launch)", "loss": float(out["loss"].detach()),
+            "launch": "zero/forward/loss/backward replayed from ONE captured HIP graph; all-reduce + Adam eager" if graph
+                      else "eager (every kernel launched from Python)"}
 
 
 def main():
@@ -245,13 +247,16 @@ def main():
     if not args.no_extra:
         try:
             leg = train_dp_leg(O, dev, "bf16", rank, world, steps=max(3, min(args.steps, 10)))
+            leg_graph = train_dp_leg(O, dev, "bf16", rank, world, steps=max(3, min(args.steps, 10)), graph=True)
             leg32 = train_dp_leg(O, dev, "fp32", rank, world, steps=3) if world == 1 else None
         except AssertionError:
             raise
         except Exception as e:                      # noqa: BLE001
-            leg, leg32 = {"error": repr(e)}, None
+            leg, leg_graph, leg32 = {"error": repr(e)}, None, None
         if rank == 0:
             res["train_dp"] = leg
+            if leg_graph is not None:
+                res["train_dp_graph"] = leg_graph
             if leg32 is not None:
                 res["train_dp_fp32"] = leg32
 

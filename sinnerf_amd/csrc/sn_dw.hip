@@ -23,8 +23,7 @@ namespace snd {
 #define SN_DW_CPOL 2      // nt: G and X are streamed once (measured -3 % in the bandwidth-bound bf16 mode, neutral in fp32)
 #endif
 constexpr int KB = 16;                          // points per staged chunk
-constexpr int NBUF = 4;                         // LDS ring depth (NBUF-1 chunks in flight)
-constexpr int DW_LDS_BYTES = NBUF * KB * (256 + 256) * 4;   // 131072
+constexpr int DW_LDS_BYTES = 4 * KB * (256 + 256) * 4;      // 131072: LDS ring, 4 chunks of the widest fp32 problem (depth per mode: run_task)
 
 struct Task {                                   // 64 bytes, built on the host (sinnerf_amd/autograd.py)
   const void* a;                                // G  + column offset (fp32, or bf16 with 0x200)
@@ -46,18 +45,32 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid;
 // replaced by the last real chunk of the task ((k1-k0) % KB == 0) -- a wave-uniform select on the chunk base, so the
 // per-thread part of the address is a 32-bit byte offset computed once per task (off[it]) and a DMA instruction costs one
 // address add instead of a 64-bit multiply + per-row clamp.
+// bf16 tiles are read back with ds_read_b64_tr_b16 (below): a half-wave then touches 4 consecutive rows x 64 bytes, and rows
+// that are a multiple of 256 B apart would all sit on the same 16 banks.  The DMA therefore builds a SWIZZLED image: the LDS
+// side of global_load_lds is lane-linear, but each lane's GLOBAL address is free, so LDS piece (row, lp) receives the global
+// 16-byte piece (row, lp ^ 4 (row & 3)) -- rows r..r+3 of a 64-byte column group land in four different 64-byte bank groups.
+// (32-wide tiles: a row is 64 B, four rows fill the 256-byte bank window by themselves -- no swizzle.)
 template <int W, int ES>                        // ES = element size in bytes (4: fp32 tile, 2: bf16 tile)
 struct RowStager {
   static constexpr int CHUNKS = KB * W * ES / 16;   // 16-byte pieces per chunk
   static constexpr int PER_ROW = W * ES / 16;
   static constexpr int IT = (CHUNKS + 255) / 256;
+  static constexpr bool SWZ = (ES == 2) && PER_ROW >= 16;
   unsigned off[IT];
   SN_DEV void init(int ld, int tid) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int c = it * 256 + tid;
-      off[it] = (unsigned)((c / PER_ROW) * ld * ES + (c % PER_ROW) * 16);
+      const int row = c / PER_ROW, lp = c % PER_ROW;
+      const int gp = SWZ ? (lp ^ (4 * (row & 3))) : lp;
+      off[it] = (unsigned)(row * ld * ES + gp * 16);
     }
+  }
+  // byte offset inside a staged chunk of the 8-byte group (row, columns col .. col+3), col % 4 == 0
+  static SN_DEV unsigned tr_offset(int row, int col) {
+    const int cp = col * ES / 16;
+    const int lp = SWZ ? (cp ^ (4 * (row & 3))) : cp;
+    return (unsigned)(row * W * ES + lp * 16 + (col * ES) % 16);
   }
   SN_DEV void stage(const void* __restrict__ g, int ld, long k, long k_end, char* lds, int tid) const {
     const long kc = k < k_end ? k : k_end - KB;
@@ -79,6 +92,13 @@ typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
 typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 dw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef short dw_i16x4 __attribute__((ext_vector_type(4)));
+typedef short dw_i16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) dw_i16x4 lds_i16x4;
+// hardware transpose read: within a 16-lane group, lane p supplies the address of 4 consecutive bf16 of row (p >> 2),
+// columns 4 (p & 3) .. +3; lane q receives column q of the 4 x 16 block, rows 0..3 (checked by tools/ubench/tr_probe.hip).
+// A builtin: the compiler tracks its lgkmcnt like any LDS read.
+SN_DEV dw_i16x4 tr_read(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)p); }
 // {bf16(a), bf16(b)}, RNE: one v_cvt_pk_bf16_f32.  A builtin, NOT inline asm: the MFMAs of this kernel are builtins too and
 // the compiler must see the VALU write -> MFMA read dependence to pad it (an asm conversion right in front of the MFMA
 // that consumes it returned garbage in the narrow variants).
@@ -99,6 +119,11 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int WA = WM * MT * 32, WB = WN * NT * 32;
   constexpr int A_BYTES = KB * WA * EA, B_BYTES = KB * WB * EB, BUF = A_BYTES + B_BYTES;
+  // Ring depth: as many chunks as the 128 KB of LDS hold, at most 16 (fp32 256x256: 4 x 32 KB as before; bf16 state: 8 x 16 KB;
+  // the narrow problems 16 x 5..9 KB).  One CU streams (NBUF-1) chunks per HBM latency: with the bf16 tiles at depth 4 the
+  // narrow problems ran at 8 GB/s per CU (15 KB in flight), latency-bound far below their share of the HBM rate.
+  constexpr int NBUF = (DW_LDS_BYTES / BUF >= 16) ? 16 : (DW_LDS_BYTES / BUF >= 8) ? 8 : 4;
+  static_assert(NBUF * BUF <= DW_LDS_BYTES, "ring fits the LDS allocation");
   // DMA instructions per thread per chunk.  A 32-wide A tile (variants 4/5) is only 128 16-byte pieces: waves 2,3 issue
   // none of it, so their vmcnt budget is one instruction per chunk smaller (the wait must be exact per wave).
   constexpr int CH_A = KB * WA * EA / 16, CH_B = KB * WB * EB / 16;
@@ -138,7 +163,21 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
     // (packed, summed, multiplied) in iteration c+1: their LDS latency hides behind the 16 MFMAs of chunk c-1 -- consumed in
     // place hipcc waits on them 19 times per chunk (measured: 2.5 k cycles per chunk against 512 of MFMA work).
     static_assert(KB == 16, "one 32x32x16 k-step per chunk");
-    unsigned ra[MT][8], rb[NT][8];                 // raw gathered values: bf16 bits (zero-extended) or fp32 bits
+    unsigned ra[MT][EA == 2 ? 4 : 8], rb[NT][EB == 2 ? 4 : 8];   // fragments as read: packed bf16 pairs (transpose reads) or raw fp32 bits
+    // transpose-read addresses of this lane inside a staged chunk: lane (q, G): feature block G & 1, point rows 8 (G >> 1) + (q >> 2)
+    unsigned ta[MT], tb[NT];
+    {
+      const int q = lane & 15, G = lane >> 4;
+      if (EA == 2) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) ta[a] = RowStager<WA, EA>::tr_offset(8 * (G >> 1) + (q >> 2), m0 + 32 * a + 16 * (G & 1) + 4 * (q & 3));
+      }
+      if (EB == 2) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) tb[b] = RowStager<WB, EB>::tr_offset(8 * (G >> 1) + (q >> 2), n0 + 32 * b + 16 * (G & 1) + 4 * (q & 3)) + A_BYTES;
+      }
+    }
+    const bool want_bias = t.bias != nullptr && wc == 0;
     for (int c = 0; c <= n_chunks; ++c) {
       char* bc = smem + (c % NBUF) * BUF;
       if (c < n_chunks) {
@@ -157,19 +196,23 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
           dw_u32x4 q;
-          float sum = 0.0f;
+          if (EA == 2) {                             // already the operand: 8 points of one feature, packed in k order
 #pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            if (EA == 2) {
-              q[w] = ra[a][2 * w] | (ra[a][2 * w + 1] << 16);
-              sum += __builtin_bit_cast(float, ra[a][2 * w] << 16) + __builtin_bit_cast(float, ra[a][2 * w + 1] << 16);
-            } else {
+            for (int w = 0; w < 4; ++w) q[w] = ra[a][w];
+            if (want_bias) {                         // column sums for the bias gradient: fp32 accumulation of the bf16 values
+#pragma unroll
+              for (int w = 0; w < 4; ++w) asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(bsum[a]) : "v"(q[w]), "v"(0x3f803f80u));
+            }
+          } else {
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
               const float v0 = __builtin_bit_cast(float, ra[a][2 * w]), v1 = __builtin_bit_cast(float, ra[a][2 * w + 1]);
               q[w] = dw_pack2(v0, v1);
               sum += v0 + v1;
             }
+            bsum[a] += sum;
           }
-          bsum[a] += sum;
           af[a] = __builtin_bit_cast(dw_bf16x8, q);
         }
 #pragma unroll
@@ -177,7 +220,7 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
           dw_u32x4 q;
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
-            if (EB == 2) q[w] = rb[b][2 * w] | (rb[b][2 * w + 1] << 16);
+            if (EB == 2) q[w] = rb[b][w];
             else q[w] = dw_pack2(__builtin_bit_cast(float, rb[b][2 * w]), __builtin_bit_cast(float, rb[b][2 * w + 1]));
           }
           bf[b] = __builtin_bit_cast(dw_bf16x8, q);
@@ -189,19 +232,31 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
       }
       if (c < n_chunks) {                          // gathers of chunk c: lane (i, h) takes rows 8h .. 8h+7 of its feature
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < MT; ++a) {
+          if (EA == 2) {                             // two transpose reads: points 8h .. 8h+3 and 8h+4 .. 8h+7 of this lane's feature
+            const dw_i16x4 lo = tr_read(bc + ta[a]), hi = tr_read(bc + ta[a] + 4 * WA * EA);
+            const dw_i16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const dw_u32x4 u = __builtin_bit_cast(dw_u32x4, v);
 #pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            if (EA == 2) ra[a][jj] = reinterpret_cast<const unsigned short*>(bc)[(8 * h + jj) * WA + m0 + i + 32 * a];
-            else ra[a][jj] = reinterpret_cast<const unsigned*>(bc)[(8 * h + jj) * WA + m0 + i + 32 * a];
+            for (int w = 0; w < 4; ++w) ra[a][w] = u[w];
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) ra[a][jj] = reinterpret_cast<const unsigned*>(bc)[(8 * h + jj) * WA + m0 + i + 32 * a];
           }
+        }
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+        for (int b = 0; b < NT; ++b) {
+          if (EB == 2) {
+            const dw_i16x4 lo = tr_read(bc + tb[b]), hi = tr_read(bc + tb[b] + 4 * WB * EB);
+            const dw_i16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const dw_u32x4 u = __builtin_bit_cast(dw_u32x4, v);
 #pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            if (EB == 2) rb[b][jj] = reinterpret_cast<const unsigned short*>(bc + A_BYTES)[(8 * h + jj) * WB + n0 + i + 32 * b];
-            else rb[b][jj] = reinterpret_cast<const unsigned*>(bc + A_BYTES)[(8 * h + jj) * WB + n0 + i + 32 * b];
+            for (int w = 0; w < 4; ++w) rb[b][w] = u[w];
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) rb[b][jj] = reinterpret_cast<const unsigned*>(bc + A_BYTES)[(8 * h + jj) * WB + n0 + i + 32 * b];
           }
+        }
       }
     }
   } else {
@@ -354,7 +409,9 @@ static const VariantInfo VARIANTS[6] = {{256, 256}, {256, 64}, {128, 256}, {128,
 // FLOPs alone left the 32x128 problem streaming 168 MB through a single CU
 static const int COST_F32[6] = {512, 161, 260, 95, 101, 59};
 static const int COST_BF16[6] = {512, 189, 226, 126, 138, 125};          // bf16 operands, fp32 state
-static const int COST_BF16_STATE[6] = {512, 313, 325, 203, 224, 192};    // bf16 operands, bf16 state (gather-bound inner loop)
+// bf16 operands, bf16 state (transpose-read fragments): the 256x256 problems run at their share of the HBM rate (52 ns per
+// point per CU = 1 KB / 17.6 GB/s), the narrow ones at the loop's fixed cost per 16-point chunk (40..47 ns per point)
+static const int COST_BF16_STATE[6] = {512, 438, 453, 410, 429, 396};
 constexpr int TARGET_WGS = 256;                 // one workgroup per CU
 
 struct HostPlan {

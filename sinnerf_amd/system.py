@@ -113,14 +113,55 @@ class SinNeRFSystem(nn.Module):
             self.configure_optimizers()          # (an existing FlatAdam already saw the broadcast: its flat buffer IS p.data)
         return self._flat
 
-    def train_step(self, batch):
-        """zero -> forward -> loss -> backward -> [all-reduce of the flat gradient buffer + fused Adam] (FlatAdam.step)."""
-        if not hasattr(self, "optimizer"):
-            self.configure_optimizers()
+    def _zero_forward_backward(self, batch):
         self.optimizer.zero_grad()
         out = self.training_step(batch)
         out["loss"].backward()
+        return out
+
+    def train_step(self, batch, graph=False):
+        """zero -> forward -> loss -> backward -> [all-reduce of the flat gradient buffer + fused Adam] (FlatAdam.step).
+
+        ``graph=True``: the zero / forward / loss / backward part (~45 kernel launches and ~60 small torch ops per step, all
+        on the current stream, nothing built or copied from the host) is captured ONCE into a HIP graph for this batch shape
+        and replayed with the batch copied into static buffers; the exchange step stays eager (one all-reduce + one Adam
+        launch), so the same code serves one rank and N ranks.  The returned dict holds the graph's static output tensors
+        (overwritten by the next replay)."""
+        if not hasattr(self, "optimizer"):
+            self.configure_optimizers()
+        if graph:
+            out = self._graphed_step(batch)
+        else:
+            out = self._zero_forward_backward(batch)
         self.optimizer.step()                    # the one exchange step (RCCL all-reduce, mean) + sn_adam_step
+        return out
+
+    def _graphed_step(self, batch):
+        tensors = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        key = tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in tensors.items()))
+        cache = self.__dict__.setdefault("_step_graphs", {})
+        hit = cache.get(key)
+        if hit is None:
+            if not isinstance(self.optimizer, FlatAdam):
+                raise RuntimeError("train_step(graph=True) needs the flat optimiser (parameters on a ROCm device)")
+            static = {k: v.clone() for k, v in tensors.items()}
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):        # eager warm-up on a side stream: one-time attribute calls, pack tables,
+                for _ in range(2):               # allocator pools -- nothing of that may happen during capture
+                    self._zero_forward_backward(static)
+            cur.wait_stream(side)
+            for m in self.models:                # the re-pack of the weight blobs (one gather launch per blob, normally skipped
+                m.invalidate_packed()            # while the parameters are unchanged) must be PART of the captured step:
+            g = torch.cuda.CUDAGraph()           # the replays run behind optimizer steps no Python code sees
+            with torch.cuda.graph(g):
+                out = self._zero_forward_backward(static)
+            hit = cache[key] = (g, static, out)
+        g, static, out = hit
+        for k, v in tensors.items():
+            static[k].copy_(v)
+        g.replay()
         return out
 
     def replica_checksum(self):
