@@ -254,7 +254,7 @@ composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z_
 }
 
 // ---- importance sampler + merge --------------------------------------------------------------------
-// One wave per ray.  LDS per wave: cdf[S-1] | bins[S-1] | keys[S+NI].
+// One wave per ray.  LDS per wave: cdf[S-1] | bins[S-1] | keys[S+NI] | merged[S+NI] (FROM_Z only).
 // FROM_Z = true : render_rays path -- bins are the mid points of z_vals (N,S), pdf weights are weights[:,1:-1],
 //                 the S+NI merged depths are written sorted.
 // FROM_Z = false: plain sample_pdf(bins (N,S-1), weights (N,S-2)) of rendering.py:15-61, no merge.
@@ -269,10 +269,11 @@ sample_pdf_kernel(const float* __restrict__ z_vals, const float* __restrict__ we
   const int M = S - 2;                       // pdf bins   (weights[:, 1:-1])      rendering.py:311
   const int L = S - 1;                       // cdf / bins entries
   const int n = S + NI;
-  const int per_wave = 2 * L + n;
+  const int per_wave = 2 * L + n + (FROM_Z ? n : 0);
   float* cdf = reinterpret_cast<float*>(smem) + (long)wv * per_wave;
   float* bins = cdf + L;
   float* keys = bins + L;
+  float* merged = keys + n;                  // the sorted depths are scattered here and leave as coalesced rows
   if (ray >= n_rays) return;                 // whole wave exits together (no block-level barrier below)
   const long base = FROM_Z ? ray * (long)S : ray * (long)M - 1;   // weights[base + k + 1] = pdf weight k
   const float eps = 1e-5f;
@@ -332,16 +333,49 @@ sample_pdf_kernel(const float* __restrict__ z_vals, const float* __restrict__ we
   }
   if (!FROM_Z) return;
   wave_lds_sync();
-  // rank sort of the n keys (values only matter: torch.sort(...)[0], rendering.py:315)
-  for (int i = lane; i < n; i += 64) {
-    const float k = keys[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const float kj = keys[j];
-      rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
+  // sort(cat([z_vals, z_samples])) of rendering.py:315 (values only matter: torch.sort(...)[0]).  The coarse depths are
+  // ascending by construction (linspace + stratified perturb, :264-282); the samples are ascending whenever u is (det=True:
+  // u = linspace -- every eval render) and usually not with random u.  Two sorted lists merge by rank:
+  //     rank(coarse i) = i + #{samples <  z_i}       rank(sample m) = m + #{coarse <= z_m}
+  // -- exactly the permutation of the stable rank sort below (ties: coarse entries come first in the cat), one binary search
+  // per key instead of n compares.  A wave vote picks the path per ray.
+  bool ascending = true;
+  for (int i = lane; i < NI - 1; i += 64) ascending = ascending && (keys[S + i] <= keys[S + i + 1]);
+  for (int i = lane; i < S - 1; i += 64) ascending = ascending && (keys[i] <= keys[i + 1]);
+  if (__all(ascending)) {
+    const float* kf = keys + S;
+    for (int i = lane; i < S; i += 64) {
+      const float k = keys[i];
+      int lo = 0, hi = NI;                   // #{samples < k}
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (kf[mid] < k) lo = mid + 1; else hi = mid;
+      }
+      merged[i + lo] = k;
     }
-    z_merged_out[ray * (long)n + rank] = k;
+    for (int m = lane; m < NI; m += 64) {
+      const float k = kf[m];
+      int lo = 0, hi = S;                    // #{coarse <= k}
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] <= k) lo = mid + 1; else hi = mid;
+      }
+      merged[m + lo] = k;
+    }
+  } else {
+    // general case: stable rank sort of the n keys
+    for (int i = lane; i < n; i += 64) {
+      const float k = keys[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const float kj = keys[j];
+        rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
+      }
+      merged[rank] = k;
+    }
   }
+  wave_lds_sync();
+  for (int i = lane; i < n; i += 64) z_merged_out[ray * (long)n + i] = merged[i];
 }
 
 }  // namespace snr
@@ -410,7 +444,7 @@ extern "C" int sn_sample_pdf_launch(const float* z_vals, const float* weights, c
   if (n_samples < 3 || n_importance < 1) return -5;
   const long blocks = (n_rays + 3) / 4;
   if (blocks > 0x7fffffffL) return -2;
-  const size_t lds = 4 * (size_t)(2 * (n_samples - 1) + n_samples + n_importance) * sizeof(float);
+  const size_t lds = 4 * (size_t)(2 * (n_samples - 1) + 2 * (n_samples + n_importance)) * sizeof(float);
   if (lds > 64 * 1024) return -4;
   hipLaunchKernelGGL(snr::sample_pdf_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, z_vals, weights, u,
                      n_rays, n_samples, n_importance, z_fine, z_merged);
