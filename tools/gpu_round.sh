@@ -21,4 +21,9 @@ for dt in fp32 bf16; do
   echo "== instruction mix $dt"; timeout 300 $P --pmc $C -o mix_$dt -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --dtype $dt > $R/gpurun_out/mix_$dt.log 2>&1; echo "exit $?"
 done
 echo "== pmc bf16"; timeout 600 $P --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -o pmc1_bf16 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --dtype bf16 > $R/gpurun_out/prof_pmc1_bf16.log 2>&1; echo "exit $?"
-cd $R; ls gpurun_out/prof | head -60
+cd $R
+cd /tmp
+echo "== pmc train (HBM bytes of the training kernels)"
+timeout 600 $P --pmc FETCH_SIZE -o pmc_train_fetch -- python $R/tools/train_bench.py > $R/gpurun_out/prof_pmc_train_fetch.log 2>&1; echo "exit $?"
+timeout 600 $P --pmc WRITE_SIZE -o pmc_train_write -- python $R/tools/train_bench.py > $R/gpurun_out/prof_pmc_train_write.log 2>&1; echo "exit $?"
+cd $R
