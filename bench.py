@@ -118,9 +118,35 @@ def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
     tdt = (time.perf_counter() - t1) / reps
     pts = tr.shape[0] * (NS + NS + NI)
     tflop = FLOP_PER_POINT_TRAIN * pts / tdt / 1e12
-    return {"rays": tr.shape[0], "ms": tdt * 1e3, "rays_per_s": tr.shape[0] / tdt, "bound": "mfma", "achieved_tflops": tflop,
+    return {"rays": tr.shape[0], "ms": tdt * 1e3, "rays_per_s": tr.shape[0] / tdt, "bound": "mfma" if dtype == "fp32" else "hbm",
+            **({"roofline": train_hbm_roofline(tdt * 1e3, pts)} if dtype == "bf16" else {}), "achieved_tflops": tflop,
             "peak_tflops": PEAK_TFLOPS[dtype], "frac_of_mfma_peak": tflop / PEAK_TFLOPS[dtype],
             **({"frac_of_fp32_mfma_peak": tflop / PEAK_TFLOPS["fp32"]} if dtype == "fp32" else {})}
+
+
+# bf16 mixed-precision training keeps its state (activations, pre-activation gradients) in bf16 in HBM and every stage streams
+# it once: forward writes 10 x 512 B activations + 512 B embedded inputs + 16 B output per point, the chain reads 9 x 512 B
+# activations (+ 32 B) and writes 10 x 512 B gradients (+ 16 B), the weight-gradient contractions read 11 904 B (DESIGN.md
+# §3.3) -- the step is bound by HBM, not by the MFMA rate.
+TRAIN_BF16_BYTES_PER_POINT = (5120 + 512 + 16) + (4608 + 32 + 5120 + 16) + 11904
+HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 measured streaming ceiling)
+
+
+def train_hbm_roofline(ms_per_step, n_points):
+    """`roofline` of the bf16 training step: algorithmic HBM bytes / step time against the HBM peak; `traffic` = the bytes
+    the PMC counters saw (profiles/r02_run2_train_pmc.json, FETCH_SIZE x2 + WRITE_SIZE of the three MLP stages)."""
+    traffic, note = None, "no PMC summary"
+    try:
+        k = json.load(open(os.path.join(REPO, "profiles", "r02_run2_train_pmc.json")))["kernels"]
+        per_pt = sum(v["bytes_per_point"] for name, v in k.items() if "bf16" in name)
+        traffic, note = per_pt * n_points, "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/r02_run2_train_pmc.json)"
+    except Exception:                               # noqa: BLE001
+        pass
+    alg = TRAIN_BF16_BYTES_PER_POINT * n_points
+    ach = alg / (ms_per_step * 1e-3) / 1e12
+    return {"bound": "hbm", "kernel": "bf16 training step: mlp_fwd_bf16_kernel<STORE> + mlp_bwd_chain_bf16_kernel + dw_kernel (coarse + fine)",
+            "achieved": ach, "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": ach / HBM_PEAK_TBS, "traffic": traffic,
+            "traffic_note": note, "algorithmic_bytes_per_step": alg}
 
 
 def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2, graph=False):
@@ -168,6 +194,7 @@ def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2, graph=False):
             "all_reduce_us": float(np.mean(ar_us)) if ar_us else 0.0, "all_reduce_bytes": int(flat.flat.numel() * 4),
             "all_reduce_backend": (dist.get_backend() if world > 1 else "none (world 1)"),
             "n_ranks_seen": n_seen, "replicas_identical_after": steps + warmup,
+            **({"roofline": train_hbm_roofline(step_s * 1e3, pts)} if dtype == "bf16" else {}),
             "optimizer": "FlatAdam (sn_adam_step, one launch)", "loss": float(out["loss"].detach()),
             "launch": "zero/forward/loss/backward replayed from ONE captured HIP graph; all-reduce + Adam eager" if graph
                       else "eager (every kernel launched from Python)"}
