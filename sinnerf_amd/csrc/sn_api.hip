@@ -5,7 +5,7 @@
 
 extern "C" {
 int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                              int sigma_only, int input_mode, int use_dma, float* out, float* acts, float* emb,
+                              int sigma_only, int input_mode, float* out, float* acts, float* emb,
                               long slot_rows, hipStream_t stream);
 int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
@@ -153,7 +153,7 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
                                       nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
   return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
-                                   1, out, nullptr, nullptr, 0, (hipStream_t)stream);
+                                   out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
@@ -166,7 +166,7 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
   if (dtype != SN_DTYPE_F32)
     return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
                                       dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
-  return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, 1, out, acts, emb, slot_rows,
+  return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
                                    (hipStream_t)stream);
 }
 
@@ -181,7 +181,7 @@ int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, l
   if (dtype != SN_DTYPE_F32)
     return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows,
                                       dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
-  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, 0, 1, 1, out, acts, emb, slot_rows, (hipStream_t)stream);
+  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows, (hipStream_t)stream);
 }
 
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
@@ -262,7 +262,7 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   if (dtype == SN_DTYPE_BF16)
     return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
-  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, 1,
+  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1,
                                    out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 

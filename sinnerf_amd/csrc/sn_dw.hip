@@ -277,7 +277,9 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
       const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
       // (measured and rejected: requesting the fragments of pair s+1 ahead of the MFMAs of pair s behind scheduling fences --
       //  hipcc reads them right in front of their first use -- made the 256x256 problems 3 % and the one-MFMA-per-pair narrow
-      //  ones 30 % slower: the fences also pin the accumulator traffic of the builtin MFMAs)
+      //  ones 30 % slower: the fences also pin the accumulator traffic of the builtin MFMAs.  A rolled loop over the k-step
+      //  pairs with the next pair's fragments carried across the back edge was worse still: 6.0 against 5.1 ms on the
+      //  256x256 problems, 2x on the narrow ones)
 #pragma unroll
       for (int s = 0; s < KB / 2; ++s) {
         float av[MT], bv[NT];

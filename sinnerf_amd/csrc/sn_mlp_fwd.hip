@@ -320,10 +320,9 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 
 // ---------------------------------------------------------------------------------------------------
 extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                                         int sigma_only, int input_mode, int use_dma, float* out, float* acts, float* emb,
+                                         int sigma_only, int input_mode, float* out, float* acts, float* emb,
                                          long slot_rows, hipStream_t stream) {
   using namespace snk;
-  (void)use_dma;                                 // the register-staged ablation path was retired with the v2 pipeline
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
   const bool store = acts != nullptr;
