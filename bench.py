@@ -274,7 +274,7 @@ def main():
     if not args.no_extra:
         try:
             leg = train_dp_leg(O, dev, "bf16", rank, world, steps=max(3, min(args.steps, 10)))
-            leg_graph = train_dp_leg(O, dev, "bf16", rank, world, steps=max(3, min(args.steps, 10)), graph=True)
+            leg_graph = train_dp_leg(O, dev, "bf16", rank, world, steps=max(3, min(args.steps, 10)), graph=True) if world == 1 else None
             leg32 = train_dp_leg(O, dev, "fp32", rank, world, steps=3) if world == 1 else None
         except AssertionError:
             raise

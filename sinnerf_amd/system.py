@@ -155,7 +155,8 @@ class SinNeRFSystem(nn.Module):
             for m in self.models:                # the re-pack of the weight blobs (one gather launch per blob, normally skipped
                 m.invalidate_packed()            # while the parameters are unchanged) must be PART of the captured step:
             g = torch.cuda.CUDAGraph()           # the replays run behind optimizer steps no Python code sees
-            with torch.cuda.graph(g):
+            # thread_local: an RCCL process group's watchdog thread polls events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self._zero_forward_backward(static)
             hit = cache[key] = (g, static, out)
         g, static, out = hit
