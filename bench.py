@@ -125,10 +125,10 @@ def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
 
 
 # bf16 mixed-precision training keeps its state (activations, pre-activation gradients) in bf16 in HBM and every stage streams
-# it once: forward writes 10 x 512 B activations + 512 B embedded inputs + 16 B output per point, the chain reads 9 x 512 B
-# activations (+ 32 B) and writes 10 x 512 B gradients (+ 16 B), the weight-gradient contractions read 11 904 B (DESIGN.md
-# §3.3) -- the step is bound by HBM, not by the MFMA rate.
-TRAIN_BF16_BYTES_PER_POINT = (5120 + 512 + 16) + (4608 + 32 + 5120 + 16) + 11904
+# it once: forward writes 10 x 512 B activations + 256 B ReLU sign words + 512 B embedded inputs + 16 B output per point, the
+# chain reads the sign words + the 256 B softplus tile (+ 32 B) and writes 10 x 512 B gradients (+ 16 B), the weight-gradient
+# contractions read 11 904 B -- the step is bound by HBM, not by the MFMA rate.
+TRAIN_BF16_BYTES_PER_POINT = (5120 + 256 + 512 + 16) + (256 + 256 + 32 + 5120 + 16) + 11904
 HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 measured streaming ceiling)
 
 

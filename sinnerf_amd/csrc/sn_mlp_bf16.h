@@ -47,6 +47,36 @@ SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3) {
   uint32_t t0, t1;
   epi_relu(reg, x0, x1, x2, x3, t0, t1);
 }
+// ... and the same with the ReLU SIGN BITS kept for the backward chain (bf16-state training forward).  The two packed words
+// of a block are steps j, j+1 of a tile's 16 (both point tiles share one register: pt 0 = steps 0..7, pt 1 = 8..15):
+//     bits = (bits >> 1) | (word & 0x80008000)
+// leaves, after the 16th step, the sign of the LOW value of step j at bit j and of the HIGH value at bit 16 + j -- one
+// 32-bit word per lane and output tile (32 features x 64 points = 256 B per wave) instead of the 4 KB of activations the
+// chain otherwise re-reads for [h > 0].
+SN_DEV void epi_relu_bits(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1, uint32_t& bits) {
+  uint32_t b;                                   // (the sign mask is a VOP2 literal: no register -- this kernel has none to spare)
+  asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\t"
+               "v_lshrrev_b32 %2, 1, %2\n\tv_and_b32 %3, 0x80008000, %0\n\t"
+               "v_pk_max_i16 %0, %0, 0\n\tv_or_b32 %2, %2, %3\n\t"
+               "v_and_b32 %3, 0x80008000, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+               "v_pk_max_i16 %1, %1, 0\n\tv_or_b32 %2, %2, %3\n\t"
+               "v_accvgpr_write_b32 a[%8], %0\n\tv_accvgpr_write_b32 a[%9], %1"
+               : "=&v"(t0), "=&v"(t1), "+v"(bits), "=&v"(b)
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
+}
+// fp32 ReLU form (layer 8: the fp32 outputs also feed the sigma head): the signs are those of the fp32 inputs
+SN_DEV void epi_relu_f32_bits(int reg, float x0, float x1, float x2, float x3, float (&v)[4], uint32_t& t0, uint32_t& t1,
+                              uint32_t& bits) {
+  asm volatile("v_cvt_pk_bf16_f32 %0, %7, %8\n\tv_cvt_pk_bf16_f32 %1, %9, %10\n\t"
+               "v_max_f32 %2, 0, %7\n\tv_max_f32 %3, 0, %8\n\tv_max_f32 %4, 0, %9\n\tv_max_f32 %5, 0, %10\n\t"
+               "v_lshrrev_b32 %6, 1, %6\n\tv_and_b32 %0, 0x80008000, %0\n\t"
+               "v_and_b32 %1, 0x80008000, %1\n\tv_or_b32 %6, %6, %0\n\t"
+               "v_lshrrev_b32 %6, 1, %6\n\tv_cvt_pk_bf16_f32 %0, %2, %3\n\t"
+               "v_or_b32 %6, %6, %1\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+               "v_accvgpr_write_b32 a[%11], %0\n\tv_accvgpr_write_b32 a[%12], %1"
+               : "=&v"(t0), "=&v"(t1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "+v"(bits)
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
+}
 SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1) {   // no activation
   asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
                "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"

@@ -50,8 +50,26 @@ SN_DEV void epi_mask16(int reg, float x0, float x1, float x2, float x3, uint32_t
                : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(u0), "v"(u1), "v"(c01), "n"(reg), "n"(reg + 1));
 }
 
+// bf16 state, ReLU layers: the mask comes from the SIGN WORD the training forward left for this (layer, tile) (sn_mlp_bf16.h
+// epi_relu_bits: one dword per lane; the low / high value of the packed pair of step j at bits j / 16 + j): shift the pair's
+// two bits down, isolate them (c01 = 0x00010001), subtract 1 per half -> 0xffff where the forward value was positive, AND.
+// Step order: hidden layers 8 pt + q (point tile outermost in the forward's epilogue), layer 8 (sigma epilogue) 2 q + 2 pt.
+SN_DEV void epi_maskbits(int reg, int j0, float x0, float x1, float x2, float x3, uint32_t mw, uint32_t c01,
+                         uint32_t& t0, uint32_t& t1) {
+  uint32_t m0, m1;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\t"
+               "v_lshrrev_b32 %2, %10, %8\n\tv_lshrrev_b32 %3, %11, %8\n\t"
+               "v_and_b32 %2, %2, %9\n\tv_and_b32 %3, %3, %9\n\t"
+               "v_pk_sub_u16 %2, %2, %9\n\tv_pk_sub_u16 %3, %3, %9\n\t"
+               "v_and_b32 %0, %0, %2\n\tv_and_b32 %1, %1, %3\n\t"
+               "v_accvgpr_write_b32 a[%12], %0\n\tv_accvgpr_write_b32 a[%13], %1"
+               : "=&v"(t0), "=&v"(t1), "=&v"(m0), "=&v"(m1)
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(mw), "v"(c01), "n"(j0), "n"(j0 + 1), "n"(reg), "n"(reg + 1));
+}
+
 // S16: acts and G are bf16 arrays (SN_DTYPE_BF16_STATE): half the HBM traffic of this bandwidth-bound kernel; G then holds
-// exactly the bf16 values the next transposed layer and the weight-gradient kernel consume.
+// exactly the bf16 values the next transposed layer and the weight-gradient kernel consume.  The ReLU masks of layers 1..8
+// are read as sign words from the unused half of acts slot 9 (256 B per point instead of 4 KB: sn_mlp_fwd_bf16.hip).
 template <bool S16>
 __global__ void __launch_bounds__(256)
 mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restrict__ acts, const float* __restrict__ out_raw,
@@ -177,7 +195,13 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
     };
     uint32_t c01 = 0x00010001u;
     asm volatile("" : "+v"(c01));
+    uint32_t sign_word = 0;                                                 // bf16 state: ReLU sign word of the tile in flight
     auto load_act = [&](int slot, int t, bool values = false) __attribute__((always_inline)) {
+      if (S16 && !values) {
+        const char* src = reinterpret_cast<const char*>(acts) + (((long)9 * slot_rows + p_wave + 8 * slot + t) * 256 + 128) * 2;
+        sign_word = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src + lane * 4));
+        return;
+      }
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         if (S16) {
@@ -278,7 +302,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
     auto mask_tile_impl = [&](auto wset, auto with_sigma, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
       constexpr int W = decltype(wset)::value;
       constexpr bool SIG = decltype(with_sigma)::value;
-      act_turn(false);
+      if (!S16) act_turn(false);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -292,7 +316,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
           float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
           uint32_t t0, t1;
           if (S16) {
-            epi_mask16(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), x[0], x[1], x[2], x[3], au[pt][q >> 1][0], au[pt][q >> 1][1], c01, t0, t1);
+            epi_maskbits(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), SIG ? 2 * q + 2 * pt : 8 * pt + q, x[0], x[1], x[2], x[3], sign_word, c01, t0, t1);
           } else {
             const f32x4 a = av[pt][q >> 1];
             epi_mask(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), x[0], x[1], x[2], x[3], a[0], a[1], a[2], a[3], v, t0, t1);

@@ -42,7 +42,10 @@ namespace snk {
 // (acts[10][slot_rows][256]: the fp32 values BEFORE their bf16 rounding) and the fp32 embedded inputs (emb[slot_rows][128])
 // that the fp32 backward (sn_mlp_bwd.hip, sn_dw.hip) consumes: bf16 forward + fp32 backward, i.e. mixed precision.
 // STORE 2: the activations are stored as bf16 (acts is then a bf16 array of the same shape: exactly the values the next
-// layer consumed); emb stays fp32.
+// layer consumed); emb stays fp32.  The unused half of slot 9 (dir_encoding is 128 wide: columns 128..255, 256 B per point)
+// receives the ReLU sign words of layers 1..8 (sn_mlp_bf16.h epi_relu_bits): for the 64 points p_wave .. p_wave+63 of a wave,
+// the word of (layer l, output tile t) sits in row p_wave + 8 l + t, dword `lane` -- 256 B per point in total, what the
+// backward chain reads instead of the 4 KB of activations.
 template <bool SIGMA_ONLY, int INPUT_MODE, int STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1,
@@ -161,6 +164,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     // tile; store_tile() then writes the staged 32-point x 32-feature tiles of both point tiles to
     // acts[slot][point][32t..32t+31] as whole 128-byte rows, non-temporal.
     int cur_slot = 0;
+    uint32_t sign_bits = 0;                                  // STORE 2: ReLU sign word of the tile being finalised
     auto stage = [&](int pt, int qq, const float (&v)[4]) __attribute__((always_inline)) {
       if (STORE == 1) {
         f32x4 o;
@@ -198,6 +202,12 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             asm volatile("" : "+v"(go));
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
           }
+        if (slot < 8) {                          // ReLU layers: the tile's sign word, 256 contiguous bytes per wave
+          char* base = reinterpret_cast<char*>(acts) + (((long)9 * slot_rows + p_wave + 8 * slot + t) * 256 + 128) * 2;
+          unsigned go = (unsigned)lane * 4u;
+          asm volatile("" : "+v"(go));
+          __builtin_nontemporal_store(sign_bits, reinterpret_cast<uint32_t*>(base + go));
+        }
       }
     };
     // Epilogues of output tile t (results r) writing activation set W: dword q of the tile = accumulator registers
@@ -213,10 +223,14 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             float v[4];
             epi_relu_f32(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v);
             stage(pt, q >> 1, v);
+          } else if (STORE == 2) {
+            uint32_t t0, t1;
+            if (pt == 0 && q == 0) sign_bits = 0;
+            epi_relu_bits(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1, sign_bits);
+            stage16(pt, q >> 1, t0, t1);
           } else {
             uint32_t t0, t1;
             epi_relu(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1);
-            stage16(pt, q >> 1, t0, t1);
           }
         }
     };
@@ -224,6 +238,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     auto relu_sigma_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
       constexpr int W = decltype(wset)::value;
       const f32x4* ws = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t);
+      if (STORE == 2) sign_bits = 0;            // (block order here: q outermost -> steps 2q + 2pt, 2q + 2pt + 1 of the sign word)
 #pragma unroll
       for (int q = 0; q < 8; q += 2) {
         const f32x4 w = ws[q >> 1];
@@ -231,7 +246,10 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         for (int pt = 0; pt < PT; ++pt) {
           float v[4];
           uint32_t t0, t1;
-          epi_relu_f32(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v, t0, t1);
+          if (STORE == 2)
+            epi_relu_f32_bits(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v, t0, t1, sign_bits);
+          else
+            epi_relu_f32(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v, t0, t1);
           stage16(pt, q >> 1, t0, t1);
           sg[pt] = __builtin_fmaf(w[0], v[0], sg[pt]);
           sg[pt] = __builtin_fmaf(w[1], v[1], sg[pt]);
