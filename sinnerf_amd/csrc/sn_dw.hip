@@ -152,9 +152,13 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   sa.init(t.lda, tid);
   sb.init(t.ldb, tid);
   const int n_chunks = (int)((k1 - k0 + KB - 1) / KB);
-  // prologue: NBUF-1 chunks in flight (chunks past the end are staged as clamped copies and never consumed)
+  // bf16 modes with a deep ring meet at the barrier every SY-th chunk only (SY chunks are waited for and SY slots restaged per
+  // sync point): at 16 points per chunk the fixed cost of a sync point (counted wait, barrier skew between the four waves) is
+  // as long as the chunk's share of the HBM stream
+  constexpr int SY = (BF16 && NBUF >= 8) ? NBUF / 4 : 1;      // ring of 8: every 2nd chunk, ring of 16 (narrow problems): every 4th
+  // prologue: NBUF-SY chunks in flight (chunks past the end are staged as clamped copies and never consumed)
 #pragma unroll
-  for (int c = 0; c < NBUF - 1; ++c) {
+  for (int c = 0; c < NBUF - SY; ++c) {
     sa.stage(t.a, t.lda, k0 + (long)c * KB, k1, smem + c * BUF, tid);
     sb.stage(t.b, t.ldb, k0 + (long)c * KB, k1, smem + c * BUF + A_BYTES, tid);
   }
@@ -180,16 +184,20 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
     const bool want_bias = t.bias != nullptr && wc == 0;
     for (int c = 0; c <= n_chunks; ++c) {
       char* bc = smem + (c % NBUF) * BUF;
-      if (c < n_chunks) {
+      if (c < n_chunks && c % SY == 0) {
+        // sync point, every SY-th chunk: chunks c .. c+SY-1 have landed for every wave (the NBUF-2*SY younger ones may still be
+        // in flight), chunks c-SY .. c-1 are fully gathered -> their slots are restaged with chunks c+NBUF-SY .. c+NBUF-1
         const long k = k0 + (long)c * KB;
-        if (PART_A != 0 && wave >= PART_A) wait_vmcnt<(NBUF - 2) * (IT_A - 1 + IT_B)>();
-        else wait_vmcnt<(NBUF - 2) * (IT_A + IT_B)>();
+        if (PART_A != 0 && wave >= PART_A) wait_vmcnt<(NBUF - 2 * SY) * (IT_A - 1 + IT_B)>();
+        else wait_vmcnt<(NBUF - 2 * SY) * (IT_A + IT_B)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own gathers of chunk c-1 done before its slot is restaged
-        __builtin_amdgcn_s_barrier();             // all waves' pieces of chunk c landed; chunk c-1 fully gathered
-        const int slot = (c + NBUF - 1) % NBUF;   // = slot of chunk c-1
-        char* bn = smem + slot * BUF;
-        sa.stage(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, bn, tid);
-        sb.stage(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, bn + A_BYTES, tid);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int u = 0; u < SY; ++u) {
+          char* bn = smem + ((c + NBUF - SY + u) % NBUF) * BUF;
+          sa.stage(t.a, t.lda, k + (long)(NBUF - SY + u) * KB, k1, bn, tid);
+          sb.stage(t.b, t.ldb, k + (long)(NBUF - SY + u) * KB, k1, bn + A_BYTES, tid);
+        }
       }
       if (c > 0) {                                 // chunk c-1: pack, column sums, 16 MFMAs
         dw_bf16x8 af[MT], bf[NT];
@@ -414,9 +422,9 @@ static const VariantInfo VARIANTS[6] = {{256, 256}, {256, 64}, {128, 256}, {128,
 // FLOPs alone left the 32x128 problem streaming 168 MB through a single CU
 static const int COST_F32[6] = {512, 161, 260, 95, 101, 59};
 static const int COST_BF16[6] = {512, 189, 226, 126, 138, 125};          // bf16 operands, fp32 state
-// bf16 operands, bf16 state (transpose-read fragments): the 256x256 problems run at their share of the HBM rate (52 ns per
-// point per CU = 1 KB / 17.6 GB/s), the narrow ones at the loop's fixed cost per 16-point chunk (40..47 ns per point)
-static const int COST_BF16_STATE[6] = {512, 438, 453, 410, 429, 396};
+// bf16 operands, bf16 state (transpose-read fragments, a sync point every 2nd / 4th chunk): the 256x256 problems run at their
+// share of the HBM rate (52 ns per point per CU = 1 KB / 19.7 GB/s), the narrower ones at 19..35 ns per point
+static const int COST_BF16_STATE[6] = {512, 343, 348, 226, 296, 190};
 constexpr int TARGET_WGS = 256;                 // one workgroup per CU
 
 struct HostPlan {

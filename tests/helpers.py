@@ -92,7 +92,7 @@ _VARIANT_COST = {0: 512, 1: 161, 2: 260, 3: 95, 4: 101, 5: 59}      # measured p
 # bf16-operand mode: 8x less MFMA time, every variant is bound by its per-CU DMA stream -- measured per-point times again
 _VARIANT_COST_BF16 = {0: 512, 1: 189, 2: 226, 3: 126, 4: 138, 5: 125}
 # ... and with G / the activations stored as bf16 (gather-bound inner loop, half the bytes)
-_VARIANT_COST_BF16_STATE = {0: 512, 1: 438, 2: 453, 3: 410, 4: 429, 5: 396}
+_VARIANT_COST_BF16_STATE = {0: 512, 1: 343, 2: 348, 3: 226, 4: 296, 5: 190}
 _KB = 16                      # csrc/sn_dw.hip: points per staged chunk
 _TARGET_WGS = 256             # exactly one workgroup per CU per launch
 
