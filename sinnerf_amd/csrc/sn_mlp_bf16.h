@@ -99,6 +99,12 @@ SN_DEV void epi_relu_f32(int reg, float x0, float x1, float x2, float x3, float 
 }
 // Training variants that keep the state in bf16: per-wave staging tile of packed rows (32 points x 32 features x 2 B,
 // pitch 80 B), read back as 16-byte chunks -- one store instruction writes sixteen whole 64-byte rows.
+// ... STORE side: two consecutive 32-feature tiles are staged side by side (a point row = 64 features = 128 B, pitch 144 B) and
+// leave as whole 128-byte rows every second tile.  One tile at a time a row piece is 64 B -- half a cache line, written
+// non-temporally by two different slabs: those partial-line stores cost the chain 0.41 of 1.18 ms and the training forward
+// 0.27 of 1.24 ms (timing builds without the stores), while the fp32-state kernels' 128-byte rows are free.
+constexpr int XS16_PITCH = 144;
+static_assert(32 * XS16_PITCH <= XPOSE_WAVE_BYTES, "the tile-pair staging fits the fp32 staging tile");
 constexpr int XP16_PITCH = 80;
 constexpr int XP16_WAVE_BYTES = 32 * XP16_PITCH;            // 2560
 // D = A.B + D, D and A in VGPRs; B = a[reg : reg+3] ...

@@ -125,9 +125,11 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
   const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
-  const unsigned xp16_w = (unsigned)(j * XP16_PITCH + 8 * h);
+  const unsigned xp16_w = (unsigned)(j * XP16_PITCH + 8 * h);                        // incoming activation tile (softplus values)
   const unsigned xp16_r = (unsigned)((lane >> 2) * XP16_PITCH + 16 * (lane & 3));
-  const unsigned g16_off = (unsigned)((lane >> 2) * 512 + 16 * (lane & 3));
+  const unsigned xs16_w = (unsigned)(j * XS16_PITCH + 8 * h);                        // outgoing gradient tile PAIRS (sn_mlp_bf16.h)
+  const unsigned xs16_r = (unsigned)((lane >> 3) * XS16_PITCH + 16 * (lane & 7));
+  const unsigned g16_off = (unsigned)((lane >> 3) * 512 + 16 * (lane & 7));
   char* const xl = smem + BWD16_TAIL_BYTES + 3 * BWD16_RING_SLOT + 4 * PT * XPOSE_WAVE_BYTES + wave * (PT * XP16_WAVE_BYTES);
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -221,11 +223,11 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
         }
       }
     };
-    auto stage = [&](int pt, int qq, const float (&v)[4], uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
+    auto stage = [&](int pt, int t, int qq, const float (&v)[4], uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
       if (S16) {
         uint2 o;
         o.x = t0; o.y = t1;
-        *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xp16_w + 16 * qq) = o;
+        *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xs16_w + 64 * (t & 1) + 16 * qq) = o;
       } else {
         f32x4 o;
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
@@ -236,13 +238,19 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         if (S16) {
+          if (t & 1) {                           // tiles t-1, t: whole 128-byte rows
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp16_r + 16 * i * XP16_PITCH);
-            char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 16 * i) * 256 + 32 * t) * 2;
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xs16_r + 8 * i * XS16_PITCH);
+            char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * (t - 1)) * 2;
             unsigned go = g16_off;
             asm volatile("" : "+v"(go));
+#ifndef SN_ABL_NO_STATE_STORE                       // (timing experiments only: tools/build_variant_src.sh)
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+#else
+            asm volatile("" :: "v"(o), "s"(base), "v"(go));
+#endif
+          }
           }
         } else {
 #pragma unroll
@@ -278,7 +286,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
           }
           uint32_t t0, t1;
           epi_copy(act_reg(0, 2 * t + (q >> 2), pt) + (q & 3), v[0], v[1], v[2], v[3], t0, t1);
-          stage(pt, q >> 1, v, t0, t1);
+          stage(pt, t, q >> 1, v, t0, t1);
         }
       store_tile(9, t);
     }
@@ -295,7 +303,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
           uint32_t t0, t1;
           epi_copy(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1);
           const float v[4] = {r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]};
-          stage(pt, q >> 1, v, t0, t1);
+          stage(pt, t, q >> 1, v, t0, t1);
         }
     };
     // g_y = g_h [h > 0]; with_sigma: g_h8 also gets the sigma head's term  sigma.weight[f] g_sigma  (nerf.py:136)
@@ -321,7 +329,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
             const f32x4 a = av[pt][q >> 1];
             epi_mask(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), x[0], x[1], x[2], x[3], a[0], a[1], a[2], a[3], v, t0, t1);
           }
-          stage(pt, q >> 1, v, t0, t1);
+          stage(pt, t, q >> 1, v, t0, t1);
         }
     };
     auto mask_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {

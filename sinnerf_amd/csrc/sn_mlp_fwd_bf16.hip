@@ -99,9 +99,9 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
-  const unsigned xp16_w = (unsigned)(j * XP16_PITCH + 8 * h);                       // bf16 state: this lane's packed pairs
-  const unsigned xp16_r = (unsigned)((lane >> 2) * XP16_PITCH + 16 * (lane & 3));    // row lane>>2, 16-byte chunk lane&3
-  const unsigned g16_off = (unsigned)((lane >> 2) * 512 + 16 * (lane & 3));
+  const unsigned xp16_w = (unsigned)(j * XS16_PITCH + 8 * h);                       // bf16 state: this lane's packed pairs
+  const unsigned xp16_r = (unsigned)((lane >> 3) * XS16_PITCH + 16 * (lane & 7));    // row lane>>3, 16-byte chunk lane&7 of a tile PAIR
+  const unsigned g16_off = (unsigned)((lane >> 3) * 512 + 16 * (lane & 7));
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * (PT * 32);    // wave-uniform
@@ -172,11 +172,11 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         *reinterpret_cast<f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_w + 32 * qq) = o;
       }
     };
-    auto stage16 = [&](int pt, int qq, uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
-      if (STORE == 2) {
+    auto stage16 = [&](int pt, int t, int qq, uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
+      if (STORE == 2) {                          // tile t goes to half t & 1 of the 128-byte staged rows
         uint2 o;
         o.x = t0; o.y = t1;
-        *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xp16_w + 16 * qq) = o;
+        *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xp16_w + 64 * (t & 1) + 16 * qq) = o;
       }
     };
     auto store_tile = [&](int slot, int t) __attribute__((always_inline)) {
@@ -192,16 +192,22 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
           }
       } else if (STORE == 2) {
+        if (t & 1) {                             // tiles t-1, t: whole 128-byte rows, 8 rows per instruction
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp16_r + 16 * i * XP16_PITCH);
-            char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 16 * i) * 256 + 32 * t) * 2;
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp16_r + 8 * i * XS16_PITCH);
+            char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * (t - 1)) * 2;
             unsigned go = g16_off;
             asm volatile("" : "+v"(go));
+#ifndef SN_ABL_NO_STATE_STORE                       // (timing experiments only: tools/build_variant_src.sh)
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+#else
+            asm volatile("" :: "v"(o), "s"(base), "v"(go));
+#endif
           }
+        }
         if (slot < 8) {                          // ReLU layers: the tile's sign word, 256 contiguous bytes per wave
           char* base = reinterpret_cast<char*>(acts) + (((long)9 * slot_rows + p_wave + 8 * slot + t) * 256 + 128) * 2;
           unsigned go = (unsigned)lane * 4u;
@@ -227,7 +233,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             uint32_t t0, t1;
             if (pt == 0 && q == 0) sign_bits = 0;
             epi_relu_bits(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1, sign_bits);
-            stage16(pt, q >> 1, t0, t1);
+            stage16(pt, t, q >> 1, t0, t1);
           } else {
             uint32_t t0, t1;
             epi_relu(reg, r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1);
@@ -250,7 +256,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
             epi_relu_f32_bits(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v, t0, t1, sign_bits);
           else
             epi_relu_f32(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], v, t0, t1);
-          stage16(pt, q >> 1, t0, t1);
+          stage16(pt, t, q >> 1, t0, t1);
           sg[pt] = __builtin_fmaf(w[0], v[0], sg[pt]);
           sg[pt] = __builtin_fmaf(w[1], v[1], sg[pt]);
           sg[pt] = __builtin_fmaf(w[2], v[2], sg[pt]);
@@ -269,7 +275,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           epi_copy(act_reg(W, 2 * t + (q >> 2), pt) + (q & 3), r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3], t0, t1);
           const float v[4] = {r[pt][2 * q], r[pt][2 * q + 1], r[pt][2 * q + 2], r[pt][2 * q + 3]};
           stage(pt, q >> 1, v);
-          stage16(pt, q >> 1, t0, t1);
+          stage16(pt, t, q >> 1, t0, t1);
         }
     };
 #define SNB_LW_CUR (ring.slot(cslot) + lane * 16)
@@ -402,7 +408,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           float v[4];
           ssp4_rgb(x, w, c3[pt], v);
           stage(pt, q, v);
-          if (STORE == 2) stage16(pt, q, pack2(v[0], v[1]), pack2(v[2], v[3]));
+          if (STORE == 2) stage16(pt, t, q, pack2(v[0], v[1]), pack2(v[2], v[3]));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
