@@ -103,15 +103,9 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 #ifndef SN_ABL_NO_EMB_STORE
   if (STORE && INPUT_MODE == 0) {                // rows are allocated for whole 128-point tiles: no predicate.  (Pre-embedded
                                                  // rows, INPUT_MODE 1: the caller builds emb itself, it is a column re-layout of x)
-    float* er = emb + p_raw * 128;               // caller zero-fills emb: pad columns 63, 91..127 stay 0
     int hh = h;
-    asm volatile("" : "+v"(hh));                 // column selects stay inside the tile loop (hoisted they cost 32 VGPRs)
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
-      const int c = hh ? c1 : c0;
-      if (c >= 0) er[c] = xe[e];
-    }
+    asm volatile("" : "+v"(hh));                 // the half-dependent offsets stay inside the tile loop
+    store_emb_xyz(emb + p_raw * 128, xe, hh);    // columns [0, 63); the pad columns 63, 91..127 are never read back
   }
 #endif
 
@@ -255,15 +249,9 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   }
 #ifndef SN_ABL_NO_EMB_STORE
   if (STORE && INPUT_MODE == 0) {
-    float* er = emb + p_raw * 128;
     int hh = h;
     asm volatile("" : "+v"(hh));
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
-      const int c = hh ? c1 : c0;
-      if (c >= 0) er[64 + c] = de[e];
-    }
+    store_emb_dir(emb + p_raw * 128 + 64, de, hh);                 // columns [64, 91)
   }
 #endif
   // rgb head (nerf.py:144) accumulated from the softplus outputs while they are produced: 3 rows x this half's 64 K-slots

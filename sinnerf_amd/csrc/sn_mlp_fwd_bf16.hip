@@ -138,14 +138,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       }
       if (STORE && INPUT_MODE == 0) {            // rows are allocated for whole 256-point tiles: no predicate.  (Pre-embedded
                                                  // rows, INPUT_MODE 1: the caller builds emb itself, it is a column re-layout of x)
-        float* er = emb + p_raw[pt] * 128;       // caller zero-fills emb: pad columns 63, 91..127 stay 0
-        const int hs = ht;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-          const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
-          const int c = hs ? c1 : c0;
-          if (c >= 0) er[c] = f[e];
-        }
+        store_emb_xyz(emb + p_raw[pt] * 128, f, ht);   // columns [0, 63); the pad columns 63, 91..127 are never read back
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -372,16 +365,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           f[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
         }
       }
-      if (STORE && INPUT_MODE == 0) {
-        float* er = emb + p_raw[pt] * 128;
-        const int hs = ht;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
-          const int c = hs ? c1 : c0;
-          if (c >= 0) er[64 + c] = f[e];
-        }
-      }
+      if (STORE && INPUT_MODE == 0) store_emb_dir(emb + p_raw[pt] * 128 + 64, f, ht);      // columns [64, 91)
       de[0 * PT + pt] = pack8(f);
       de[1 * PT + pt] = pack8(f + 8);
       asm volatile("" : "+v"(de[0 * PT + pt]), "+v"(de[1 * PT + pt]));
