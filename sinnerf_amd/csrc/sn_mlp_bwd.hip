@@ -104,7 +104,12 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
   __syncthreads();                                                           \
   ++s;
-  // forward activation tile for the derivative mask (same 4 x float4 pattern as the forward's store)
+  // forward activation tile for the derivative mask (same 4 x float4 pattern as the forward's store).
+  // (Measured and dropped for this fp32 kernel: reading the masks as per-tile sign words written by the training forward, as
+  //  the bf16-state chain does.  These accumulator-layout loads cost 0.39 of 5.05 ms (timing build without them), but applying a
+  //  mask bit to an fp32 value takes 4 VALU instructions against the 2 of compare + select on the loaded activation, and
+  //  the forward pays 2 more per value to collect the bits: chain 4.86 -> 4.80, forward 5.11 -> 5.27 ms -- a net loss.
+  //  A bit-cast AND form of the mask (2 instructions) returned wrong values from the builtin-MFMA accumulators.)
 #define SNB_LOAD_ACT(slot, t)                                                                          \
   f32x4 av[4];                                                                                         \
   {                                                                                                    \
