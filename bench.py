@@ -134,12 +134,12 @@ HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/
 
 def train_hbm_roofline(ms_per_step, n_points):
     """`roofline` of the bf16 training step: algorithmic HBM bytes / step time against the HBM peak; `traffic` = the bytes
-    the PMC counters saw (profiles/r02_run2_train_pmc.json, FETCH_SIZE x2 + WRITE_SIZE of the three MLP stages)."""
+    the PMC counters saw (profiles/r02_run3_train_pmc.json, FETCH_SIZE x2 + WRITE_SIZE of the three MLP stages)."""
     traffic, note = None, "no PMC summary"
     try:
-        k = json.load(open(os.path.join(REPO, "profiles", "r02_run2_train_pmc.json")))["kernels"]
+        k = json.load(open(os.path.join(REPO, "profiles", "r02_run3_train_pmc.json")))["kernels"]
         per_pt = sum(v["bytes_per_point"] for name, v in k.items() if "bf16" in name)
-        traffic, note = per_pt * n_points, "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/r02_run2_train_pmc.json)"
+        traffic, note = per_pt * n_points, "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/r02_run3_train_pmc.json)"
     except Exception:                               # noqa: BLE001
         pass
     alg = TRAIN_BF16_BYTES_PER_POINT * n_points
