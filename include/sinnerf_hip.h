@@ -86,9 +86,15 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
  * whole point tiles without a predicate (rows >= n_points receive finite copies of the last point; their gradients are zero, so
  * sn_dw_gemm, which walks whole 16-point chunks, ignores them).
  * acts (10, slot_rows, 256): slots 0..7 = outputs of xyz_encoding_1..8 (post-ReLU), 8 = xyz_encoding_final,
- * 9 = dir_encoding output (128 wide, leading dimension 256).  emb (slot_rows, 128), ZERO-FILLED by the caller:
- * the kernel writes columns [0,63) = Embedding(xyz) and [64,91) = Embedding(dir) in the reference's column
- * order (nerf.py:36-41).                                                                                     */
+ * 9 = dir_encoding output (128 wide, leading dimension 256).  emb (slot_rows, 128): the kernel writes columns
+ * [0,63) = Embedding(xyz) and [64,91) = Embedding(dir) in the reference's column order (nerf.py:36-41) of every row
+ * of the whole point tiles; columns 63 and 91..127 are never written (nor read back by sn_weight_grads' results:
+ * zero-fill them only if you contract emb yourself).
+ * SN_DTYPE_BF16_STATE: the unused half of slot 9 (columns 128..255 of the bf16 array, 256 B per point) receives the ReLU
+ * SIGN WORDS of xyz_encoding_1..8 -- for the 64 consecutive points a wave owns, the 32-bit word of (layer l, 32-feature
+ * tile t) and lane L sits in row (first point + 8 l + t), bytes [256 + 4 L, 256 + 4 L + 4).  sn_mlp_backward_chain with
+ * SN_DTYPE_BF16_STATE takes its ReLU masks from these words (and reads no other activation but slot 9's values): pass it
+ * the acts array THIS entry wrote.                                                                             */
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                          float* out, float* acts, float* emb, long slot_rows, void* stream);
 
@@ -104,6 +110,8 @@ int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, l
  * gradient.  Writes g_acts (10, slot_rows, 256): slots 0..7 = dL/d(pre-activation) of xyz_encoding_1..8, 8 = of
  * xyz_encoding_final, 9 = of dir_encoding (128 wide); g_out (n_points,4) = dL/d(pre-activation) of rgb (3), sigma (1).
  * dtype SN_DTYPE_BF16: blob_bwd from the *_bwd_bf16 table, bf16-operand contractions, everything stored stays fp32.
+ * dtype SN_DTYPE_BF16_STATE: acts / g_acts are bf16 arrays; the ReLU masks come from the sign words sn_mlp_forward_train
+ * left in slot 9 (see there), gradients leave as whole 128-byte rows.
  * slot_rows as for sn_mlp_forward_train (>= n_points rounded up to 128, 256 for bf16; rows >= n_points of slots' 256
  * columns are written as zeros, the caller zero-fills the rest of the pad rows).  Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.   */
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,

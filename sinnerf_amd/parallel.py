@@ -68,7 +68,8 @@ class FlatGradBuffer:
         # these views (sn_weight_grads(accumulate=1), sinnerf_amd/autograd.py) instead of returning 24 tensors per network
         # for autograd's AccumulateGrad to add one launch at a time.  Per-parameter autograd hooks do not fire in that mode
         # (this class replaces DDP's hook-driven bucketing by one explicit all-reduce, so none are needed); it is taken only
-        # while every .grad still IS its view (sinnerf_amd.autograd._sink_of).
+        # while every .grad still IS its view (sinnerf_amd.autograd._sink_of).  Functional differentiation w.r.t. the parameters
+        # (torch.autograd.grad(loss, params)) needs the gradients RETURNED: build the buffer with sink=False for that.
         if sink:
             for m in modules:
                 if hasattr(m, "raw_tensors") and all(t.requires_grad for t in m.raw_tensors()):

@@ -183,6 +183,36 @@ def test_sample_pdf_merge_sorted_and_complete():
         assert (np.abs(zf - zf_ref) <= sample_pdf_tol(mid, w[:, 1:-1], uu))[ok].all()
 
 
+def test_sample_pdf_merge_with_ties_and_unsorted_samples():
+    """The merge-by-rank path (both lists ascending: one binary search per key) against sort(cat) on inputs full of TIES --
+    repeated coarse depths, samples that coincide with coarse depths, a degenerate ray (near == far: every key equal) -- and
+    the rank-sort fallback on rays whose samples are not ascending (random u), ray by ray in the same launch."""
+    from sinnerf_amd import _lib
+    r = np.random.RandomState(11)
+    S, NI = 64, 64
+    n = 96
+    near = r.uniform(1.5, 2.5, n).astype(np.float32); far = (near + r.uniform(0.5, 4, n)).astype(np.float32)
+    far[:8] = near[:8]                                                       # degenerate rays: coarse depths equal up to rounding
+    t = np.linspace(0, 1, S, dtype=np.float32)
+    zc = (near[:, None] * (1 - t) + far[:, None] * t).astype(np.float32)
+    zc[8:24, 10:20] = zc[8:24, 10:11]                                        # runs of equal coarse depths
+    zc = np.sort(zc, -1)
+    w = (r.uniform(0, 1, (n, S)) ** 4).astype(np.float32)
+    w[24:40] = 0                                                             # uniform pdf: det samples land on bin mid points
+    u = r.uniform(0, 1, (n, NI)).astype(np.float32)
+    u[:48] = np.sort(u[:48], -1)                                             # first half: ascending u -> ascending samples (merge path)
+    u[40:48, 5:30] = u[40:48, 5:6]                                           # ... with repeated samples
+    for use_u in (True, False):
+        zc_d, w_d = torch.from_numpy(zc).to(dev()), torch.from_numpy(w).to(dev())
+        u_d = torch.from_numpy(u).to(dev()) if use_u else None
+        zf = torch.empty((n, NI), device=dev()); zm = torch.empty((n, S + NI), device=dev())
+        _lib.check(_lib.lib.sn_sample_pdf(_lib.ptr(zc_d), _lib.ptr(w_d), _lib.ptr(u_d), n, S, NI, _lib.ptr(zf), _lib.ptr(zm), None), "sn_sample_pdf")
+        torch.cuda.synchronize()
+        zf_h, zm_h = zf.cpu().numpy(), zm.cpu().numpy()
+        assert np.isfinite(zm_h).all()
+        assert np.array_equal(zm_h, np.sort(np.concatenate([zc, zf_h], -1), -1)), use_u      # exactly the sorted multiset
+
+
 @pytest.mark.parametrize("name", ["render_lego_eval_teacher", "render_llff_eval_128", "render_lego_train_teacher"])
 def test_sample_pdf_on_real_render_cases_exclusion_fraction(name):
     """the knot-exclusion of the sample_pdf comparisons (helpers.well_conditioned) must stay a small,

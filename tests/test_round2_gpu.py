@@ -274,3 +274,43 @@ def test_train_step_replayed_from_hip_graph_equals_eager():
     losses = [float(sysm.train_step(batches[0], graph=True)["loss"]) for _ in range(12)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     assert len(set(losses)) == len(losses)                                    # fresh random draws on every replay
+
+
+def test_gradient_sink_is_skipped_for_frozen_or_detached_parameters():
+    """The sink is only taken while EVERY parameter that needs a gradient still has its flat-buffer view as .grad: a frozen
+    parameter simply receives nothing; a parameter whose .grad was replaced makes the backward fall back to returning the
+    gradients (autograd accumulates them as usual) -- same numbers either way."""
+    from sinnerf_amd.system import SinNeRFSystem
+    d = dev()
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::411][:256]).to(d)
+    rgbs = torch.rand((rays.shape[0], 3), device=d)
+    torch.manual_seed(0)
+    ref = SinNeRFSystem(N_importance=64, perturb=0.0, noise_std=0.0).to(d)
+    ref.configure_optimizers()
+    ref.optimizer.zero_grad()
+    ref.training_step({"rays": rays, "rgbs": rgbs})["loss"].backward()
+    want = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    # (a) frozen parameter
+    torch.manual_seed(0)
+    a = SinNeRFSystem(N_importance=64, perturb=0.0, noise_std=0.0).to(d)
+    a.nerf_fine.xyz_encoding_3[0].weight.requires_grad_(False)
+    a.configure_optimizers()
+    a.optimizer.zero_grad()
+    a.training_step({"rays": rays, "rgbs": rgbs})["loss"].backward()
+    for n, p in a.named_parameters():
+        if n == "nerf_fine.xyz_encoding_3.0.weight":
+            assert p.grad is None
+        else:
+            assert torch.allclose(p.grad, want[n], rtol=1e-5, atol=1e-9), n
+    # (b) one .grad detached from the flat buffer: fallback route, autograd accumulates into the replacement
+    torch.manual_seed(0)
+    b = SinNeRFSystem(N_importance=64, perturb=0.0, noise_std=0.0).to(d)
+    b.configure_optimizers()
+    b.optimizer.zero_grad()
+    w = b.nerf_coarse.xyz_encoding_1[0].weight
+    w.grad = torch.zeros_like(w)
+    b.training_step({"rays": rays, "rgbs": rgbs})["loss"].backward()
+    for n, p in b.named_parameters():
+        assert torch.allclose(p.grad, want[n], rtol=1e-5, atol=1e-9), n
+    assert b._flat.sync_views() == 1                                          # ... and the step repairs the stray view
+    assert torch.allclose(b._flat.flat, ref._flat.flat, rtol=1e-5, atol=1e-9)
