@@ -169,10 +169,11 @@ int sn_composite_forward(const float* raw, int has_rgb, const float* z_vals, con
 int sn_sample_pdf(const float* z_vals, const float* weights, const float* u, long n_rays, int n_samples,
                   int n_importance, float* z_fine, float* z_merged, void* stream);
 
-/* ---- models/rendering.py:15-61  sample_pdf(bins, weights, N_importance, det) exactly as the reference exposes
- * it: bins (n_rays, n_bins+1), weights (n_rays, n_bins) -> samples (n_rays, n_importance); u as above.       */
+/* ---- models/rendering.py:15-61  sample_pdf(bins, weights, N_importance, det, eps) exactly as the reference exposes
+ * it: bins (n_rays, n_bins+1), weights (n_rays, n_bins) -> samples (n_rays, n_importance); u as above; eps > 0 (the
+ * reference default 1e-5 is what render_rays uses, rendering.py:311).                                          */
 int sn_sample_pdf_bins(const float* bins, const float* weights, const float* u, long n_rays, int n_bins,
-                       int n_importance, float* samples, void* stream);
+                       int n_importance, float eps, float* samples, void* stream);
 
 /* ==== "next" rows: the steps immediately before / after the hot path ========================== */
 

@@ -54,7 +54,7 @@ SIGNATURES = {
     "sn_mlp_forward_embedded": (_int, [c_vp, _int, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
     "sn_composite_forward": (_int, [c_fp, _int, c_fp, c_fp, c_fp, _float, _long, _int, _int, c_fp, c_fp, c_fp, c_vp]),
     "sn_sample_pdf": (_int, [c_fp, c_fp, c_fp, _long, _int, _int, c_fp, c_fp, c_vp]),
-    "sn_sample_pdf_bins": (_int, [c_fp, c_fp, c_fp, _long, _int, _int, c_fp, c_vp]),
+    "sn_sample_pdf_bins": (_int, [c_fp, c_fp, c_fp, _long, _int, _int, _float, c_fp, c_vp]),
 }
 
 

@@ -41,7 +41,7 @@ int sn_composite_forward_launch(const float* raw, int has_rgb, const float* z_va
 int sn_sample_pdf_launch(const float* z_vals, const float* weights, const float* u, long n_rays, int n_samples,
                          int n_importance, float* z_fine, float* z_merged, hipStream_t stream);
 int sn_sample_pdf_bins_launch(const float* bins, const float* weights, const float* u, long n_rays, int n_bins,
-                              int n_importance, float* samples, hipStream_t stream);
+                              int n_importance, float eps, float* samples, hipStream_t stream);
 }
 
 namespace {
@@ -282,9 +282,9 @@ int sn_sample_pdf(const float* z_vals, const float* weights, const float* u, lon
 }
 
 int sn_sample_pdf_bins(const float* bins, const float* weights, const float* u, long n_rays, int n_bins,
-                       int n_importance, float* samples, void* stream) {
-  if (!bins || !weights || !samples || n_rays < 0) return SN_E_BADARG;
-  return sn_sample_pdf_bins_launch(bins, weights, u, n_rays, n_bins, n_importance, samples, (hipStream_t)stream);
+                       int n_importance, float eps, float* samples, void* stream) {
+  if (!bins || !weights || !samples || n_rays < 0 || !(eps > 0.0f)) return SN_E_BADARG;
+  return sn_sample_pdf_bins_launch(bins, weights, u, n_rays, n_bins, n_importance, eps, samples, (hipStream_t)stream);
 }
 
 }  // extern "C"

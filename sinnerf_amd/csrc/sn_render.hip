@@ -261,7 +261,7 @@ composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z_
 template <bool FROM_Z>
 __global__ void __launch_bounds__(256)
 sample_pdf_kernel(const float* __restrict__ z_vals, const float* __restrict__ weights, const float* __restrict__ u_in,
-                  long n_rays, int S, int NI, float* __restrict__ z_fine_out, float* __restrict__ z_merged_out) {
+                  long n_rays, int S, int NI, float eps, float* __restrict__ z_fine_out, float* __restrict__ z_merged_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -276,7 +276,6 @@ sample_pdf_kernel(const float* __restrict__ z_vals, const float* __restrict__ we
   float* merged = keys + n;                  // the sorted depths are scattered here and leave as coalesced rows
   if (ray >= n_rays) return;                 // whole wave exits together (no block-level barrier below)
   const long base = FROM_Z ? ray * (long)S : ray * (long)M - 1;   // weights[base + k + 1] = pdf weight k
-  const float eps = 1e-5f;
 
   // pdf -> cdf: lanes own C consecutive bins
   const int C = (M + 63) / 64;
@@ -400,7 +399,7 @@ extern "C" int sn_composite_forward_launch(const float* raw, int has_rgb, const 
   using namespace snr;
   if (n_rays <= 0) return 0;
   const int C = (n_samples + 63) / 64;
-  if (C < 1 || C > 8) return -4;
+  if (C < 1 || C > 16) return -4;
   const long blocks = (n_rays + 3) / 4;
   if (blocks > 0x7fffffffL) return -2;
   dim3 grid((unsigned)blocks), block(256);
@@ -411,7 +410,8 @@ extern "C" int sn_composite_forward_launch(const float* raw, int has_rgb, const 
     else hipLaunchKernelGGL((composite_fwd_kernel<CC, false>), grid, block, 0, stream, raw, z_vals, rays, noise,  \
                             noise_std, n_rays, n_samples, white_back, rgb, depth, weights);                      \
     break;
-  switch (C) { SN_CL(1) SN_CL(2) SN_CL(3) SN_CL(4) SN_CL(5) SN_CL(6) SN_CL(7) SN_CL(8) }
+  switch (C) { SN_CL(1) SN_CL(2) SN_CL(3) SN_CL(4) SN_CL(5) SN_CL(6) SN_CL(7) SN_CL(8) SN_CL(9) SN_CL(10) SN_CL(11) SN_CL(12)
+               SN_CL(13) SN_CL(14) SN_CL(15) SN_CL(16) }
 #undef SN_CL
   return (int)hipGetLastError();
 }
@@ -423,7 +423,7 @@ extern "C" int sn_composite_backward_launch(const float* raw, const float* z_val
   using namespace snr;
   if (n_rays <= 0) return 0;
   const int C = (n_samples + 63) / 64;
-  if (C < 1 || C > 8) return -4;
+  if (C < 1 || C > 16) return -4;
   const long blocks = (n_rays + 3) / 4;
   if (blocks > 0x7fffffffL) return -2;
   dim3 grid((unsigned)blocks), block(256);
@@ -432,7 +432,8 @@ extern "C" int sn_composite_backward_launch(const float* raw, const float* z_val
     hipLaunchKernelGGL((composite_bwd_kernel<CC>), grid, block, 0, stream, raw, z_vals, rays, noise, noise_std, n_rays, \
                        n_samples, white_back, g_rgb, g_depth, g_w, g_raw);                                       \
     break;
-  switch (C) { SN_CB(1) SN_CB(2) SN_CB(3) SN_CB(4) SN_CB(5) SN_CB(6) SN_CB(7) SN_CB(8) }
+  switch (C) { SN_CB(1) SN_CB(2) SN_CB(3) SN_CB(4) SN_CB(5) SN_CB(6) SN_CB(7) SN_CB(8) SN_CB(9) SN_CB(10) SN_CB(11) SN_CB(12)
+               SN_CB(13) SN_CB(14) SN_CB(15) SN_CB(16) }
 #undef SN_CB
   return (int)hipGetLastError();
 }
@@ -447,13 +448,13 @@ extern "C" int sn_sample_pdf_launch(const float* z_vals, const float* weights, c
   const size_t lds = 4 * (size_t)(2 * (n_samples - 1) + 2 * (n_samples + n_importance)) * sizeof(float);
   if (lds > 64 * 1024) return -4;
   hipLaunchKernelGGL(snr::sample_pdf_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, stream, z_vals, weights, u,
-                     n_rays, n_samples, n_importance, z_fine, z_merged);
+                     n_rays, n_samples, n_importance, 1e-5f /* render_rays calls sample_pdf with its default eps */, z_fine, z_merged);
   return (int)hipGetLastError();
 }
 
 // bins (n_rays, n_bins+1), weights (n_rays, n_bins): the standalone sample_pdf of rendering.py:15-61
 extern "C" int sn_sample_pdf_bins_launch(const float* bins, const float* weights, const float* u, long n_rays,
-                                         int n_bins, int n_importance, float* samples, hipStream_t stream) {
+                                         int n_bins, int n_importance, float eps, float* samples, hipStream_t stream) {
   if (n_rays <= 0) return 0;
   if (n_bins < 1 || n_importance < 1) return -5;
   const int S = n_bins + 2;
@@ -462,6 +463,6 @@ extern "C" int sn_sample_pdf_bins_launch(const float* bins, const float* weights
   const size_t lds = 4 * (size_t)(2 * (S - 1) + S + n_importance) * sizeof(float);
   if (lds > 64 * 1024) return -4;
   hipLaunchKernelGGL(snr::sample_pdf_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, bins, weights, u,
-                     n_rays, S, n_importance, samples, (float*)nullptr);
+                     n_rays, S, n_importance, eps, samples, (float*)nullptr);
   return (int)hipGetLastError();
 }

@@ -188,14 +188,14 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
     """Drop-in for reference ``models/rendering.py:15-61``: bins (N, M+1), weights (N, M) -> (N, N_importance)."""
     if not bins.is_cuda:
         raise RuntimeError("sinnerf_amd.sample_pdf: CUDA/ROCm tensors only (no CPU fallback)")
-    if abs(eps - 1e-5) > 1e-12:
-        raise NotImplementedError("sample_pdf: eps is fixed to the reference default 1e-5")
+    if not eps > 0:
+        raise ValueError("sample_pdf: eps must be positive")
     n, m = weights.shape
     bins = bins.contiguous().float()
     weights = weights.detach().contiguous().float()
     with torch.cuda.device(bins.device):
         u = None if det else torch.rand((n, N_importance), device=bins.device)        # rendering.py:43
         out = torch.empty((n, N_importance), dtype=torch.float32, device=bins.device)
-        _lib.check(_lib.lib.sn_sample_pdf_bins(_lib.ptr(bins), _lib.ptr(weights), _lib.ptr(u), n, m, N_importance,
+        _lib.check(_lib.lib.sn_sample_pdf_bins(_lib.ptr(bins), _lib.ptr(weights), _lib.ptr(u), n, m, N_importance, float(eps),
                                                _lib.ptr(out), _lib.stream_ptr()), "sn_sample_pdf_bins")
     return out

@@ -117,7 +117,8 @@ def test_nerf_forward_embedded_golden():
 
 @pytest.mark.parametrize("S,white_back,noise_std,has_rgb", [(64, True, 0.0, True), (128, False, 1.0, True),
                                                             (192, True, 0.5, True), (24, False, 1.0, True),
-                                                            (64, True, 1.0, False), (100, False, 0.0, True)])
+                                                            (64, True, 1.0, False), (100, False, 0.0, True),
+                                                            (640, True, 0.5, True), (1000, False, 0.0, True)])
 def test_composite_vs_oracle(S, white_back, noise_std, has_rgb):
     from sinnerf_amd import rendering
     r = np.random.RandomState(S)
@@ -181,6 +182,23 @@ def test_sample_pdf_merge_sorted_and_complete():
         ok = well_conditioned(mid, w[:, 1:-1], uu)
         assert ok.mean() >= 0.97, ok.mean()                                        # the exclusion stays a small minority
         assert (np.abs(zf - zf_ref) <= sample_pdf_tol(mid, w[:, 1:-1], uu))[ok].all()
+
+
+@pytest.mark.parametrize("eps", [1e-5, 1e-3, 1e-7])
+def test_sample_pdf_eps_argument(eps):
+    """sample_pdf(bins, weights, N, det, eps) of rendering.py:15 with a non-default eps (pdf floor AND the denom < eps rule)."""
+    import sinnerf_amd
+    r = np.random.RandomState(3)
+    n, m, NI = 300, 40, 50
+    bins = np.sort(r.uniform(2, 6, (n, m + 1)).astype(np.float32), -1)
+    w = (r.uniform(0, 1, (n, m)) ** 6).astype(np.float32)                 # many tiny weights: eps matters
+    got = sinnerf_amd.sample_pdf(torch.from_numpy(bins).to(dev()), torch.from_numpy(w).to(dev()), NI, det=True, eps=eps).cpu().numpy()
+    ref = O.sample_pdf(bins, w, NI, det=True, eps=eps)
+    uu = O.linspace01(NI)[None].repeat(n, 0)
+    ok = well_conditioned(bins, w, uu, eps=eps)
+    assert ok.mean() >= 0.9
+    assert (np.abs(got - ref) <= sample_pdf_tol(bins, w, uu, eps=eps))[ok].all()
+    assert ((got >= bins[:, :1]) & (got <= bins[:, -1:])).all()
 
 
 def test_sample_pdf_merge_with_ties_and_unsorted_samples():
@@ -398,9 +416,12 @@ def test_empty_batch_and_unsupported_sizes():
     with torch.no_grad():
         res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.zeros((0, 8), device=dev()), 64, False, 0, 0, 64, 32768, True)
     assert res["rgb_fine"].shape == (0, 3) and res["opacity_fine"].shape == (0, 128) and res["depth_coarse"].shape == (0,)
-    with pytest.raises(SinnerfHipError):            # > 8 samples per lane: compositor refuses loudly
+    with torch.no_grad():                            # 600 samples per ray (10 per lane) render fine ...
+        r600 = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.rand((4, 8), device=dev()) + 1, 600, False, 0, 0, 0, 32768, True)
+    assert r600["opacity_coarse"].shape == (4, 600) and torch.isfinite(r600["rgb_coarse"]).all()
+    with pytest.raises(SinnerfHipError):            # ... > 16 samples per lane (1024 per ray): the compositor refuses loudly
         with torch.no_grad():
-            sinnerf_amd.render_rays([mc, mf], embeddings(), torch.rand((4, 8), device=dev()) + 1, 600, False, 0, 0, 0, 32768, True)
+            sinnerf_amd.render_rays([mc, mf], embeddings(), torch.rand((4, 8), device=dev()) + 1, 1100, False, 0, 0, 0, 32768, True)
     with pytest.raises(NotImplementedError):
         sinnerf_amd.NeRF(D=4, W=128, use_new_activation=True)
     with pytest.raises(NotImplementedError):
