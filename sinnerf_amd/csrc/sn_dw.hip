@@ -14,32 +14,13 @@
 // once per problem, so unlike the L2-resident weight slabs of the MLP kernels the DMA needs depth: a 4-deep LDS ring,
 // three chunks in flight, COUNTED s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the queue).
 // Partial results go to a per-task slab; the K-split partials are summed afterwards (deterministic, no atomics).
-#include "sn_device.h"
-#include "sn_launch.h"
+#include "sn_dw_common.h"
 
 namespace snd {
 
 #ifndef SN_DW_CPOL
 #define SN_DW_CPOL 2      // nt: G and X are streamed once (measured -3 % in the bandwidth-bound bf16 mode, neutral in fp32)
 #endif
-constexpr int KB = 16;                          // points per staged chunk
-constexpr int DW_LDS_BYTES = 4 * KB * (256 + 256) * 4;      // 131072: LDS ring, 4 chunks of the widest fp32 problem (depth per mode: run_task)
-
-struct Task {                                   // 64 bytes, built on the host (sinnerf_amd/autograd.py)
-  const void* a;                                // G  + column offset (fp32, or bf16 with 0x200)
-  const void* b;                                // X  + column offset (fp32; bf16 with 0x200 except in variants 1 / 3)
-  float* c;                                     // partial dW  [M_wg][ldc]
-  float* bias;                                  // partial db  [M_wg] or nullptr
-  long k0, k1;                                  // point range: (k1-k0) % 16 == 0, rows [k0,k1) readable (callers zero-pad G)
-  int lda, ldb;
-  int ldc, variant;                             // M x N: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64, 4 = 32x256, 5 = 32x128;
-                                                // | 0x100: bf16 operands (mixed-precision training), fp32 accumulate;
-                                                // | 0x200: G and the 256-wide activations are stored as bf16 (the embedded
-                                                //   inputs of variants 1 / 3 stay fp32); lda / ldb stay in ELEMENTS
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 // copy KB x W floats (row-major, W*4 bytes per row) global -> LDS.  A chunk past k_end (the ring's prefetch overrun) is
 // replaced by the last real chunk of the task ((k1-k0) % KB == 0) -- a wave-uniform select on the chunk base, so the
@@ -324,41 +305,9 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   }
 }
 
-// The whole network's contractions described by value (kernel arguments: no host-built table, no H2D copy, capturable in
-// a HIP graph): problem q = one dW = G^T X, split into ns K-ranges of `per` points, tasks [first, first + ns).
-struct Prob {
-  const void* a;
-  const void* b;
-  float* c;                                     // ns partial results, M*N floats apart
-  float* bias;                                  // ns partial column sums, M floats apart, or nullptr
-  int lda, ldb, ldc, variant;
-  int ns, per, first, m;
-};
-constexpr int MAX_PROBS = 14;
-struct Plan {
-  Prob p[MAX_PROBS];
-  long P;                                       // rows (points) of every operand
-  int n_probs, n_tasks;
-};
-
 __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks, const Plan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  Task t;
-  if (tasks != nullptr) {
-    t = tasks[blockIdx.x];
-  } else {
-    int q = 0;
-#pragma unroll 1
-    for (int i = 1; i < plan.n_probs; ++i) q = ((int)blockIdx.x >= plan.p[i].first) ? i : q;      // scalar loads of the kernarg segment
-    const Prob& pr = plan.p[q];
-    const int j = (int)blockIdx.x - pr.first;
-    t.a = pr.a; t.b = pr.b;
-    t.c = pr.c + (long)j * pr.m * pr.ldc;
-    t.bias = pr.bias ? pr.bias + (long)j * pr.m : nullptr;
-    t.k0 = (long)j * pr.per;
-    t.k1 = t.k0 + pr.per < plan.P ? t.k0 + pr.per : plan.P;
-    t.lda = pr.lda; t.ldb = pr.ldb; t.ldc = pr.ldc; t.variant = pr.variant;
-  }
+  const Task t = tasks != nullptr ? tasks[blockIdx.x] : task_of(plan, (int)blockIdx.x);
   const int tid = threadIdx.x;
   if (t.variant & 0x100) {
     const int mode = (t.variant & 0x200) ? 2 : 1;     // 0x200: G and the activations are stored as bf16
@@ -428,10 +377,27 @@ static const int COST_BF16_STATE[6] = {512, 343, 348, 226, 296, 190};
 constexpr int TARGET_WGS = 256;                 // one workgroup per CU
 
 struct HostPlan {
-  Plan plan;
+  Plan plan;                                    // all problems (task numbering of the single-launch modes)
   long c_off[MAX_PROBS], b_off[MAX_PROBS];      // workspace byte offsets of the partial buffers (b_off < 0: no bias)
   long bytes;
+  bool two_launches;                            // fp32: group 0 = the 256x256 problems (sn_dw_f32.hip), group 1 = the rest
+  int group[MAX_PROBS], first_in_group[MAX_PROBS];
 };
+// the problems of one group as a plan of their own (task numbering restarts at 0)
+static Plan group_plan(const HostPlan& hp, int g) {
+  Plan out;
+  out.P = hp.plan.P;
+  out.n_probs = 0;
+  out.n_tasks = 0;
+  for (int i = 0; i < hp.plan.n_probs; ++i) {
+    if (hp.group[i] != g) continue;
+    Prob q = hp.plan.p[i];
+    q.first = hp.first_in_group[i];
+    out.p[out.n_probs++] = q;
+    out.n_tasks += q.ns;
+  }
+  return out;
+}
 // problems in the order build_plan emits them
 enum { W0 = 0, W1 = 1, W2 = 2, W3 = 3, W4 = 4, W4E = 5, W5 = 6, W6 = 7, W7 = 8, WF = 9, WD = 10, WDE = 11, SIG = 12, RGB = 13 };
 
@@ -458,27 +424,37 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
   pr[n++] = {Gs(9, 0), emb + 64 * 4, 256, 128, 3, false};         // dir_encoding[:, 256:]
   pr[n++] = {Gs(9, 128), As(7), 256, 256, 4, false};              // sigma (nerf.py:136): row 3 of the 32-wide head block
   pr[n++] = {Gs(9, 128), As(9), 256, 256, 5, true};               // rgb (nerf.py:144): rows 0..2; bias = [g_rgb(3), g_sigma(1)]
-  double tot = 0;
-  for (int i = 0; i < n; ++i) tot += cost[pr[i].var];
+  // fp32: the 256x256 problems run in their own launch (sn_dw_f32.hip, hand-scheduled inner loop), the narrow ones in a second
+  // launch of the kernel above -- each group is K-split over one workgroup per CU by itself (group[i]: 0 / 1; other modes: one
+  // group, one launch)
+  int group[MAX_PROBS];
+  for (int i = 0; i < n; ++i) group[i] = (dtype == 0 && pr[i].var != 0) ? 1 : 0;
+  hp.two_launches = dtype == 0;
   int splits[MAX_PROBS];
-  double frac[MAX_PROBS];
-  int sum = 0;
-  for (int i = 0; i < n; ++i) {
-    const double ideal = TARGET_WGS * cost[pr[i].var] / tot;
-    splits[i] = (int)ideal < 1 ? 1 : (int)ideal;
-    frac[i] = ideal - (int)ideal;
-    sum += splits[i];
-  }
-  bool used[MAX_PROBS] = {};
-  while (sum < TARGET_WGS) {                                      // largest remainders get the slack
-    int best = -1;
-    for (int i = 0; i < n; ++i) if (!used[i] && (best < 0 || frac[i] > frac[best])) best = i;
-    if (best < 0) break;
-    used[best] = true; ++splits[best]; ++sum;
+  for (int gsel = 0; gsel < 2; ++gsel) {
+    double tot = 0;
+    for (int i = 0; i < n; ++i) if (group[i] == gsel) tot += cost[pr[i].var];
+    if (tot == 0) continue;
+    double frac[MAX_PROBS];
+    int sum = 0;
+    for (int i = 0; i < n; ++i) {
+      if (group[i] != gsel) continue;
+      const double ideal = TARGET_WGS * cost[pr[i].var] / tot;
+      splits[i] = (int)ideal < 1 ? 1 : (int)ideal;
+      frac[i] = ideal - (int)ideal;
+      sum += splits[i];
+    }
+    bool used[MAX_PROBS] = {};
+    while (sum < TARGET_WGS) {                                    // largest remainders get the slack
+      int best = -1;
+      for (int i = 0; i < n; ++i) if (group[i] == gsel && !used[i] && (best < 0 || frac[i] > frac[best])) best = i;
+      if (best < 0) break;
+      used[best] = true; ++splits[best]; ++sum;
+    }
   }
   const long max_split = rows / (4 * KB) < 1 ? 1 : rows / (4 * KB);
   long off = 0;
-  int first = 0;
+  int first = 0, first_g[2] = {0, 0};
   hp.plan.P = rows;
   hp.plan.n_probs = n;
   for (int i = 0; i < n; ++i) {
@@ -492,6 +468,9 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
     q.lda = pr[i].lda; q.ldb = pr[i].ldb; q.ldc = v.n; q.variant = pr[i].var | flags;
     q.ns = (int)ns; q.per = (int)per; q.first = first; q.m = v.m;
     first += (int)ns;
+    hp.group[i] = group[i];
+    hp.first_in_group[i] = first_g[group[i]];
+    first_g[group[i]] += (int)ns;
     hp.c_off[i] = off; off += ns * v.m * v.n * 4;
     hp.b_off[i] = pr[i].bias ? off : -1;
     if (pr[i].bias) off += ns * v.m * 4;
@@ -501,6 +480,8 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
 }
 
 }  // namespace snd
+
+extern "C" int sn_dw_f32_asm_launch(const snd::Plan* plan_host, hipStream_t stream);      // sn_dw_f32.hip
 
 extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype) {
   snd::HostPlan hp;
@@ -519,8 +500,16 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
     hp.plan.p[i].bias = hp.b_off[i] >= 0 ? (float*)(ws + hp.b_off[i]) : nullptr;
   }
   SN_ENSURE_DYN_LDS(dw_kernel, DW_LDS_BYTES);
-  hipLaunchKernelGGL(dw_kernel, dim3((unsigned)hp.plan.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, hp.plan);
-  int rc = (int)hipGetLastError();
+  int rc;
+  if (hp.two_launches) {
+    const Plan pa = group_plan(hp, 0), pb = group_plan(hp, 1);
+    rc = sn_dw_f32_asm_launch(&pa, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, pb);
+  } else {
+    hipLaunchKernelGGL(dw_kernel, dim3((unsigned)hp.plan.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, hp.plan);
+  }
+  rc = (int)hipGetLastError();
   if (rc) return rc;
   Segs sg;
   int n = 0, total = 0;

@@ -198,7 +198,8 @@ def test_weight_grads_entry_vs_fp64_contractions(mode):
         want = (rb if i % 2 else r).reshape(o.shape)
         assert torch.isfinite(o).all(), i
         err = ((o.double() - want).norm() / want.norm()).item()
-        assert err < (2e-6 if mode == "fp32" or i % 2 else 2e-5), (mode, i, err)
+        # fp32 sums over 4144 points split into up to ~100 K-ranges: 1e-5 covers the association order; bf16 operands 2e-5
+        assert err < (1e-5 if mode == "fp32" or i % 2 else 2e-5), (mode, i, err)
     _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(emb), _lib.ptr(G), rows, code, _lib.ptr(ws), arr, 1, None), "wg")
     torch.cuda.synchronize()
     for i, (o, f) in enumerate(zip(outs, first)):
