@@ -168,6 +168,11 @@ constexpr int act_reg(int set, int kstep, int pt) { return set * 128 + (kstep * 
 //              (NK % 4 == 0 everywhere except the four dir_encoding slabs, whose phases 0,2,0,2 are still static).
 //   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead): compile-time -> no DMA branches
 //              (a K = 288 slab ends in a half piece that only waves 0,1 carry).
+//              (Measured and dropped for the bf16-state chain: a COUNTED protocol -- post_sync behind the slab's last DMA piece
+//              with its row stores last, s_waitcnt vmcnt(8) in front of the next epilogue so that the rows stay in flight, a raw
+//              s_barrier, every LDS access near the pieces as inline asm so that hipcc does not guard it with vmcnt(0) --
+//              removed 39 of 74 full drains from the code and changed nothing: 1.04 ms either way.  The waves' parked time
+//              (PMC SQ_WAIT_ANY 44 %) is not the store drain; non-temporal stores are acknowledged by the L2 quickly.)
 //   post_sync  run right after the sync point: the training kernels issue their HBM traffic here (activation-tile stores /
 //              loads) so that it has a whole slab to complete before the next s_waitcnt vmcnt(0) -- issued just in front of
 //              the sync point it exposes the full HBM latency on every slab (measured: 3.9 us per slab instead of ~1)
