@@ -109,7 +109,7 @@ int sn_build_pack_table(int dtype, int32_t* table_host) {
 }
 
 long sn_packed_weights_bytes_bwd(void) { return snl::bblob_bytes(); }
-long sn_pack_table_entries_bwd(void) { return snl::B_TOTAL_ELEMS; }
+long sn_pack_table_entries_bwd(void) { return snl::b_table_entries(); }
 int sn_build_pack_table_bwd(int32_t* table_host) {
   if (!table_host) return SN_E_BADARG;
   snl::build_pack_table_bwd(reinterpret_cast<snl::PackEntry*>(table_host));

@@ -199,24 +199,27 @@ inline void build_pack_table(int dt, PackEntry* out) {
 // ================================================================================================
 // Backward-chain blob: TRANSPOSED weights for  g_x[in_feature, point] = W^T * g_y   (same register-resident
 // scheme as the forward: the masked accumulators of one transposed layer are the B operand of the next).
-// Slabs in execution order (one 32-row tile of INPUT features x padded K of OUTPUT features in K-slot order):
-//   0.. 3  RGBT  K= 32  rows = h2 features (inputs of rgb.0);          k-slots: rows 0..2 of the rgb tile
-//   4..11  DIRT  K=128  rows = final features (dir_encoding.0[:, :256]) k-slots: 4 tiles of g_y2
-//  12..19  FINT  K=288  rows = h8 features; k = [g_final (256) | sigma tile (32: slot 0 / half 0 = g_sigma)]
-//  20..75  LT    K=256  layers i = 7,6,5,4,3,2,1 (xyz_encoding_{i+1}^T), 8 tiles each, rows = hidden inputs of layer i
+// Slabs in execution order (one 32-row tile of INPUT features x K of OUTPUT features in K-slot order):
+//   0.. 7  DIRT  K=128  rows = final features (dir_encoding.0[:, :256]^T)   k-slots: g_y2 (128)
+//   8..15  FINT  K=256  rows = h8 features (xyz_encoding_final^T)           k-slots: g_final (256)
+//  16..71  LT    K=256  layers i = 7,6,5,4,3,2,1 (xyz_encoding_{i+1}^T), 8 tiles each, rows = hidden inputs of layer i
 //                       (for the skip layer i=4 the hidden part = columns 63..318 of its weight, nerf.py:133)
-// fp32 only (the training path of configs[1] is fp32); no bias area.
-constexpr int NB_SLABS = 76;
-constexpr int BSLAB_DIRT = 4, BSLAB_FINT = 12, BSLAB_LT = 20;
-constexpr int bslab_k(int s) { return s < 4 ? 32 : s < 12 ? 128 : s < 20 ? 288 : 256; }
-constexpr long bslab_elem_offset(int s) {
-  long o = 0;
-  for (int i = 0; i < s; ++i) o += 32 * bslab_k(i);
-  return o;
-}
+// followed by a tail: 64 zeros (the slab pipeline's "bias" slot: these layers have no bias term) and the aux table of the
+// two narrow transposed heads, applied on the VALU like in the forward:
+//   rgbT[3][2][64] (rgb.0.weight[c][f], f = K-slot order of the 128 h2 features) | sigT[2][128] (sigma.weight[f]).
+// fp32 (the training path of configs[1]); the bf16-operand chain has its own blob below.
+constexpr int NB_SLABS = 72;
+constexpr int BSLAB_FINT = 8, BSLAB_LT = 16;
+constexpr int bslab_k(int s) { return s < 8 ? 128 : 256; }
+constexpr long bslab_elem_offset(int s) { return s < 8 ? (long)s * 32 * 128 : 8L * 32 * 128 + (long)(s - 8) * 32 * 256; }
 constexpr long B_TOTAL_ELEMS = bslab_elem_offset(NB_SLABS);
-constexpr long bblob_bytes() { return B_TOTAL_ELEMS * 4; }
-constexpr int B_MAX_SLAB_K = 288;
+constexpr int B_ZERO_FLOATS = 64;
+constexpr int B_AUX_RGBT = 0, B_AUX_SIGT = 384, B_AUX_FLOATS = 640;
+constexpr int B_TAIL_FLOATS = B_ZERO_FLOATS + B_AUX_FLOATS;                      // 704 floats = 2816 B
+constexpr long b_tail_byte_offset() { return B_TOTAL_ELEMS * 4; }
+constexpr long bblob_bytes() { return b_tail_byte_offset() + (long)B_TAIL_FLOATS * 4; }
+constexpr long b_table_entries() { return B_TOTAL_ELEMS + B_TAIL_FLOATS; }
+constexpr int B_MAX_SLAB_K = 256;
 
 inline void build_pack_table_bwd(PackEntry* out) {
   long n = 0;
@@ -227,17 +230,11 @@ inline void build_pack_table_bwd(PackEntry* out) {
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 4; ++j) {
           const int i = lane & 31, h = lane >> 5, q = 4 * g + j;
-          int32_t src = -1;
-          if (s < BSLAB_DIRT) {                               // rgb.0^T : W_r (3 x 128)
-            const int out_f = acc_row(q, h), in_f = 32 * s + i;
-            if (out_f < 3) src = (RAW_RGB << 20) | (out_f * 128 + in_f);
-          } else if (s < BSLAB_FINT) {                        // dir_encoding.0^T : W_d (128 x 283), cols 0..255
-            const int out_f = hid_slot_feature(q, h), in_f = 32 * (s - BSLAB_DIRT) + i;
-            src = (RAW_DIR << 20) | (out_f * 283 + in_f);
-          } else if (s < BSLAB_LT) {                          // [xyz_encoding_final ; sigma]^T
-            const int in_f = 32 * (s - BSLAB_FINT) + i;
-            if (q < 128) src = (RAW_FIN << 20) | (hid_slot_feature(q, h) * 256 + in_f);
-            else if (q == 128 && h == 0) src = (RAW_SIG << 20) | in_f;
+          int32_t src;
+          if (s < BSLAB_FINT) {                               // dir_encoding.0^T : W_d (128 x 283), cols 0..255
+            src = (RAW_DIR << 20) | (hid_slot_feature(q, h) * 283 + 32 * s + i);
+          } else if (s < BSLAB_LT) {                          // xyz_encoding_final^T
+            src = (RAW_FIN << 20) | (hid_slot_feature(q, h) * 256 + 32 * (s - BSLAB_FINT) + i);
           } else {                                            // xyz_encoding_{li+1}^T, li = 7..1
             const int li = 7 - (s - BSLAB_LT) / 8, t = (s - BSLAB_LT) % 8;
             const int ncol = raw_cols(2 * li), coloff = (li == 4) ? 63 : 0;
@@ -248,6 +245,21 @@ inline void build_pack_table_bwd(PackEntry* out) {
           e.src = src;
           out[n++] = e;
         }
+  }
+  const long tail = b_tail_byte_offset();
+  for (int a = 0; a < B_TAIL_FLOATS; ++a) {
+    PackEntry e;
+    e.dst = (int32_t)(tail + (long)a * 4);
+    e.src = -2;
+    const int x = a - B_ZERO_FLOATS;
+    if (x >= B_AUX_RGBT && x < B_AUX_SIGT) {                  // rgbT[c][h][q], q < 64
+      const int c = x / 128, h = (x % 128) / 64, q = x % 64;
+      e.src = SRC_F32_FLAG | (RAW_RGB << 20) | (c * 128 + hid_slot_feature(q, h));
+    } else if (x >= B_AUX_SIGT) {                             // sigT[h][q], q < 128
+      const int h = (x - B_AUX_SIGT) / 128, q = (x - B_AUX_SIGT) % 128;
+      e.src = SRC_F32_FLAG | (RAW_SIG << 20) | hid_slot_feature(q, h);
+    }
+    out[n++] = e;
   }
 }
 

@@ -6,45 +6,11 @@
 
 namespace snk {
 
-constexpr int BIAS_LDS_BYTES = 10240;                       // 78*32*4 = 9984, padded
-constexpr int SLAB_LDS_BYTES_F32 = snl::MAX_SLAB_K * 128;   // 40960
-constexpr int MLP_F32_LDS_BYTES = BIAS_LDS_BYTES + 2 * SLAB_LDS_BYTES_F32;   // 92160
-
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
-// ---- slab staging of the double-buffered backward chain: copy n_iter*4096 bytes global -> LDS by
-// global_load_lds_dwordx4 (LDS address = wave-uniform base + lane*16, no VGPR round trip), 16 B per thread per iteration
-struct Stager {
-  SN_DEV void issue(const char* __restrict__ g, char* lds, int n_iter, int tid) {
-    char* lw = lds + __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
-#pragma unroll
-    for (int i = 0; i < 10; ++i)
-      if (i < n_iter)
-        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(g + i * 4096 + tid * 16), (lds_void*)(lw + i * 4096), 16, 0, 0);
-  }
-};
-
 __device__ __forceinline__ int slab_k_rt(int s) {
   return s < 8 ? snl::K_L0 : s < 32 ? snl::K_HID : s < 40 ? snl::K_SKIP : s < 72 ? snl::K_HID : snl::K_DIR;
-}
-
-// NG groups of 4 k-steps: one ds_read_b128 (4 A operands) + 4 MFMAs per group.  The A fragments of group
-// g+1 are requested before the MFMAs of group g issue, so the LDS latency hides under 4x64 MFMA cycles.
-template <int NG>
-SN_DEV void mma_f32(f32x16& acc, const char* lds_lane, const float* b) {
-  f32x4 a_cur = *reinterpret_cast<const f32x4*>(lds_lane);
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    f32x4 a_nxt;
-    if (g + 1 < NG) a_nxt = *reinterpret_cast<const f32x4*>(lds_lane + (g + 1) * 1024);
-    __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this group's MFMAs
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[4 * g + 0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b[4 * g + 1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b[4 * g + 2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b[4 * g + 3], acc, 0, 0, 0);
-    if (g + 1 < NG) a_cur = a_nxt;
-  }
 }
 
 SN_DEV f32x16 load_bias(const float* lds_bias, int s, int h) {

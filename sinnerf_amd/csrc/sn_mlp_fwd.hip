@@ -167,16 +167,18 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   // the slab TWO ahead in the stream: K/32 -> 2 (xyz_encoding_1), 8 (256-wide), 10 (skip), 9 (dir_encoding).
 #define SN_SLAB(T_, NG0_, NG1_, S0_, S1_, GB_, NP_, BV_, EPI_, W_, SLOT_)                                          \
   do {                                                                                                             \
+    /* training forward: DMA pieces in [GB, LS), the four row stores in the groups behind them (sn_mlp_pipe.h) */  \
+    constexpr int LS_ = !STORE ? -1 : ((NG0_) + (NG1_) == 8) ? 4 : (GB_) + (NP_);                                  \
     if (((T_) & 1) == 0)                                                                                           \
-      slab_f32a<NG0_, NG1_, S0_, S1_, GB_, NP_>(acc0, acc1, af, SN_LW_CUR, BV_, SN_LW_NEXT, lds_bias,              \
+      slab_f32a<NG0_, NG1_, S0_, S1_, GB_, NP_, LS_>(acc0, acc1, af, SN_LW_CUR, BV_, SN_LW_NEXT, lds_bias,    \
           (s + 1 == n_used ? 0 : s + 1), h, ring,                                                                  \
           [&](int q) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SN_W(W_), SLOT_, (T_) - 1, q, acc1); },   \
-          [&](int i) __attribute__((always_inline)) { if ((T_) > 0) store_rows(SLOT_, (T_) - 1, i); });            \
+          [&](int i) __attribute__((always_inline)) { if ((T_) > 0 && i < 4) store_rows(SLOT_, (T_) - 1, i); });   \
     else                                                                                                           \
-      slab_f32a<NG0_, NG1_, S0_, S1_, GB_, NP_>(acc1, acc0, af, SN_LW_CUR, BV_, SN_LW_NEXT, lds_bias,              \
+      slab_f32a<NG0_, NG1_, S0_, S1_, GB_, NP_, LS_>(acc1, acc0, af, SN_LW_CUR, BV_, SN_LW_NEXT, lds_bias,    \
           (s + 1 == n_used ? 0 : s + 1), h, ring,                                                                  \
           [&](int q) __attribute__((always_inline)) { EPI_(SN_W(W_), SLOT_, (T_) - 1, q, acc0); },                 \
-          [&](int i) __attribute__((always_inline)) { store_rows(SLOT_, (T_) - 1, i); });                          \
+          [&](int i) __attribute__((always_inline)) { if (i < 4) store_rows(SLOT_, (T_) - 1, i); });               \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
   } while (0)
   // the 8 output tiles of a layer; tiles 6,7 stage the NEXT layer's slabs (NPB_); the last tile's epilogue is not deferred

@@ -14,8 +14,8 @@
 // The transition slab s -> s+1 needs no barrier: the bias of slab s+1 and its first A fragment are requested while
 // the last MFMAs of slab s are still issuing, the accumulator epilogue of slab s (ReLU, moves, activation stores) runs
 // under the first MFMAs of slab s+1, and the barrier itself waits under an MFMA that is already in flight.
-// (First generation = Stager in sn_mlp_common.h: double buffer, barrier + DMA issue + bias/fragment reload on the
-//  critical path at every slab boundary -- 85 % MFMA-busy; see profiles/r01_run2_pmc.json.)
+// (First generation: double buffer, barrier + DMA issue + bias/fragment reload on the critical path at every slab
+//  boundary -- 85 % MFMA-busy; see profiles/r01_run2_pmc.json.)
 #pragma once
 #include "sn_mlp_common.h"
 
@@ -131,7 +131,14 @@ typedef RingT<128, RING_SLOT_BYTES> Ring;          // fp32 weights: 128 B per K 
 // non-MFMA work of a group is dealt over its four gaps --
 //     MFMA0 | A-fragment prefetch | MFMA1 | one DMA piece | MFMA2 | epilogue slice / activation-store step | MFMA3
 // pending(i), i = 0..3: slice i (4 accumulator registers) of the previous slab's epilogue, run in groups 0..3;
-// late(i), i = 0..3: the training forward's row-group store of that tile, run in groups 4..7.
+// late(i), i = 0..7 (groups S0 .. S0+7): the memory steps of the training kernels -- the row-group stores of the previous
+// tile (steps 0..3) and, in the backward chain, the requests of the next activation tile (steps 4..7).
+// ONE vector-memory instruction per group and per wave: the DMA pieces of the slab go to the groups [GB, S0) before them
+// (two or three per group saturate the CU's address path and stall MFMA issue), and the chain's scattered activation
+// loads (64 cache lines per instruction) come LAST: whatever is issued behind them queues up in the address path
+// (measured on the chain, 4.4 ms of MFMAs: stores+loads beside the pieces 4.82-5.15 ms, pieces | loads | stores 4.98,
+// pieces | stores | loads 4.77).  Waiting with a counted vmcnt for everything but the youngest stores (fence-less barrier,
+// loads in inline asm) was measured too: no gain, dropped.
 // The compiler does not know the asm is an MFMA: the MFMA -> VALU-read hazard (18 wait states for this 16-pass MFMA) is kept
 // by construction -- pending(0) sits behind three MFMAs of the NEXT slab, at a layer end an explicit s_nop run is used.
 // FIRST = first MFMA of a slab: its C operand may have just been written by compiler-inserted VALU copies (accumulator
@@ -150,12 +157,14 @@ SN_DEV void mma32_v(f32x16& acc, float a, float b) {       // ... B in a VGPR
 // (the softplus epilogue) could otherwise be scheduled above the wait.
 SN_DEV void mfma32_result_fence(f32x16& acc) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc)); }
 
-template <int NG0, int NG1, int SET0, int SET1, int GB, int NP, class Pending, class Late>
+template <int NG0, int NG1, int SET0, int SET1, int GB, int NP, int S0 = -1, class RingX, class Pending, class Late>
 SN_DEV void slab_f32a(f32x16& acc, f32x16& accn, f32x4 (&af)[2], const char* lw, const float* bv, const char* lw_next,
-                      const float* lds_bias, int s_next, int h, Ring& ring, Pending&& pending, Late&& late) {
+                      const float* lds_bias, int s_next, int h, RingX& ring, Pending&& pending, Late&& late) {
   constexpr int NG = NG0 + NG1;
-  constexpr int PPG = (NP + (NG - GB) - 1) / (NG - GB);      // DMA pieces per group after the sync point
+  constexpr int GL = S0 < 0 ? NG : S0;                       // first group of the late steps; DMA pieces go to [GB, GL)
+  constexpr int PPG = (NP + (GL - GB) - 1) / (GL - GB);      // DMA pieces per group of that window
   static_assert(GB >= 2 && GB % 2 == 0 && GB <= 4 && NG >= 8 && NG % 2 == 0, "sync point inside the slab; fragments come in pairs");
+  static_assert(GL >= 4 && GL > GB && GL <= NG, "late steps follow the pending steps and the DMA window");
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     if (g == GB) {                               // sync point (one longer gap per slab)
@@ -192,7 +201,7 @@ SN_DEV void slab_f32a(f32x16& acc, f32x16& accn, f32x4 (&af)[2], const char* lw,
     }
     mma(1);
     __builtin_amdgcn_sched_barrier(0);
-    if (g >= GB) {                               // gap 2: weight DMA
+    if (g >= GB && g < GL) {                     // gap 2: weight DMA
 #pragma unroll
       for (int i = 0; i < PPG; ++i) if ((g - GB) * PPG + i < NP) ring.piece_static();
       __builtin_amdgcn_sched_barrier(0);
@@ -200,7 +209,7 @@ SN_DEV void slab_f32a(f32x16& acc, f32x16& accn, f32x4 (&af)[2], const char* lw,
     mma(2);
     __builtin_amdgcn_sched_barrier(0);
     if (g < 4) pending(g);                       // gap 3: epilogue slice of the previous slab ...
-    else if (g < 8) late(g - 4);                 // ... then its activation-store steps (training forward)
+    else if (g >= GL && g < GL + 8) late(g - GL); // ... later the memory steps of the training kernels: late(0..7)
     __builtin_amdgcn_sched_barrier(0);
     mma(3);
     if (g & 1) { af[0] = n0; af[1] = n1; }

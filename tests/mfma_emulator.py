@@ -28,6 +28,11 @@ def mfma_f32_32x32x2(a, b, acc):
         acc[:, r] += D[acc_row(r, H), J]
 
 
+def fma32(a, b, c):
+    """fp32 fused multiply-add (product exact in float64, one rounding of the sum to fp32 up to double rounding)."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
 def pack_blob(lib, params, dtype_code=0):
     """Run the library's pack table on host numpy arrays (what pack_kernel does on the device)."""
     order = ([f"xyz_encoding_{i+1}.0" for i in range(8)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"])
@@ -139,8 +144,12 @@ def pack_blob_bwd(lib, params):
 def emulate_bwd_tile(blob, acts, out_raw, g_raw):
     """csrc/sn_mlp_bwd.hip for one 32-point tile.  acts: dict slot -> (32,256) forward activations (h1..h8, final, h2);
     out_raw, g_raw: (32,4).  Returns G: dict slot -> (32,256) and g_out (32,4)."""
-    ks = [32] * 4 + [128] * 8 + [288] * 8 + [256] * 56
+    ks = [128] * 8 + [256] * 64
     off = np.cumsum([0] + [32 * k for k in ks])
+    aux = blob[off[-1] + 64:off[-1] + 64 + 640]
+    assert not blob[off[-1]:off[-1] + 64].any()                 # the slab pipeline's zero "bias" slot
+    rgbT = aux[:384].reshape(3, 2, 64)                          # [c][h][K-slot]
+    sigT = aux[384:].reshape(2, 128)
 
     def tile_from_acc(acc, width_tile=None):
         # accumulator layout -> (32 points, 32 features)
@@ -171,15 +180,15 @@ def emulate_bwd_tile(blob, acts, out_raw, g_raw):
     k = np.float32(0.5 * 1.002 * 0.5)
     t3 = (2 * out_raw[:, :3] - 1) / np.float32(1.002)
     gy3 = g_raw[:, :3] * k * (1 - t3 * t3)
-    b_rgb = np.zeros((64, 16), np.float32); b_sig = np.zeros((64, 16), np.float32)
-    b_rgb[:32, :3] = gy3
-    b_sig[:32, 0] = g_raw[:, 3]
     g_out = np.concatenate([gy3, g_raw[:, 3:4]], 1)
     G = {}
     s = 0
     g2 = np.zeros((64, 64), np.float32); G[9] = np.zeros((32, 256), np.float32)
-    for t in range(4):
-        acc = run_slab(s, [b_rgb]); s += 1
+    for t in range(4):                     # rgb.0^T on the VALU: fma chain over the three colour rows
+        w = rgbT[:, H, 16 * t:16 * t + 16]                      # (3, 64 lanes, 16)
+        acc = w[0] * gy3[J, 0:1]
+        acc = fma32(w[1], gy3[J, 1:2], acc)
+        acc = fma32(w[2], gy3[J, 2:3], acc)
         g2[:, 16 * t:16 * t + 16] = acc * (1 - np.exp(-act_tile(9, t)))
         G[9][:, 32 * t:32 * t + 32] = tile_from_acc(g2[:, 16 * t:16 * t + 16])
     gh = np.zeros((64, 128), np.float32); G[8] = np.zeros((32, 256), np.float32)
@@ -189,7 +198,8 @@ def emulate_bwd_tile(blob, acts, out_raw, g_raw):
         G[8][:, 32 * t:32 * t + 32] = tile_from_acc(acc)
     nxt = np.zeros_like(gh); G[7] = np.zeros((32, 256), np.float32)
     for t in range(8):
-        acc = run_slab(s, [gh, b_sig]); s += 1
+        acc = run_slab(s, [gh]); s += 1
+        acc = fma32(sigT[H, 16 * t:16 * t + 16], g_raw[J, 3:4], acc)        # sigma^T on the VALU, after the MFMA sum
         nxt[:, 16 * t:16 * t + 16] = np.where(act_tile(7, t) > 0, acc, 0)
         G[7][:, 32 * t:32 * t + 32] = tile_from_acc(nxt[:, 16 * t:16 * t + 16])
     gh = nxt.copy()
@@ -200,5 +210,5 @@ def emulate_bwd_tile(blob, acts, out_raw, g_raw):
             nxt[:, 16 * t:16 * t + 16] = np.where(act_tile(li - 1, t) > 0, acc, 0)
             G[li - 1][:, 32 * t:32 * t + 32] = tile_from_acc(nxt[:, 16 * t:16 * t + 16])
         gh = nxt.copy()
-    assert s == 76
+    assert s == 72
     return G, g_out

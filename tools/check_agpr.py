@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Build check for sn_mlp_fwd.hip / sn_mlp_fwd_bf16.hip / sn_mlp_bwd_bf16.hip (run by sinnerf_amd/csrc/Makefile on the hipcc -S output).
 
-These kernels manage the AGPR file by hand and emit their MFMAs as inline asm, so three things the compiler normally
+These kernels manage the AGPR file by hand and emit their MFMAs as inline asm, so a few things the compiler normally
 guarantees are checked on the generated code instead:
   1. the compiler allocated no AGPR itself (every AGPR reference sits inside ASMSTART/ASMEND) and spilled nothing;
   2. no VALU instruction writes a register an MFMA reads within the next 2 wait states (VALU write -> MFMA read hazard);
   3. no VALU / LDS / memory instruction reads an MFMA result before two further MFMAs (or 12 other instructions) have issued
-     (MFMA write -> VALU read hazard: 11 wait states for the 8-pass bf16 MFMA, 18 for the 16-pass fp32 one).
+     (MFMA write -> VALU read hazard: 11 wait states for the 8-pass bf16 MFMA, 18 for the 16-pass fp32 one);
+  4. the destination of a global load issued from inline asm is not referenced before the next s_waitcnt vmcnt.
 usage: check_agpr.py file.s"""
 import re, sys
 
@@ -22,9 +23,9 @@ def vregs(tok):
             out |= {('a', r) for r in range(lo, hi + 1)}
     return out
 
-kern = None; ina = False; ins = []; bad_agpr = []; spills = 0
+kern = None; ina = False; ins = []; bad_agpr = []; spills = 0; pend_ld = set(); bad_async = []
 for ln, l in enumerate(open(sys.argv[1]), 1):
-    m = re.match(r'^(_Z\S*(?:mlp_(?:fwd_bf16|fwd_bf16_v3|fwd_f32|bwd_chain_bf16)_kernel|dw_f32_asm_kernel)\S*):', l)
+    m = re.match(r'^(_Z\S*(?:mlp_(?:fwd_bf16|fwd_bf16_v3|fwd_f32|bwd_chain_bf16|bwd_chain_f32)_kernel|dw_f32_asm_kernel)\S*):', l)
     if m: kern = m.group(1); continue
     if kern is None: continue
     if re.match(r'^\s*s_endpgm', l): kern = None; continue
@@ -45,6 +46,11 @@ for ln, l in enumerate(open(sys.argv[1]), 1):
     else:
         dst = set(); src = set().union(*[vregs(p) for p in parts]) if parts else set()
     ins.append((ln, op, dst, src, is_valu, t, reads_regs))
+    # 4. destination registers of a global load issued from inline asm (the wait is hand-placed) are not touched by anything
+    #    until an s_waitcnt vmcnt has issued
+    if op == 's_waitcnt' and 'vmcnt' in args: pend_ld = set()
+    elif pend_ld and (vregs(args) & pend_ld): bad_async.append((ln, t))
+    if ina and op.startswith('global_load_dword') and 'lds' not in op: pend_ld |= vregs(parts[0])
 
 haz1 = []; haz2 = []
 for i, (ln, op, dst, src, is_valu, t, _rr) in enumerate(ins):
@@ -67,8 +73,9 @@ for i, (ln, op, dst, src, is_valu, t, _rr) in enumerate(ins):
         j += 1
 
 print(f"compiler-allocated AGPR references: {len(bad_agpr)}; scratch instructions: {spills}; "
-      f"VALU->MFMA read hazards: {len(haz1)}; MFMA->VALU read hazards: {len(haz2)}")
+      f"VALU->MFMA read hazards: {len(haz1)}; MFMA->VALU read hazards: {len(haz2)}; early uses of asm loads: {len(bad_async)}")
+for b in bad_async[:5]: print("  async line %d: %s" % b)
 for b in bad_agpr[:5]: print("  agpr  line %d: %s" % b)
 for b in haz1[:5]: print("  haz1  line %d: %s  ->  %s" % b)
 for b in haz2[:5]: print("  haz2  line %d: %s  ->  %s" % b)
-sys.exit(1 if bad_agpr or spills or haz1 or haz2 else 0)
+sys.exit(1 if bad_agpr or spills or haz1 or haz2 or bad_async else 0)
