@@ -1,6 +1,6 @@
 """time the backward chain of the fine pass (524288 points) -- used with SINNERF_HIP_LIB to compare experimental builds"""
-import sys, numpy as np, torch
-sys.path.insert(0, ".")
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle_np as O
 import sinnerf_amd
 from sinnerf_amd import autograd as A, _lib
