@@ -2,6 +2,9 @@
 // inline-asm MFMAs with VGPR accumulators over the hand-managed AGPR activation file, epilogue blocks, the slab loop.
 // See the header of sn_mlp_fwd_bf16.hip for the register plan and the hazard rules (checked by tools/check_agpr.py).
 #pragma once
+#ifndef SN_SPREAD_MEM
+#define SN_SPREAD_MEM 1
+#endif
 #include "sn_mlp_pipe.h"
 #include <type_traits>
 
@@ -173,9 +176,13 @@ constexpr int act_reg(int set, int kstep, int pt) { return set * 128 + (kstep * 
 //              s_barrier, every LDS access near the pieces as inline asm so that hipcc does not guard it with vmcnt(0) --
 //              removed 39 of 74 full drains from the code and changed nothing: 1.04 ms either way.  The waves' parked time
 //              (PMC SQ_WAIT_ANY 44 %) is not the store drain; non-temporal stores are acknowledged by the L2 quickly.)
-//   post_sync  run right after the sync point: the training kernels issue their HBM traffic here (activation-tile stores /
-//              loads) so that it has a whole slab to complete before the next s_waitcnt vmcnt(0) -- issued just in front of
-//              the sync point it exposes the full HBM latency on every slab (measured: 3.9 us per slab instead of ~1)
+//   post_sync  (step, n_steps): the memory steps of the training kernels (activation-tile row stores, then the loads of the
+//              next tile's masks), called once per k-step behind the sync point and behind the k-steps that carry the slab's
+//              DMA pieces: the callee deals its operations evenly over the n_steps calls -- one vector-memory instruction
+//              per k-step and wave instead of a burst of nine at the sync point (sn_mlp_pipe.h: the fp32 chain gained 6 %
+//              from that placement).  They still follow the sync point so that they have most of a slab to complete before
+//              the next s_waitcnt vmcnt(0); issued just in FRONT of it they expose the full HBM latency on every slab
+//              (measured: 3.9 us per slab instead of ~1).
 template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, class Pending, class PostSync>
 SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], const char* lw, const u32x4* bv,
                       const char* lw_next, const float* lds_bias, int s_next, int h, RingB& ring, Pending&& pending,
@@ -183,6 +190,13 @@ SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], con
   constexpr int NK = NK0 + NK1;
   constexpr int NP = (NBYTES + 4095) / 4096;
   constexpr int PPK = (NP + (NK - GB) - 1) / (NK - GB);      // DMA pieces per k-step after the sync point (1; 2 in layer 0)
+  constexpr int NPS = (NP + PPK - 1) / PPK;                  // k-steps that carry a DMA piece
+#if SN_SPREAD_MEM
+  constexpr int MS0 = (NK - GB - NPS >= 3) ? NPS : 0;        // the memory steps start behind them when that leaves >= 3 k-steps
+  constexpr int NMS = NK - GB - MS0;
+#else
+  constexpr int MS0 = 0, NMS = 1;                            // (comparison build: everything right at the sync point)
+#endif
   static_assert(GB >= 1 && GB < NK && NK >= 4 && GB + 3 <= NK, "sync point inside the slab, not after the first next-slab fragment read");
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
@@ -190,7 +204,6 @@ SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], con
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       ring.begin_static();
-      post_sync();
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) accn[pt] = load_bias(lds_bias, s_next, h);
     }
@@ -210,6 +223,7 @@ SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], con
         }
       }
     }
+    if (ks >= GB + MS0 && ks - GB - MS0 < NMS) post_sync(ks - GB - MS0, NMS);
     __builtin_amdgcn_sched_barrier(0);
     const u32x4 a_cur = af[(PHASE + ks) & 3];
 #pragma unroll

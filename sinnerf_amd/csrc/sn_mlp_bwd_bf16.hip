@@ -198,30 +198,34 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
     uint32_t c01 = 0x00010001u;
     asm volatile("" : "+v"(c01));
     uint32_t sign_word = 0;                                                 // bf16 state: ReLU sign word of the tile in flight
-    auto load_act = [&](int slot, int t, bool values = false) __attribute__((always_inline)) {
+    // load operation k of the activation tile (slot, t): S16 ReLU masks: k = 0 is the tile's sign word (one dword per lane);
+    // S16 values (softplus tile): k = 2 pt + i, two row-coalesced loads per point tile; fp32 state: k = 4 pt + q4, the
+    // accumulator layout directly (4 x 16 B per lane and point tile)
+    auto load_act_op = [&](int slot, int t, bool values, int k) __attribute__((always_inline)) {
       if (S16 && !values) {
-        const char* src = reinterpret_cast<const char*>(acts) + (((long)9 * slot_rows + p_wave + 8 * slot + t) * 256 + 128) * 2;
-        sign_word = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src + lane * 4));
-        return;
-      }
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        if (S16) {
-          // row-coalesced: lane -> (row lane>>2 [+16], 16-byte chunk lane&3) of the 32-point x 64-byte tile; 2 loads per
-          // point tile instead of 4 scattered 8-byte ones (64 cache lines per instruction: the TA, not HBM, was the limit)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const long row = p_wave + pt * 32 + 16 * i + (lane >> 2);
-            const long rc = row < P ? row : P - 1;
-            const char* src = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + rc) * 256 + 32 * t) * 2 + 16 * (lane & 3);
-            ald[pt][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-          }
-        } else {
-          const float* src = acts + ((long)slot * slot_rows + p[pt]) * 256 + 32 * t + 4 * h;
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) av[pt][q4] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 8 * q4));
+        if (k == 0) {
+          const char* src = reinterpret_cast<const char*>(acts) + (((long)9 * slot_rows + p_wave + 8 * slot + t) * 256 + 128) * 2;
+          sign_word = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src + lane * 4));
         }
+      } else if (S16) {
+        // row-coalesced: lane -> (row lane>>2 [+16], 16-byte chunk lane&3) of the 32-point x 64-byte tile; 2 loads per
+        // point tile instead of 4 scattered 8-byte ones (64 cache lines per instruction: the TA, not HBM, was the limit)
+        if (k < 2 * PT) {
+          const int pt = k >> 1, i = k & 1;
+          const long row = p_wave + pt * 32 + 16 * i + (lane >> 2);
+          const long rc = row < P ? row : P - 1;
+          const char* src = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + rc) * 256 + 32 * t) * 2 + 16 * (lane & 3);
+          ald[pt][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+        }
+      } else if (k < 4 * PT) {
+        const int pt = k >> 2, q4 = k & 3;
+        const float* src = acts + ((long)slot * slot_rows + p[pt]) * 256 + 32 * t + 4 * h;
+        av[pt][q4] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 8 * q4));
       }
+    };
+    auto load_act = [&](int slot, int t, bool values = false) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4 * PT; ++k) load_act_op(slot, t, values, k);
     };
     auto stage = [&](int pt, int t, int qq, const float (&v)[4], uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
       if (S16) {
@@ -234,35 +238,45 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
         *reinterpret_cast<f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_w + 32 * qq) = o;
       }
     };
-    auto store_tile = [&](int slot, int t) __attribute__((always_inline)) {      // rows >= P receive the zeros their lanes hold
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        if (S16) {
-          if (t & 1) {                           // tiles t-1, t: whole 128-byte rows
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xs16_r + 8 * i * XS16_PITCH);
-            char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * (t - 1)) * 2;
-            unsigned go = g16_off;
-            asm volatile("" : "+v"(go));
+    // row-group store k = 4 pt + i of finished tile t (rows >= P receive the zeros their lanes hold)
+    auto store_op = [&](int slot, int t, int k) __attribute__((always_inline)) {
+      const int pt = k >> 2, i = k & 3;
+      if (S16) {
+        if (t & 1) {                             // tiles t-1, t: whole 128-byte rows
+          const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xs16_r + 8 * i * XS16_PITCH);
+          char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * (t - 1)) * 2;
+          unsigned go = g16_off;
+          asm volatile("" : "+v"(go));
 #ifndef SN_ABL_NO_STATE_STORE                       // (timing experiments only: tools/build_variant_src.sh)
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+          __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
 #else
-            asm volatile("" :: "v"(o), "s"(base), "v"(go));
+          asm volatile("" :: "v"(o), "s"(base), "v"(go));
 #endif
-          }
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_r + 8 * i * XPOSE_PITCH * 4);
-            char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * t) * 4;
-            unsigned go = g_off;
-            asm volatile("" : "+v"(go));
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
-          }
         }
+      } else {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_r + 8 * i * XPOSE_PITCH * 4);
+        char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * t) * 4;
+        unsigned go = g_off;
+        asm volatile("" : "+v"(go));
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
       }
+    };
+    auto store_tile = [&](int slot, int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4 * PT; ++k) store_op(slot, t, k);
+    };
+    // memory step `step` of `n` of a slab (sn_mlp_bf16.h): the load operations of the activation tile t_next of slot mslot
+    // (if any) FIRST -- a bf16 slab is only ~1 us long and the next slab's epilogue consumes them (requested last they cost
+    // 7 % of the launch) -- then the 4 PT row stores of the finished tile t_done (if any), dealt evenly over the n calls
+    constexpr int N_LD_OPS = S16 ? 1 : 4 * PT;
+    constexpr int N_MEM_OPS = 4 * PT + N_LD_OPS;
+    auto mem_step = [&](int oslot, int t_done, int mslot, int t_next, bool mask, int step, int n) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < N_MEM_OPS; ++k)
+        if (k >= step * N_MEM_OPS / n && k < (step + 1) * N_MEM_OPS / n) {
+          if (k < N_LD_OPS) { if (mask) load_act_op(mslot, t_next, false, k); }
+          else if (t_done >= 0) store_op(oslot, t_done, k - N_LD_OPS);
+        }
     };
 
     // ---- rgb.0^T on the VALU: g_h2 = W_r^T g_y3 ; g_y2 = g_h2 (1 - exp(-h2)); written to set 0 (K-slots 16t + r)
@@ -343,18 +357,18 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
 #define SNC_SNEXT (s + 1 == snl::NBB_SLABS ? 0 : s + 1)
 #define SNC_W(W_) std::integral_constant<int, W_>{}
     // slab of output tile T_ (literal).  The deferred epilogue of tile T_-1 runs behind the first MFMA pair; its row stores and
-    // the loads of the activation tile THIS slab's epilogue needs (MASK_) are issued right after the sync point, so that they
-    // have a whole slab before the next s_waitcnt vmcnt(0).
+    // the loads of the activation tile THIS slab's epilogue needs (MASK_) are the slab's memory steps (behind the sync point
+    // and the DMA pieces, one per k-step: sn_mlp_bf16.h).
 #define SNC_SLAB(T_, NK_, SET_, NB_, EPI_, W_, MASK_)                                                              \
   do {                                                                                                             \
     if (((T_) & 1) == 0)                                                                                           \
       slab_bf16<NK_, 0, SET_, SET_, 2, 0, NB_>(acc0, acc1, af, SNC_LW_CUR, static_cast<const u32x4*>(nullptr), SNC_LW_NEXT, lds_zero, SNC_SNEXT, h, \
           ring, [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNC_W(W_), (T_) - 1, acc1); },           \
-          [&]() __attribute__((always_inline)) { if ((T_) > 0) store_tile(out_slot, (T_) - 1); if (MASK_) load_act(mask_slot, T_); }); \
+          [&](int st, int n) __attribute__((always_inline)) { mem_step(out_slot, (T_) - 1, mask_slot, T_, MASK_, st, n); }); \
     else                                                                                                           \
       slab_bf16<NK_, 0, SET_, SET_, 2, 0, NB_>(acc1, acc0, af, SNC_LW_CUR, static_cast<const u32x4*>(nullptr), SNC_LW_NEXT, lds_zero, SNC_SNEXT, h, \
           ring, [&]() __attribute__((always_inline)) { EPI_(SNC_W(W_), (T_) - 1, acc0); },                         \
-          [&]() __attribute__((always_inline)) { store_tile(out_slot, (T_) - 1); if (MASK_) load_act(mask_slot, T_); }); \
+          [&](int st, int n) __attribute__((always_inline)) { mem_step(out_slot, (T_) - 1, mask_slot, T_, MASK_, st, n); }); \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
   } while (0)
 #define SNC_LAYER(NK_, SET_, NBA_, NBB_, EPI_, W_, MASK_)   \

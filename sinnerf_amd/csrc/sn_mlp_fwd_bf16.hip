@@ -172,35 +172,29 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xp16_w + 64 * (t & 1) + 16 * qq) = o;
       }
     };
-    auto store_tile = [&](int slot, int t) __attribute__((always_inline)) {
-      if (STORE == 1) {
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_r + 8 * i * XPOSE_PITCH * 4);
-            char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * t) * 4;
-            unsigned go = g_off;
-            asm volatile("" : "+v"(go));         // opaque per store: no hoisted per-slot address registers
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
-          }
-      } else if (STORE == 2) {
+    // memory operation k of finished tile t: k = 0..7 row group (pt = k >> 2, i = k & 3), k = 8 the tile's ReLU sign word
+    constexpr int N_MEM_OPS = 9;
+    auto mem_op = [&](int slot, int t, int k) __attribute__((always_inline)) {
+      const int pt = k >> 2, i = k & 3;
+      if (STORE == 1 && k < 8) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_r + 8 * i * XPOSE_PITCH * 4);
+        char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * t) * 4;
+        unsigned go = g_off;
+        asm volatile("" : "+v"(go));             // opaque per store: no hoisted per-slot address registers
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+      } else if (STORE == 2 && k < 8) {
         if (t & 1) {                             // tiles t-1, t: whole 128-byte rows, 8 rows per instruction
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp16_r + 8 * i * XS16_PITCH);
-            char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * (t - 1)) * 2;
-            unsigned go = g16_off;
-            asm volatile("" : "+v"(go));
+          const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp16_r + 8 * i * XS16_PITCH);
+          char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * (t - 1)) * 2;
+          unsigned go = g16_off;
+          asm volatile("" : "+v"(go));
 #ifndef SN_ABL_NO_STATE_STORE                       // (timing experiments only: tools/build_variant_src.sh)
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
+          __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
 #else
-            asm volatile("" :: "v"(o), "s"(base), "v"(go));
+          asm volatile("" :: "v"(o), "s"(base), "v"(go));
 #endif
-          }
         }
+      } else if (STORE == 2 && k == 8) {
         if (slot < 8) {                          // ReLU layers: the tile's sign word, 256 contiguous bytes per wave
           char* base = reinterpret_cast<char*>(acts) + (((long)9 * slot_rows + p_wave + 8 * slot + t) * 256 + 128) * 2;
           unsigned go = (unsigned)lane * 4u;
@@ -209,6 +203,13 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
         }
       }
     };
+    // the operations of memory step `step` of `n` (sn_mlp_bf16.h: dealt evenly over the k-steps behind the DMA pieces)
+    auto mem_step = [&](int slot, int t, int step, int n) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < N_MEM_OPS; ++k)
+        if (k >= step * N_MEM_OPS / n && k < (step + 1) * N_MEM_OPS / n) mem_op(slot, t, k);
+    };
+    auto store_tile = [&](int slot, int t) __attribute__((always_inline)) { mem_step(slot, t, 0, 1); };
     // Epilogues of output tile t (results r) writing activation set W: dword q of the tile = accumulator registers
     // 2q, 2q+1 -> k-steps 2t, 2t+1 of the next layer (dwords q, q+1 for even q are adjacent registers).
     auto relu_tile = [&](auto wset, int t, const f32x16 (&r)[PT]) __attribute__((always_inline)) {
@@ -283,11 +284,11 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(acc0, acc1, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
                                                      SNB_SNEXT, h, ring,                                           \
                                                      [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNB_W(W_), (T_) - 1, acc1); }, \
-                                                     [&]() __attribute__((always_inline)) { if ((T_) > 0) store_tile(cur_slot, (T_) - 1); }); \
+                                                     [&](int st, int n) __attribute__((always_inline)) { if ((T_) > 0) mem_step(cur_slot, (T_) - 1, st, n); }); \
     else                                                                                                           \
       slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(acc1, acc0, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
                                                      SNB_SNEXT, h, ring, [&]() __attribute__((always_inline)) { EPI_(SNB_W(W_), (T_) - 1, acc0); }, \
-                                                     [&]() __attribute__((always_inline)) { store_tile(cur_slot, (T_) - 1); }); \
+                                                     [&](int st, int n) __attribute__((always_inline)) { mem_step(cur_slot, (T_) - 1, st, n); }); \
     SNB_ADVANCE();                                                                                                 \
   } while (0)
     // the 8 output tiles of a layer, T_ literal (it ends up in asm immediates); tiles 6,7 stage the NEXT layer's slabs

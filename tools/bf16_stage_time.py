@@ -1,7 +1,7 @@
 """time the three MLP stages of the bf16-state training step on the fine pass (524 288 points) -- used with SINNERF_HIP_LIB to
 compare experimental builds"""
-import sys, torch
-sys.path.insert(0, ".")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle_np as O
 import sinnerf_amd
 from sinnerf_amd import autograd as A, _lib
