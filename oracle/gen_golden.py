@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate golden vectors from the UNMODIFIED reference (run in the build container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--grads | --rays | --loss | --pfm | --classic-heads]
 
 Imports ``models.rendering`` / ``models.nerf`` straight from ``/root/reference`` (read-only mount,
 never present on the GPU box), executes them on CPU/fp32 with seeded synthetic inputs and stores
@@ -31,8 +31,8 @@ OUT = os.path.join(REPO, "tests", "golden")
 torch.set_num_threads(8)
 
 
-def ref_model(seed, teacher):
-    m = NeRF(use_new_activation=True)
+def ref_model(seed, teacher, new_act=True):
+    m = NeRF(use_new_activation=new_act)
     p = O.init_params(seed, teacher)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
     return m.eval(), p
@@ -162,7 +162,7 @@ def main():
     print("done ->", OUT)
 
 
-if __name__ == "__main__" and "--grads" not in sys.argv and "--rays" not in sys.argv and "--loss" not in sys.argv and "--pfm" not in sys.argv:
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--grads", "--rays", "--loss", "--pfm", "--classic-heads")):
     main()
 
 
@@ -217,6 +217,54 @@ def main_grads():
 
 if __name__ == "__main__" and "--grads" in sys.argv:
     main_grads()
+
+
+def main_classic_heads():
+    """NeRF(use_new_activation=False) (nerf.py:91-100: ReLU / Sigmoid heads, the constructor's default): MLP outputs and the
+    reference's own autograd gradients on one batch of embedded points, plus one eval render."""
+    os.makedirs(OUT, exist_ok=True)
+    m, p = ref_model(6, True, new_act=False)
+    r = np.random.RandomState(21)
+    n = 160
+    xyz = r.uniform(-2.5, 2.5, (n, 3)).astype(np.float32)
+    d = r.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    exyz, edir = Embedding(3, 10), Embedding(3, 4)
+    with torch.no_grad():
+        x = torch.cat([exyz(torch.from_numpy(xyz)), edir(torch.from_numpy(d))], 1)
+    m.train()
+    out = m(x)
+    g = r.standard_normal((n, 4)).astype(np.float32)
+    m.zero_grad()
+    out.backward(torch.from_numpy(g))
+    grads = {}                                   # as case_grad: norms, 256 sampled entries per matrix, the biases in full
+    idx_r = np.random.RandomState(5)
+    for k, v in m.named_parameters():
+        gr = v.grad.numpy()
+        grads["gnorm." + k] = np.asarray(np.linalg.norm(gr.astype(np.float64)))
+        if gr.ndim == 1:
+            grads["gfull." + k] = gr.copy()
+        else:
+            idx = idx_r.choice(gr.size, min(256, gr.size), replace=False)
+            grads["gidx." + k] = idx
+            grads["gval." + k] = gr.reshape(-1)[idx]
+    with torch.no_grad():
+        sig = m(x[:, :63], sigma_only=True)
+    np.savez_compressed(os.path.join(OUT, "nerf_mlp_classic_heads.npz"), seed=6, teacher=True, x=x.numpy(),
+                        out=out.detach().numpy(), sigma_only=sig.numpy(), g=g, **grads)
+    # one eval render through the reference's render_rays with both networks on the classic heads
+    lego = O.lego_rays(400, 400, seed=0)
+    rays = np.ascontiguousarray(lego[np.random.RandomState(8).choice(lego.shape[0], 80, replace=False)])
+    models = [ref_model(6, True, new_act=False)[0], ref_model(7, True, new_act=False)[0]]
+    with torch.no_grad():
+        res = ref_rendering.render_rays(models, [exyz, edir], torch.from_numpy(rays), 64, False, 0, 0, 64, 1024 * 32, True)
+    np.savez_compressed(os.path.join(OUT, "render_lego_eval_classic_heads.npz"), rays=rays, seeds=np.array([6, 7]),
+                        teacher=True, **{k: v.numpy() for k, v in res.items()})
+    print("classic heads: out", out.shape, "render keys", sorted(res))
+
+
+if __name__ == "__main__" and "--classic-heads" in sys.argv:
+    main_classic_heads()
 
 
 def main_rays():

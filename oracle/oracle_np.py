@@ -98,10 +98,36 @@ def _linear(x, w, b, head=False):
     return (x @ w.T + b).astype(F)
 
 
+# ``NeRF(use_new_activation=...)`` (nerf.py:47-50): True (both reference call sites) = ShiftedSoftplus / WidenedSigmoid heads,
+# False (the constructor's default) = ReLU / Sigmoid.  Switched for a block of oracle calls by ``with classic_heads():``.
+_NEW_ACT = True
+
+
+class classic_heads:
+    """``with classic_heads():`` -- nerf_forward / nerf_backward (and everything built on them) restate
+    ``NeRF(use_new_activation=False)`` (nerf.py:91-100) inside the block."""
+
+    def __enter__(self):
+        global _NEW_ACT
+        self._old, _NEW_ACT = _NEW_ACT, False
+        return self
+
+    def __exit__(self, *exc):
+        global _NEW_ACT
+        _NEW_ACT = self._old
+
+
+def sigmoid(x):
+    """nn.Sigmoid in fp32 (nerf.py:100)."""
+    x = np.asarray(x, F)
+    with np.errstate(over="ignore"):
+        return (F(1) / (F(1) + np.exp(-x))).astype(F)
+
+
 def nerf_forward(params, x, sigma_only=False, D=8, W=256, in_xyz=63, in_dir=27, skips=(4,),
                  return_hidden=False, cache=None):
-    """NeRF MLP forward, reference ``models/nerf.py:122-148`` with
-    ``use_new_activation=True`` (both call sites: sinnerf.py:137,140 / eval.py:136-137).
+    """NeRF MLP forward, reference ``models/nerf.py:122-148``; ``use_new_activation=True`` (both call sites:
+    sinnerf.py:137,140 / eval.py:136-137) unless called inside ``with classic_heads():``.
 
     x: (B, 63[+27]) embedded input.  Returns (B,1) raw sigma if sigma_only else (B,4)=[rgb,sigma].
     """
@@ -126,12 +152,12 @@ def nerf_forward(params, x, sigma_only=False, D=8, W=256, in_xyz=63, in_dir=27, 
     final = _linear(h, params["xyz_encoding_final.weight"], params["xyz_encoding_final.bias"])  # :140
     d_in = np.concatenate([final, input_dir], -1)                            # :142
     y2 = _linear(d_in, params["dir_encoding.0.weight"], params["dir_encoding.0.bias"])
-    d = shifted_softplus(y2)                                                 # :143
+    d = shifted_softplus(y2) if _NEW_ACT else np.maximum(y2, F(0))          # :143 (ShiftedSoftplus, nerf.py:81-84 / ReLU, :91-94)
     y3 = _linear(d, params["rgb.0.weight"], params["rgb.0.bias"], head=True)
-    rgb = widened_sigmoid(y3)                                                # :144
+    rgb = widened_sigmoid(y3) if _NEW_ACT else sigmoid(y3)                   # :144 (WidenedSigmoid, nerf.py:86-90 / Sigmoid, :96-100)
     out = np.concatenate([rgb, sigma], -1)                                   # :146
     if cache is not None:
-        cache.update(x=x, final=final, y2=y2, d=d, y3=y3)
+        cache.update(x=x, final=final, y2=y2, d=d, y3=y3, new_act=_NEW_ACT)
     if return_hidden:
         return out, hidden + [final, d]
     return out
@@ -370,14 +396,21 @@ def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None,
     x = cache["x"].astype(f8)
     input_xyz, input_dir = x[:, :in_xyz], x[:, in_xyz:]
     g_rgb, g_sigma = g_out[:, :3].astype(f8), g_out[:, 3:4].astype(f8)
-    t = np.tanh(0.5 * cache["y3"].astype(f8))
-    g_y3 = g_rgb * (0.5 * 1.002 * 0.5) * (1.0 - t * t)
+    new_act = cache.get("new_act", True)
+    if new_act:
+        t = np.tanh(0.5 * cache["y3"].astype(f8))
+        g_y3 = g_rgb * (0.5 * 1.002 * 0.5) * (1.0 - t * t)
+    else:                                                                    # Sigmoid' = s (1 - s)
+        sg = 1.0 / (1.0 + np.exp(-cache["y3"].astype(f8)))
+        g_y3 = g_rgb * sg * (1.0 - sg)
     d = cache["d"].astype(f8)
     g["rgb.0.weight"], g["rgb.0.bias"] = rd(g_y3).T @ rd(d), rd(g_y3).sum(0)
     if gy_out is not None:
         gy_out["rgb"], gy_out["sigma"] = g_y3, g_sigma
     g_d = g_y3 @ params["rgb.0.weight"].astype(f8)
-    if operand_round is not None:
+    if not new_act:
+        g_y2 = g_d * (d > 0)                                                 # ReLU(inplace): g * [out > 0]
+    elif operand_round is not None:
         g_y2 = g_d * (1.0 - np.exp(-d))
     else:
         g_y2 = g_d / (1.0 + np.exp(-(cache["y2"].astype(f8) - 1.0)))

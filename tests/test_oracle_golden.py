@@ -93,3 +93,32 @@ def test_known_answers():
     for k in range(10):
         sn, cs = e[:, 3 + 6 * k:6 + 6 * k], e[:, 6 + 6 * k:9 + 6 * k]
         assert np.allclose(sn * sn + cs * cs, 1.0, atol=1e-6)
+
+
+def test_classic_heads_mlp_forward_backward_and_render():
+    """``NeRF(use_new_activation=False)`` (nerf.py:91-100, the constructor's default): the oracle inside
+    ``with O.classic_heads():`` against the reference's outputs, its own autograd gradients and one eval render."""
+    z = np.load(f"{GOLDEN}/nerf_mlp_classic_heads.npz")
+    p = O.init_params(int(z["seed"]), bool(z["teacher"]))
+    with O.classic_heads():
+        cache = {}
+        out = O.nerf_forward(p, z["x"], cache=cache)
+        sig = O.nerf_forward(p, z["x"][:, :63], sigma_only=True)
+        grads = O.nerf_backward(p, cache, z["g"])
+    assert O._NEW_ACT is True                                           # restored on exit
+    assert max_rel(out, z["out"]) <= 2e-5 and max_rel(sig, z["sigma_only"]) <= 2e-5
+    assert not np.allclose(out[:, :3], O.nerf_forward(p, z["x"])[:, :3], atol=1e-3)    # the heads really differ
+    for k, g in grads.items():
+        ref_norm = float(z["gnorm." + k])
+        if g.ndim == 1:
+            ref, got = z["gfull." + k].astype(np.float64), g
+        else:
+            idx = z["gidx." + k]
+            ref, got = z["gval." + k].astype(np.float64), g.reshape(-1)[idx]
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6 * ref_norm, k     # reference = fp32 autograd
+        assert abs(np.linalg.norm(g) - ref_norm) <= 2e-5 * ref_norm, k
+    r = np.load(f"{GOLDEN}/render_lego_eval_classic_heads.npz")
+    models = [O.init_params(int(s), bool(r["teacher"])) for s in r["seeds"]]
+    with O.classic_heads():
+        res = O.render_rays(models, r["rays"], 64, False, 0, 0, 64, 32768, True)
+    check_render(res, {k: r[k] for k in r.files if k not in ("rays", "seeds", "teacher")}, tag="classic_heads")
