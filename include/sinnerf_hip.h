@@ -23,6 +23,11 @@ extern "C" {
 #define SN_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate                    */
 #define SN_DTYPE_BF16_STATE 2 /* training entries only: SN_DTYPE_BF16 arithmetic AND acts / g_acts stored as bf16
                                * (same shapes; the float* parameters then point at bf16 arrays; emb stays fp32)   */
+/* OR-ed into `dtype` of the sn_mlp_* entry points: the network was built as NeRF(use_new_activation=False), the
+ * constructor's default (models/nerf.py:47-50, :91-100) -- ReLU after dir_encoding, Sigmoid after rgb -- instead of the
+ * ShiftedSoftplus / WidenedSigmoid heads both reference call sites ask for (models/nerf.py:81-90, models/activations.py).
+ * Blobs, training state and every other entry point are the same for both.                                          */
+#define SN_DTYPE_CLASSIC_HEADS 0x100
 
 #define SN_E_BADARG (-1)
 #define SN_E_TOOLARGE (-2)

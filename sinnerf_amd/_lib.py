@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SINNERF_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 SN_DTYPE_F32 = 0
 SN_DTYPE_BF16 = 1
 SN_DTYPE_BF16_STATE = 2
+SN_DTYPE_CLASSIC_HEADS = 0x100      # OR-ed into dtype: NeRF(use_new_activation=False) heads (include/sinnerf_hip.h)
 N_RAW_TENSORS = 24
 
 c_fp = ctypes.c_void_p      # device float*

@@ -93,7 +93,7 @@ class _MLPFn(torch.autograd.Function):
             emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
             emb[:n, :63] = rays[:, :63]
             emb[:n, 64:91] = rays[:, 63:90]
-            _lib.check(_lib.lib.sn_mlp_forward_train_embedded(_lib.ptr(model.packed()), code, _lib.ptr(rays), n, rays.shape[1],
+            _lib.check(_lib.lib.sn_mlp_forward_train_embedded(_lib.ptr(model.packed()), model.kernel_dtype(code), _lib.ptr(rays), n, rays.shape[1],
                                                               _lib.ptr(out), _lib.ptr(acts), rows, _lib.stream_ptr()),
                        "sn_mlp_forward_train_embedded")
         else:
@@ -102,7 +102,7 @@ class _MLPFn(torch.autograd.Function):
             # blocks that _weight_grads slices away ([:, :63], [:, :27]) -- a contraction's output column depends on its own
             # X column only
             emb = torch.empty((rows, 128), dtype=torch.float32, device=dev)
-            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
+            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code), _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                                      _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
                        "sn_mlp_forward_train")
         ctx.model = model
@@ -125,7 +125,7 @@ class _MLPFn(torch.autograd.Function):
             code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
             if acts.dtype == torch.bfloat16:
                 code = _lib.SN_DTYPE_BF16_STATE
-            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(model.compute_dtype)), code,
+            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(model.compute_dtype)), model.kernel_dtype(code),
                                                       _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")
             needs = ctx.needs_input_grad[3:]

@@ -7,9 +7,17 @@ extern "C" {
 int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                               int sigma_only, int input_mode, float* out, float* acts, float* emb,
                               long slot_rows, hipStream_t stream);
+int sn_mlp_forward_f32_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                              int sigma_only, int input_mode, float* out, float* acts, float* emb,
+                              long slot_rows, hipStream_t stream);
 int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
+int sn_mlp_backward_chain_f32_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                     long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                      long n_points, long slot_rows, float* G, float* g_out, int state_bf16,
+                                      hipStream_t stream);
+int sn_mlp_backward_chain_bf16_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                       long n_points, long slot_rows, float* G, float* g_out, int state_bf16,
                                       hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
@@ -28,7 +36,12 @@ int sn_render_loss_launch(const float* rgb_c, const float* rgb_f, const float* d
 int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
                                int state_bf16, hipStream_t stream);
+int sn_mlp_forward_bf16_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                               int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
+                               int state_bf16, hipStream_t stream);
 int sn_mlp_forward_bf16_v3_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
+                                  float* out, hipStream_t stream);
+int sn_mlp_forward_bf16_v3_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
                                   float* out, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
@@ -143,31 +156,39 @@ int sn_sample_coarse(const float* rays, long n_rays, int n_samples, int use_disp
   return sn_sample_coarse_launch(rays, n_rays, n_samples, use_disp, perturb, perturb_rand, z_vals, (hipStream_t)stream);
 }
 
+// the two compilation passes of the MLP kernels (sn_device.h): SN_DTYPE_CLASSIC_HEADS in `dtype` selects the ReLU / Sigmoid
+// pass; a sigma-only evaluation never reaches the heads and always runs the main pass
+#define SN_HEADS(classic, name) ((classic) ? name##_classic_launch : name##_launch)
+
 int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                    int sigma_only, int flags, float* out, void* stream) {
   if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  const bool classic = (dtype & SN_DTYPE_CLASSIC_HEADS) && !sigma_only;
+  dtype &= ~SN_DTYPE_CLASSIC_HEADS;
   if (dtype == SN_DTYPE_BF16 && !sigma_only && !(flags & SN_FLAG_BF16_COMPILER_SCHEDULED))     // the hand-scheduled kernel
-    return sn_mlp_forward_bf16_v3_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, out, (hipStream_t)stream);
+    return SN_HEADS(classic, sn_mlp_forward_bf16_v3)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, out, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16)
-    return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out, nullptr,
-                                      nullptr, 0, 0, (hipStream_t)stream);
+    return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out, nullptr,
+                                                  nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
-  return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
-                                   out, nullptr, nullptr, 0, (hipStream_t)stream);
+  return SN_HEADS(classic, sn_mlp_forward_f32)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
+                                               out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                          float* out, float* acts, float* emb, long slot_rows, void* stream) {
   if (!blob || !rays || !z_vals || !out || !acts || !emb || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
+  const bool classic = dtype & SN_DTYPE_CLASSIC_HEADS;
+  dtype &= ~SN_DTYPE_CLASSIC_HEADS;
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
   const long n_points = n_rays * (long)n_samples;
   const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are stored
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
   if (dtype != SN_DTYPE_F32)
-    return sn_mlp_forward_bf16_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
-                                      dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
-  return sn_mlp_forward_f32_launch(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
-                                   (hipStream_t)stream);
+    return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
+                                                  dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
+  return SN_HEADS(classic, sn_mlp_forward_f32)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
+                                               (hipStream_t)stream);
 }
 
 int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, long n_rows, int ld, float* out,
@@ -175,26 +196,30 @@ int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, l
   if (!blob || !x || !out || !acts || n_rows < 0) return SN_E_BADARG;
   float* emb = acts;                             // not written for pre-embedded rows (the kernels only need it non-null)
   if (ld < 90) return SN_E_BADSHAPE;
+  const bool classic = dtype & SN_DTYPE_CLASSIC_HEADS;
+  dtype &= ~SN_DTYPE_CLASSIC_HEADS;
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;   // mixed precision keeps bf16 state
   const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;
   if (slot_rows < (n_rows + tile - 1) / tile * tile) return SN_E_BADSHAPE;
   if (dtype != SN_DTYPE_F32)
-    return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows,
-                                      dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
-  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows, (hipStream_t)stream);
+    return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows,
+                                                  dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
+  return SN_HEADS(classic, sn_mlp_forward_f32)(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows, (hipStream_t)stream);
 }
 
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream) {
   if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;
+  const bool classic = dtype & SN_DTYPE_CLASSIC_HEADS;
+  dtype &= ~SN_DTYPE_CLASSIC_HEADS;
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
   const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are written
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
   if (dtype != SN_DTYPE_F32)
-    return sn_mlp_backward_chain_bf16_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
-                                             dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
-  return sn_mlp_backward_chain_f32_launch(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
-                                          (hipStream_t)stream);
+    return SN_HEADS(classic, sn_mlp_backward_chain_bf16)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
+                                                         dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
+  return SN_HEADS(classic, sn_mlp_backward_chain_f32)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
+                                                      (hipStream_t)stream);
 }
 
 int sn_generate_rays(const float* c2w, int H, int W, float focal, float near, float far, int x0, int y0, int stride_x,
@@ -259,11 +284,13 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
                             int flags, float* out, void* stream) {
   if (!blob || !x || !out || n_rows < 0) return SN_E_BADARG;
   if (ld < (sigma_only ? 63 : 90)) return SN_E_BADSHAPE;
+  const bool classic = (dtype & SN_DTYPE_CLASSIC_HEADS) && !sigma_only;
+  dtype &= ~SN_DTYPE_CLASSIC_HEADS;
   if (dtype == SN_DTYPE_BF16)
-    return sn_mlp_forward_bf16_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
+    return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
-  return sn_mlp_forward_f32_launch(blob, x, nullptr, n_rows, ld, sigma_only, 1,
-                                   out, nullptr, nullptr, 0, (hipStream_t)stream);
+  return SN_HEADS(classic, sn_mlp_forward_f32)(blob, x, nullptr, n_rows, ld, sigma_only, 1,
+                                               out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int sn_composite_forward(const float* raw, int has_rgb, const float* z_vals, const float* rays, const float* noise,

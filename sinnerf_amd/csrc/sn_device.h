@@ -9,6 +9,19 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 #define SN_DEV __device__ __forceinline__
 
+// The MLP kernel sources are compiled twice (csrc/Makefile): as they are for NeRF(use_new_activation=True) -- ShiftedSoftplus /
+// WidenedSigmoid heads, both reference call sites -- and with -DSN_CLASSIC_HEADS for the constructor's default
+// (models/nerf.py:91-100: ReLU after dir_encoding, Sigmoid after rgb).  The second pass lives in its own kernel namespace and
+// exports <name>_classic_launch; everything but the two head activations (and their derivatives) is the same code.
+#ifdef SN_CLASSIC_HEADS
+#define snk snkc
+constexpr bool SN_NEWACT = false;
+#define SN_LAUNCH_NAME(base) base##_classic_launch
+#else
+constexpr bool SN_NEWACT = true;
+#define SN_LAUNCH_NAME(base) base##_launch
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // sin/cos of 2^b * x for power-of-two frequencies (reference: models/nerf.py:36-41, torch.sin(freq*x)).
 // freq*x is exact in fp32, so the reference value is sin() of an exactly known argument up to ~2^9*|x|.
@@ -63,5 +76,9 @@ SN_DEV float widened_sigmoid(float x) {
   const float SCALE = 1.002f;                  // 1 + 2*EPS, EPS = 1e-3
   return 0.5f * (1.0f + SCALE * tanhf(0.5f * x));
 }
+
+SN_DEV float plain_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }      // nn.Sigmoid (nerf.py:100)
+// rgb head activation / dir_encoding activation of this compilation pass
+SN_DEV float rgb_activation(float x) { return SN_NEWACT ? widened_sigmoid(x) : plain_sigmoid(x); }
 
 SN_DEV int lane_id() { return (int)(threadIdx.x & 63); }

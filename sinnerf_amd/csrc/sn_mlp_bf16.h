@@ -147,7 +147,11 @@ SN_DEV void ssp4_rgb(const float (&x)[4], const f32x4 (&w)[3], f32x2 (&c)[3], fl
     m.x = __builtin_fmaxf(sx.x, 0.0f);
     m.y = __builtin_fmaxf(sx.y, 0.0f);
     const f32x2 ln2 = {0.69314718055994530942f, 0.69314718055994530942f};
-    const f32x2 vv = __builtin_elementwise_fma(l, ln2, m);
+    f32x2 vv = __builtin_elementwise_fma(l, ln2, m);
+    if (!SN_NEWACT) {                            // classic heads: ReLU after dir_encoding (nerf.py:94)
+      vv.x = __builtin_fmaxf(x[2 * p], 0.0f);
+      vv.y = __builtin_fmaxf(x[2 * p + 1], 0.0f);
+    }
     v[2 * p] = vv.x;
     v[2 * p + 1] = vv.y;
 #pragma unroll

@@ -115,9 +115,15 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
       const float k = 0.5f * 1.002f * 0.5f;
       const float tx = (2.0f * o.x - 1.0f) * (1.0f / 1.002f), ty = (2.0f * o.y - 1.0f) * (1.0f / 1.002f),
                   tz = (2.0f * o.z - 1.0f) * (1.0f / 1.002f);
-      gy3[0] = valid ? g.x * k * (1.0f - tx * tx) : 0.0f;
-      gy3[1] = valid ? g.y * k * (1.0f - ty * ty) : 0.0f;
-      gy3[2] = valid ? g.z * k * (1.0f - tz * tz) : 0.0f;
+      if (SN_NEWACT) {
+        gy3[0] = valid ? g.x * k * (1.0f - tx * tx) : 0.0f;
+        gy3[1] = valid ? g.y * k * (1.0f - ty * ty) : 0.0f;
+        gy3[2] = valid ? g.z * k * (1.0f - tz * tz) : 0.0f;
+      } else {                                   // Sigmoid (nerf.py:100): s (1 - s)
+        gy3[0] = valid ? g.x * o.x * (1.0f - o.x) : 0.0f;
+        gy3[1] = valid ? g.y * o.y * (1.0f - o.y) : 0.0f;
+        gy3[2] = valid ? g.z * o.z * (1.0f - o.z) : 0.0f;
+      }
       gsig = valid ? g.w : 0.0f;
       if (valid && h == 0) {
         float4 gy;
@@ -182,7 +188,7 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float gh = __builtin_fmaf(w2[i], gy3[2], __builtin_fmaf(w1[i], gy3[1], w0[i] * gy3[0]));
-          v[i] = gh * (1.0f - expf(-h2[4 * t + q][i]));
+          v[i] = SN_NEWACT ? gh * (1.0f - expf(-h2[4 * t + q][i])) : (h2[4 * t + q][i] > 0.0f ? gh : 0.0f);   // ReLU (nerf.py:94)
         }
         epi32_copy(16 * t + 4 * q, v[0], v[1], v[2], v[3]);
         stage(q, v);
@@ -289,7 +295,7 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
 
 }  // namespace snk
 
-extern "C" int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const float* out_raw,
+extern "C" int SN_LAUNCH_NAME(sn_mlp_backward_chain_f32)(const void* bblob, const float* acts, const float* out_raw,
                                                 const float* g_raw, long n_points, long slot_rows, float* G,
                                                 float* g_out, hipStream_t stream) {
   using namespace snk;

@@ -146,9 +146,15 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
       const float k = 0.5f * 1.002f * 0.5f;                                // d/dy WidenedSigmoid = .2505 (1 - t^2)
       const float tx = (2.0f * o.x - 1.0f) * (1.0f / 1.002f), ty = (2.0f * o.y - 1.0f) * (1.0f / 1.002f),
                   tz = (2.0f * o.z - 1.0f) * (1.0f / 1.002f);
-      gy3[pt][0] = valid ? g.x * k * (1.0f - tx * tx) : 0.0f;
-      gy3[pt][1] = valid ? g.y * k * (1.0f - ty * ty) : 0.0f;
-      gy3[pt][2] = valid ? g.z * k * (1.0f - tz * tz) : 0.0f;
+      if (SN_NEWACT) {
+        gy3[pt][0] = valid ? g.x * k * (1.0f - tx * tx) : 0.0f;
+        gy3[pt][1] = valid ? g.y * k * (1.0f - ty * ty) : 0.0f;
+        gy3[pt][2] = valid ? g.z * k * (1.0f - tz * tz) : 0.0f;
+      } else {                                   // Sigmoid (nerf.py:100): s (1 - s)
+        gy3[pt][0] = valid ? g.x * o.x * (1.0f - o.x) : 0.0f;
+        gy3[pt][1] = valid ? g.y * o.y * (1.0f - o.y) : 0.0f;
+        gy3[pt][2] = valid ? g.z * o.z * (1.0f - o.z) : 0.0f;
+      }
       gsig[pt] = valid ? g.w : 0.0f;
       if (valid && h == 0) {
         float4 gy;
@@ -296,7 +302,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
             const float w1 = lds_aux[snl::BB_AUX_RGBT + 1 * 128 + h * 64 + 16 * t + r];
             const float w2 = lds_aux[snl::BB_AUX_RGBT + 2 * 128 + h * 64 + 16 * t + r];
             const float gh = __builtin_fmaf(w2, gy3[pt][2], __builtin_fmaf(w1, gy3[pt][1], w0 * gy3[pt][0]));
-            v[i] = gh * (1.0f - __expf(-av[pt][r >> 2][r & 3]));
+            v[i] = SN_NEWACT ? gh * (1.0f - __expf(-av[pt][r >> 2][r & 3])) : (av[pt][r >> 2][r & 3] > 0.0f ? gh : 0.0f);   // ReLU (nerf.py:94)
           }
           uint32_t t0, t1;
           epi_copy(act_reg(0, 2 * t + (q >> 2), pt) + (q & 3), v[0], v[1], v[2], v[3], t0, t1);
@@ -412,7 +418,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
 
 }  // namespace snk
 
-extern "C" int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float* acts, const float* out_raw,
+extern "C" int SN_LAUNCH_NAME(sn_mlp_backward_chain_bf16)(const void* bblob, const float* acts, const float* out_raw,
                                                  const float* g_raw, long n_points, long slot_rows, float* G,
                                                  float* g_out, int state_bf16, hipStream_t stream) {
   using namespace snk;

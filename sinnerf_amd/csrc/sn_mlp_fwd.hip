@@ -261,7 +261,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   auto ssp_slice = [&](auto, int, int t, int q, const f32x16& r) __attribute__((always_inline)) {
     float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = shifted_softplus_fast(r[4 * q + i]);
+    for (int i = 0; i < 4; ++i) v[i] = SN_NEWACT ? shifted_softplus_fast(r[4 * q + i]) : relu1(r[4 * q + i]);   // nerf.py:84 / :94
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_RGBW + c * 128 + h * 64 + 16 * t + 4 * q);
@@ -283,16 +283,16 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 #pragma unroll
   for (int i = 0; i < 4; ++i) store_rows(9, 3, i);
 
-  // ---- WidenedSigmoid (nerf.py:144) of the three cross-half sums
+  // ---- WidenedSigmoid (resp. Sigmoid; nerf.py:144) of the three cross-half sums
   {
     float o3[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) o3[c] = c3[c] + __shfl_xor(c3[c], 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c];
     if (valid && h == 0) {
       float4 o;
-      o.x = widened_sigmoid(o3[0]);
-      o.y = widened_sigmoid(o3[1]);
-      o.z = widened_sigmoid(o3[2]);
+      o.x = rgb_activation(o3[0]);
+      o.y = rgb_activation(o3[1]);
+      o.z = rgb_activation(o3[2]);
       o.w = sigma;                               // cat([rgb, sigma]) nerf.py:146
       reinterpret_cast<float4*>(out)[p_raw] = o;
     }
@@ -309,7 +309,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
 }  // namespace snk
 
 // ---------------------------------------------------------------------------------------------------
-extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+extern "C" int SN_LAUNCH_NAME(sn_mlp_forward_f32)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                          int sigma_only, int input_mode, float* out, float* acts, float* emb,
                                          long slot_rows, hipStream_t stream) {
   using namespace snk;
@@ -330,11 +330,21 @@ extern "C" int sn_mlp_forward_f32_launch(const void* blob, const float* in0, con
   } while (0)
   if (store) {
     if (input_mode == 0) SN_LAUNCH(false, 0, true); else SN_LAUNCH(false, 1, true);
+#ifdef SN_CLASSIC_HEADS                         // the sigma-only kernels never reach the heads: sn_api.hip routes them to the main pass
+  } else if (sigma_only) {
+    return -4;
+  } else if (input_mode == 0) {
+    SN_LAUNCH(false, 0, false);
+  } else {
+    SN_LAUNCH(false, 1, false);
+  }
+#else
   } else if (input_mode == 0) {
     if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false);
   } else {
     if (sigma_only) SN_LAUNCH(true, 1, false); else SN_LAUNCH(false, 1, false);
   }
+#endif
 #undef SN_LAUNCH
   return (int)hipGetLastError();
 }

@@ -412,7 +412,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       float o3[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        o3[c] = widened_sigmoid(hsum(c3[pt][c]) + __shfl_xor(hsum(c3[pt][c]), 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c]);
+        o3[c] = rgb_activation(hsum(c3[pt][c]) + __shfl_xor(hsum(c3[pt][c]), 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c]);
       if (valid[pt] && h == 0) {
         float4 o;
         o.x = o3[0]; o.y = o3[1]; o.z = o3[2]; o.w = sigma[pt];
@@ -432,7 +432,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 
 }  // namespace snk
 
-extern "C" int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+extern "C" int SN_LAUNCH_NAME(sn_mlp_forward_bf16)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                           int sigma_only, int input_mode, float* out, float* acts, float* emb,
                                           long slot_rows, int state_bf16, hipStream_t stream) {
   using namespace snk;
@@ -454,8 +454,14 @@ extern "C" int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, co
     if (input_mode == 0) { if (state_bf16) SN_LAUNCH(false, 0, 2); else SN_LAUNCH(false, 0, 1); }
     else { if (state_bf16) SN_LAUNCH(false, 1, 2); else return -4; }    // embedded rows + fp32 state: out of registers, not built
   }
+#ifdef SN_CLASSIC_HEADS                         // the sigma-only kernels never reach the heads: sn_api.hip routes them to the main pass
+  else if (sigma_only) return -4;
+  else if (input_mode == 0) SN_LAUNCH(false, 0, 0);
+  else SN_LAUNCH(false, 1, 0);
+#else
   else if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, 0); else SN_LAUNCH(false, 0, 0); }
   else { if (sigma_only) SN_LAUNCH(true, 1, 0); else SN_LAUNCH(false, 1, 0); }
+#endif
 #undef SN_LAUNCH
   return (int)hipGetLastError();
 }

@@ -71,19 +71,21 @@ def _pack_table(device, code):
 class NeRF(nn.Module):
     """``NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False)``.
 
-    Reference ``models/nerf.py:46-148``.  The HIP kernels implement the configuration both reference call sites
-    construct (``sinnerf.py:137,140``, ``eval.py:136-137``): D=8, W=256, 63/27 inputs, skips=[4],
-    ``use_new_activation=True`` (ShiftedSoftplus / WidenedSigmoid heads).  Other configurations raise
-    ``NotImplementedError`` at construction.
+    Reference ``models/nerf.py:46-148``.  The HIP kernels implement the layer configuration both reference call sites
+    construct (``sinnerf.py:137,140``, ``eval.py:136-137``): D=8, W=256, 63/27 inputs, skips=[4]; other layer
+    configurations raise ``NotImplementedError`` at construction.  Both head variants of ``nerf.py:77-100`` are built:
+    ``use_new_activation=True`` (ShiftedSoftplus / WidenedSigmoid, what SinNeRF uses) and the constructor's default
+    ``False`` (ReLU / Sigmoid).
     """
 
     def __init__(self, D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False,
                  compute_dtype="fp32"):
         super().__init__()
-        if (D, W, in_channels_xyz, in_channels_dir, list(skips)) != (8, 256, 63, 27, [4]) or not use_new_activation:
+        if (D, W, in_channels_xyz, in_channels_dir, list(skips)) != (8, 256, 63, 27, [4]):
             raise NotImplementedError(
-                "sinnerf_amd.NeRF implements the SinNeRF configuration NeRF(D=8, W=256, 63, 27, skips=[4], "
-                "use_new_activation=True) (models/sinnerf.py:137,140)")
+                "sinnerf_amd.NeRF implements the SinNeRF layer configuration NeRF(D=8, W=256, 63, 27, skips=[4]) "
+                "(models/sinnerf.py:137,140)")
+        self.use_new_activation = bool(use_new_activation)
         self.D, self.W = D, W
         self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
         self.skips = skips
@@ -97,13 +99,19 @@ class NeRF(nn.Module):
                 layer = nn.Linear(W, W)
             setattr(self, f"xyz_encoding_{i+1}", nn.Sequential(layer, nn.ReLU(True)))
         self.xyz_encoding_final = nn.Linear(W, W)                    # nerf.py:76
-        # nn.Identity stands in for ShiftedSoftplus / WidenedSigmoid (parameter-free, applied in-kernel):
-        # keeps the state_dict keys "dir_encoding.0.*" / "rgb.0.*" of nerf.py:81-90.
+        # nn.Identity stands in for ShiftedSoftplus / WidenedSigmoid resp. ReLU / Sigmoid (parameter-free, applied
+        # in-kernel): keeps the state_dict keys "dir_encoding.0.*" / "rgb.0.*" of nerf.py:81-100.
         self.dir_encoding = nn.Sequential(nn.Linear(W + in_channels_dir, W // 2), nn.Identity())
         self.sigma = nn.Linear(W, 1)
         self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Identity())
         self._packed = {}          # dtype_code -> (blob tensor, version signature)
         self._pack_generation = 0  # bumped by invalidate_packed(): writes through .data do not bump Parameter._version
+
+    def kernel_dtype(self, code=None):
+        """The ``dtype`` argument of the ``sn_mlp_*`` entry points for this network: the arithmetic code (default: of
+        ``compute_dtype``) plus the head-variant flag."""
+        code = dtype_code(self.compute_dtype) if code is None else code
+        return code if self.use_new_activation else code | _lib.SN_DTYPE_CLASSIC_HEADS
 
     # ---- packed weights -------------------------------------------------------------------------------
     def raw_tensors(self):
@@ -204,7 +212,7 @@ class NeRF(nn.Module):
         code = dtype_code(self.compute_dtype)
         out = torch.empty((x.shape[0], 1 if sigma_only else 4), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib.sn_mlp_forward_embedded(_lib.ptr(self.packed()), code, _lib.ptr(x), x.shape[0],
+            _lib.check(_lib.lib.sn_mlp_forward_embedded(_lib.ptr(self.packed()), self.kernel_dtype(code), _lib.ptr(x), x.shape[0],
                                                         x.shape[1], int(sigma_only), 0, _lib.ptr(out),
                                                         _lib.stream_ptr()), "sn_mlp_forward_embedded")
         return out

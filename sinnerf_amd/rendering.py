@@ -45,7 +45,7 @@ def _mlp(model, rays, z_vals, sigma_only, flags=0):
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.check(_lib.lib.sn_mlp_forward(_lib.ptr(blob), code, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
+    _lib.check(_lib.lib.sn_mlp_forward(_lib.ptr(blob), model.kernel_dtype(code), _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                        int(sigma_only), flags, _lib.ptr(out), _lib.stream_ptr()), "sn_mlp_forward")
     if PROFILE is not None:
         ev1.record()
