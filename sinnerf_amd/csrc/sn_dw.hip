@@ -427,9 +427,11 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
   // fp32: the 256x256 problems run in their own launch (sn_dw_f32.hip, hand-scheduled inner loop), the narrow ones in a second
   // launch of the kernel above -- each group is K-split over one workgroup per CU by itself (group[i]: 0 / 1; other modes: one
   // group, one launch)
+  // ... and so do the bf16-state 256x256 problems (sn_dw_bf16.hip)
   int group[MAX_PROBS];
-  for (int i = 0; i < n; ++i) group[i] = (dtype == 0 && pr[i].var != 0) ? 1 : 0;
-  hp.two_launches = dtype == 0;
+  const bool split_launch = dtype == 0 || dtype == 2;
+  for (int i = 0; i < n; ++i) group[i] = (split_launch && pr[i].var != 0) ? 1 : 0;
+  hp.two_launches = split_launch;
   int splits[MAX_PROBS];
   for (int gsel = 0; gsel < 2; ++gsel) {
     double tot = 0;
@@ -460,7 +462,8 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
   for (int i = 0; i < n; ++i) {
     long ns = splits[i] < max_split ? splits[i] : max_split;
     long per = (rows + ns - 1) / ns;
-    per = (per + KB - 1) / KB * KB;
+    const long gran = (dtype == 2 && pr[i].var == 0) ? 2 * KB : KB;      // sn_dw_bf16.hip consumes chunk PAIRS (an odd tail
+    per = (per + gran - 1) / gran * gran;                                // chunk of the last K-range costs a statement of its own)
     ns = (rows + per - 1) / per;
     const VariantInfo v = VARIANTS[pr[i].var];
     Prob& q = hp.plan.p[i];
@@ -482,6 +485,7 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
 }  // namespace snd
 
 extern "C" int sn_dw_f32_asm_launch(const snd::Plan* plan_host, hipStream_t stream);      // sn_dw_f32.hip
+extern "C" int sn_dw_bf16_asm_launch(const snd::Plan* plan_host, hipStream_t stream);     // sn_dw_bf16.hip
 
 extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype) {
   snd::HostPlan hp;
@@ -503,7 +507,7 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
   int rc;
   if (hp.two_launches) {
     const Plan pa = group_plan(hp, 0), pb = group_plan(hp, 1);
-    rc = sn_dw_f32_asm_launch(&pa, stream);
+    rc = dtype == 0 ? sn_dw_f32_asm_launch(&pa, stream) : sn_dw_bf16_asm_launch(&pa, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, pb);
   } else {
