@@ -107,6 +107,15 @@ SN_DEV void epi_relu_f32(int reg, float x0, float x1, float x2, float x3, float 
 // non-temporally by two different slabs: those partial-line stores cost the chain 0.41 of 1.18 ms and the training forward
 // 0.27 of 1.24 ms (timing builds without the stores), while the fp32-state kernels' 128-byte rows are free.
 constexpr int XS16_PITCH = 144;
+// 8-byte write into a wave's staging tile as inline asm: hipcc guards every LDS WRITE it sees with s_waitcnt vmcnt(0) while
+// LDS-DMA pieces may be in flight (it cannot tell the ring slots from the staging tile) -- at the first staging write of an
+// epilogue that drained the row stores issued two k-steps earlier, a full HBM store round trip per slab.  `lds` = byte offset
+// in LDS (the kernels have no static __shared__: dynamic LDS starts at 0), off = compile-time part.
+SN_DEV void lds_write_b64(unsigned lds, int off, uint32_t lo, uint32_t hi) {
+  typedef unsigned u32x2_lds __attribute__((ext_vector_type(2)));
+  const u32x2_lds v = {lo, hi};
+  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(lds), "v"(v), "n"(off) : "memory");
+}
 static_assert(32 * XS16_PITCH <= XPOSE_WAVE_BYTES, "the tile-pair staging fits the fp32 staging tile");
 constexpr int XP16_PITCH = 80;
 constexpr int XP16_WAVE_BYTES = 32 * XP16_PITCH;            // 2560
@@ -187,7 +196,7 @@ constexpr int act_reg(int set, int kstep, int pt) { return set * 128 + (kstep * 
 //              from that placement).  They still follow the sync point so that they have most of a slab to complete before
 //              the next s_waitcnt vmcnt(0); issued just in FRONT of it they expose the full HBM latency on every slab
 //              (measured: 3.9 us per slab instead of ~1).
-template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, class Pending, class PostSync>
+template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, int VMW = 0, class Pending, class PostSync>
 SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], const char* lw, const u32x4* bv,
                       const char* lw_next, const float* lds_bias, int s_next, int h, RingB& ring, Pending&& pending,
                       PostSync&& post_sync) {
@@ -205,8 +214,11 @@ SN_DEV void slab_bf16(f32x16 (&acc)[PT], f32x16 (&accn)[PT], u32x4 (&af)[4], con
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
     if (ks == GB) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      // VMW > 0: the youngest VMW memory operations are row stores issued BEHIND the previous slab's DMA pieces -- they may
+      // stay in flight (vmcnt retires in issue order); the barrier then must not be a fence (__syncthreads() drains stores)
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
+      if (VMW == 0) __syncthreads();
+      else __builtin_amdgcn_s_barrier();
       ring.begin_static();
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) accn[pt] = load_bias(lds_bias, s_next, h);

@@ -35,6 +35,9 @@
 //
 // Persistent workgroups, 3-slot weight ring with a mid-slab barrier, compile-time DMA piece counts: sn_mlp_pipe.h.
 #include "sn_mlp_bf16.h"
+#ifndef SN_BF16_COUNTED
+#define SN_BF16_COUNTED 1      // counted vmcnt at the sync points of the bf16-state training forward (0: comparison build)
+#endif
 
 namespace snk {
 
@@ -100,6 +103,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
   const unsigned xp16_w = (unsigned)(j * XS16_PITCH + 8 * h);                       // bf16 state: this lane's packed pairs
+  const unsigned xp16_lds = (unsigned)(MLP_BF16_LDS_BYTES + wave * (PT * XPOSE_WAVE_BYTES)) + xp16_w;   // ... as an LDS byte address
   const unsigned xp16_r = (unsigned)((lane >> 3) * XS16_PITCH + 16 * (lane & 7));    // row lane>>3, 16-byte chunk lane&7 of a tile PAIR
   const unsigned g16_off = (unsigned)((lane >> 3) * 512 + 16 * (lane & 7));
 
@@ -167,9 +171,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     };
     auto stage16 = [&](int pt, int t, int qq, uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
       if (STORE == 2) {                          // tile t goes to half t & 1 of the 128-byte staged rows
-        uint2 o;
-        o.x = t0; o.y = t1;
-        *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xp16_w + 64 * (t & 1) + 16 * qq) = o;
+        lds_write_b64(xp16_lds, pt * XPOSE_WAVE_BYTES + 64 * (t & 1) + 16 * qq, t0, t1);
       }
     };
     // memory operation k of finished tile t: k = 0..7 row group (pt = k >> 2, i = k & 3), k = 8 the tile's ReLU sign word
@@ -280,13 +282,16 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     // slab of output tile T_ (compile-time: selects the accumulator set); EPI_ = the previous tile's epilogue into set W_
 #define SNB_SLAB(T_, NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, BV_, EPI_, W_)                                           \
   do {                                                                                                             \
+    /* bf16 state: the eight row stores of an odd finished tile sit behind the DMA pieces of their slab; the next   \
+       slab's sync point leaves them in flight (tiles 3, 5, 7, and tile 0 behind the previous layer's last tile) */ \
+    constexpr int VW_ = (STORE == 2 && SN_BF16_COUNTED && (NK0_) + (NK1_) >= 8 && ((T_) == 0 || (((T_) & 1) && (T_) >= 3))) ? 8 : 0; \
     if (((T_) & 1) == 0)                                                                                           \
-      slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(acc0, acc1, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
+      slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(acc0, acc1, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
                                                      SNB_SNEXT, h, ring,                                           \
                                                      [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNB_W(W_), (T_) - 1, acc1); }, \
                                                      [&](int st, int n) __attribute__((always_inline)) { if ((T_) > 0) mem_step(cur_slot, (T_) - 1, st, n); }); \
     else                                                                                                           \
-      slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(acc1, acc0, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
+      slab_bf16<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(acc1, acc0, af, SNB_LW_CUR, BV_, SNB_LW_NEXT, lds_bias,       \
                                                      SNB_SNEXT, h, ring, [&]() __attribute__((always_inline)) { EPI_(SNB_W(W_), (T_) - 1, acc0); }, \
                                                      [&](int st, int n) __attribute__((always_inline)) { mem_step(cur_slot, (T_) - 1, st, n); }); \
     SNB_ADVANCE();                                                                                                 \
