@@ -129,22 +129,25 @@ def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
 # chain reads the sign words + the 256 B softplus tile (+ 32 B) and writes 10 x 512 B gradients (+ 16 B), the weight-gradient
 # contractions read 11 904 B -- the step is bound by HBM, not by the MFMA rate.
 TRAIN_BF16_BYTES_PER_POINT = (5120 + 256 + 512 + 16) + (256 + 256 + 32 + 5120 + 16) + 11904
-HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 measured streaming ceiling)
+HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/s spec (stock kernels: 6.2 read / 6.7 write / 5.2 copy, tools/hbm_calib.py)
 
 
 def train_hbm_roofline(ms_per_step, n_points):
     """`roofline` of the bf16 training step: algorithmic HBM bytes / step time against the HBM peak; `traffic` = the bytes
-    the PMC counters saw (profiles/r02_run3_train_pmc.json, FETCH_SIZE x2 + WRITE_SIZE of the three MLP stages)."""
+    the PMC counters saw (newest profiles/r*_train_pmc.json: FETCH_SIZE x2 + WRITE_SIZE of the MLP stages of the bf16 step)."""
     traffic, note = None, "no PMC summary"
     try:
-        k = json.load(open(os.path.join(REPO, "profiles", "r02_run3_train_pmc.json")))["kernels"]
-        per_pt = sum(v["bytes_per_point"] for name, v in k.items() if "bf16" in name)
-        traffic, note = per_pt * n_points, "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/r02_run3_train_pmc.json)"
+        import glob
+        path = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_train_pmc.json")))[-1]
+        k = json.load(open(path))["kernels"]
+        per_pt = sum(v["bytes_per_point"] for name, v in k.items() if v.get("step", "bf16" if "bf16" in name else "fp32") == "bf16")
+        traffic = per_pt * n_points
+        note = "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/%s)" % os.path.basename(path)
     except Exception:                               # noqa: BLE001
         pass
     alg = TRAIN_BF16_BYTES_PER_POINT * n_points
     ach = alg / (ms_per_step * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "bf16 training step: mlp_fwd_bf16_kernel<STORE> + mlp_bwd_chain_bf16_kernel + dw_kernel (coarse + fine)",
+    return {"bound": "hbm", "kernel": "bf16 training step: mlp_fwd_bf16_kernel<STORE> + mlp_bwd_chain_bf16_kernel + dw_bf16_asm_kernel + dw_kernel (coarse + fine)",
             "achieved": ach, "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": ach / HBM_PEAK_TBS, "traffic": traffic,
             "traffic_note": note, "algorithmic_bytes_per_step": alg}
 

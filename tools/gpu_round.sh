@@ -27,3 +27,5 @@ echo "== pmc train (HBM bytes of the training kernels)"
 timeout 600 $P --pmc FETCH_SIZE -o pmc_train_fetch -- python $R/tools/train_bench.py > $R/gpurun_out/prof_pmc_train_fetch.log 2>&1; echo "exit $?"
 timeout 600 $P --pmc WRITE_SIZE -o pmc_train_write -- python $R/tools/train_bench.py > $R/gpurun_out/prof_pmc_train_write.log 2>&1; echo "exit $?"
 cd $R
+echo "== pmc train (cycles, MFMA-busy, clock of the training kernels)"
+bash tools/train_pmc.sh > gpurun_out/train_pmc.log 2>&1; echo "exit $?"; tail -12 gpurun_out/train_pmc.txt

@@ -10,7 +10,9 @@ timeout 300 $P --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_
 timeout 300 $P --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -o p2 -- python $R/tools/train_bench.py > $R/gpurun_out/tpmc2.log 2>&1; echo "p2 exit $?"
 cd $R
 python - <<'PY' | tee gpurun_out/train_pmc.txt
-import csv, collections, glob
+import csv, collections, glob, json, statistics
+out = {"command": "rocprofv3 --kernel-trace --pmc <SQ counters> -- python tools/train_bench.py (two passes)",
+       "note": "median over the fine-pass-sized dispatches of each kernel (the first dispatches after an allocation run at lower clocks)", "kernels": {}}
 for tag in ("p1", "p2"):
     fs = glob.glob(f"gpurun_out/tpmc/**/{tag}_counter_collection.csv", recursive=True)
     if not fs: print(tag, "no counters"); continue
@@ -19,20 +21,23 @@ for tag in ("p1", "p2"):
         k = (r["Kernel_Name"][:60], r["Dispatch_Id"])
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
         dur[k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    best = {}
-    for k, d in dur.items():
-        if k[0] not in best or d > dur[best[k[0]]]: best[k[0]] = k
-    for name, k in sorted(best.items(), key=lambda kv: -dur[kv[1]])[:8]:
-        c = per[k]; ms = dur[k]; cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8
-        line = "%-60s ms %.3f clock %.3f GHz" % (name, ms, cyc / (ms * 1e6) if ms else 0)
+    for name in sorted({k[0] for k in dur}):
+        ks = [k for k in dur if k[0] == name]; mx = max(dur[k] for k in ks)
+        if mx < 0.4: continue
+        ks = [k for k in ks if dur[k] > 0.6 * mx]
+        med = lambda f: statistics.median(f(k) for k in ks)
+        cyc = med(lambda k: per[k]["GRBM_GUI_ACTIVE"] / 8)
+        rec = out["kernels"].setdefault(name, {})
+        rec.update(dispatches=len(ks), ms=med(lambda k: dur[k]), gpu_cycles=cyc, clock_ghz=med(lambda k: per[k]["GRBM_GUI_ACTIVE"] / 8 / (dur[k] * 1e6)))
         if tag == "p1":
-            line += "  mfma_busy %.3f  wait_any %.3f  wait_inst %.3f  active_inst %.3f" % (
-                c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-                c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"])
+            rec.update(mfma_busy=med(lambda k: per[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (per[k]["GRBM_GUI_ACTIVE"] / 8)),
+                       wait_any=med(lambda k: per[k]["SQ_WAIT_ANY"] / per[k]["SQ_WAVE_CYCLES"]))
         else:
-            m = max(c["SQ_INSTS_MFMA"], 1)
-            line += "  lds_conflict/idx_active %.3f  lds/mfma %.2f  valu/mfma %.2f  salu/mfma %.2f  wait_lds_raw %.3g" % (
-                c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1), c["SQ_INSTS_LDS"] / m,
-                (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / m, c["SQ_INSTS_SALU"] / m, c["SQ_WAIT_INST_LDS"])
-        print(tag, line)
+            m = lambda k: max(per[k]["SQ_INSTS_MFMA"], 1)
+            rec.update(lds_per_mfma=med(lambda k: per[k]["SQ_INSTS_LDS"] / m(k)), valu_per_mfma=med(lambda k: (per[k]["SQ_INSTS_VALU"] - per[k]["SQ_INSTS_MFMA"]) / m(k)),
+                       salu_per_mfma=med(lambda k: per[k]["SQ_INSTS_SALU"] / m(k)),
+                       lds_bank_conflict_frac=med(lambda k: per[k]["SQ_LDS_BANK_CONFLICT"] / max(per[k]["SQ_LDS_IDX_ACTIVE"], 1)))
+for name, rec in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["ms"]):
+    print("%-60s" % name, " ".join("%s=%.3g" % kv for kv in rec.items()))
+json.dump(out, open("gpurun_out/train_pmc_cycles.json", "w"), indent=1)
 PY
