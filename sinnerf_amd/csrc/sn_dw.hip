@@ -18,6 +18,9 @@
 
 namespace snd {
 
+#ifndef SN_DW_NARROW_2WG
+#define SN_DW_NARROW_2WG 1      // bf16-state narrow problems: two workgroups per CU (0: comparison build)
+#endif
 #ifndef SN_DW_CPOL
 #define SN_DW_CPOL 2      // nt: G and X are streamed once (measured -3 % in the bandwidth-bound bf16 mode, neutral in fp32)
 #endif
@@ -93,7 +96,7 @@ SN_DEV unsigned dw_pack2(float a, float b) {
 // conflict-free across lanes), converts them to a bf16x8 fragment (RNE) and keeps the fp32 column sums for the bias
 // gradient.  16 MFMAs of 32 cycles per chunk instead of 128 of 64: the kernel becomes HBM-bound.
 // MODE 0: fp32 MFMAs.  1: bf16 MFMAs, fp32 tiles.  2: bf16 MFMAs, bf16 A and B tiles.  3: bf16 MFMAs, bf16 A tile, fp32 B tile.
-template <int MT, int NT, int WM, int WN, int MODE>
+template <int MT, int NT, int WM, int WN, int MODE, int LDSB = DW_LDS_BYTES>
 SN_DEV void run_task(const Task& t, char* smem, int tid) {
   constexpr bool BF16 = MODE != 0;
   constexpr int EA = (MODE >= 2) ? 2 : 4, EB = (MODE == 2) ? 2 : 4;
@@ -103,8 +106,8 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   // Ring depth: as many chunks as the 128 KB of LDS hold, at most 16 (fp32 256x256: 4 x 32 KB as before; bf16 state: 8 x 16 KB;
   // the narrow problems 16 x 5..9 KB).  One CU streams (NBUF-1) chunks per HBM latency: with the bf16 tiles at depth 4 the
   // narrow problems ran at 8 GB/s per CU (15 KB in flight), latency-bound far below their share of the HBM rate.
-  constexpr int NBUF = (DW_LDS_BYTES / BUF >= 16) ? 16 : (DW_LDS_BYTES / BUF >= 8) ? 8 : 4;
-  static_assert(NBUF * BUF <= DW_LDS_BYTES, "ring fits the LDS allocation");
+  constexpr int NBUF = (LDSB / BUF >= 16) ? 16 : (LDSB / BUF >= 8) ? 8 : 4;
+  static_assert(NBUF * BUF <= LDSB, "ring fits the LDS allocation");
   // DMA instructions per thread per chunk.  A 32-wide A tile (variants 4/5) is only 128 16-byte pieces: waves 2,3 issue
   // none of it, so their vmcnt budget is one instruction per chunk smaller (the wait must be exact per wave).
   constexpr int CH_A = KB * WA * EA / 16, CH_B = KB * WB * EB / 16;
@@ -335,6 +338,22 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks,
   }
 }
 
+// The narrow problems of the bf16-state mode in a kernel of their own: half the LDS and at most 256 registers per wave, so that
+// TWO workgroups share a CU -- these problems are latency-bound (few MFMAs per chunk), a second set of waves fills the stalls.
+constexpr int DW_NARROW_LDS_BYTES = 65536;
+__global__ void __launch_bounds__(256, 2) dw_narrow_bf16_kernel(const Plan plan) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Task t = task_of(plan, (int)blockIdx.x);
+  const int tid = threadIdx.x;
+  switch (t.variant & 0xff) {                    // variants 1 / 3 contract with the embedded inputs, which stay fp32 (MODE 3)
+    case 1: run_task<4, 1, 2, 2, 3, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    case 2: run_task<2, 4, 2, 2, 2, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    case 3: run_task<2, 1, 2, 2, 3, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    case 4: run_task<1, 2, 1, 4, 2, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    default: run_task<1, 1, 1, 4, 2, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+  }
+}
+
 // ---- finish: deterministic sum of the K-split partials, written straight into the parameter-shaped gradients -------------
 struct Seg {                                    // dst[r][dst_col0 + c] (+)= sum_j src[j*stride + (src_row0 + r)*src_ld + src_col0 + c]
   float* dst;
@@ -437,17 +456,19 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
     double tot = 0;
     for (int i = 0; i < n; ++i) if (group[i] == gsel) tot += cost[pr[i].var];
     if (tot == 0) continue;
+    // (the bf16-state narrow problems run two workgroups per CU: dw_narrow_bf16_kernel)
+    const int target = (gsel == 1 && dtype == 2 && SN_DW_NARROW_2WG) ? 2 * TARGET_WGS : TARGET_WGS;
     double frac[MAX_PROBS];
     int sum = 0;
     for (int i = 0; i < n; ++i) {
       if (group[i] != gsel) continue;
-      const double ideal = TARGET_WGS * cost[pr[i].var] / tot;
+      const double ideal = target * cost[pr[i].var] / tot;
       splits[i] = (int)ideal < 1 ? 1 : (int)ideal;
       frac[i] = ideal - (int)ideal;
       sum += splits[i];
     }
     bool used[MAX_PROBS] = {};
-    while (sum < TARGET_WGS) {                                    // largest remainders get the slack
+    while (sum < target) {                                        // largest remainders get the slack
       int best = -1;
       for (int i = 0; i < n; ++i) if (group[i] == gsel && !used[i] && (best < 0 || frac[i] > frac[best])) best = i;
       if (best < 0) break;
@@ -509,7 +530,12 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
     const Plan pa = group_plan(hp, 0), pb = group_plan(hp, 1);
     rc = dtype == 0 ? sn_dw_f32_asm_launch(&pa, stream) : sn_dw_bf16_asm_launch(&pa, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, pb);
+    if (dtype == 2 && SN_DW_NARROW_2WG) {
+      SN_ENSURE_DYN_LDS(dw_narrow_bf16_kernel, DW_NARROW_LDS_BYTES);
+      hipLaunchKernelGGL(dw_narrow_bf16_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_NARROW_LDS_BYTES, stream, pb);
+    } else {
+      hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, pb);
+    }
   } else {
     hipLaunchKernelGGL(dw_kernel, dim3((unsigned)hp.plan.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, hp.plan);
   }
