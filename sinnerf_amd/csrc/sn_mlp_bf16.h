@@ -57,28 +57,27 @@ SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3) {
 // 32-bit word per lane and output tile (32 features x 64 points = 256 B per wave) instead of the 4 KB of activations the
 // chain otherwise re-reads for [h > 0].
 SN_DEV void epi_relu_bits(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1, uint32_t& bits) {
-  uint32_t b;                                   // (the sign mask is a VOP2 literal: no register -- this kernel has none to spare)
-  asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\t"
-               "v_lshrrev_b32 %2, 1, %2\n\tv_and_b32 %3, 0x80008000, %0\n\t"
-               "v_pk_max_i16 %0, %0, 0\n\tv_or_b32 %2, %2, %3\n\t"
-               "v_and_b32 %3, 0x80008000, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
-               "v_pk_max_i16 %1, %1, 0\n\tv_or_b32 %2, %2, %3\n\t"
-               "v_accvgpr_write_b32 a[%8], %0\n\tv_accvgpr_write_b32 a[%9], %1"
-               : "=&v"(t0), "=&v"(t1), "+v"(bits), "=&v"(b)
-               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
+  const uint32_t sm = 0x80008000u;              // in an SGPR: v_and_or_b32 takes no literal on gfx9, and no VGPR is spent on it
+  asm volatile("v_cvt_pk_bf16_f32 %0, %3, %4\n\tv_cvt_pk_bf16_f32 %1, %5, %6\n\t"
+               "v_lshrrev_b32 %2, 1, %2\n\tv_and_or_b32 %2, %0, %9, %2\n\t"
+               "v_pk_max_i16 %0, %0, 0\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+               "v_and_or_b32 %2, %1, %9, %2\n\tv_pk_max_i16 %1, %1, 0\n\t"
+               "v_accvgpr_write_b32 a[%7], %0\n\tv_accvgpr_write_b32 a[%8], %1"
+               : "=&v"(t0), "=&v"(t1), "+v"(bits)
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1), "s"(sm));
 }
 // fp32 ReLU form (layer 8: the fp32 outputs also feed the sigma head): the signs are those of the fp32 inputs
 SN_DEV void epi_relu_f32_bits(int reg, float x0, float x1, float x2, float x3, float (&v)[4], uint32_t& t0, uint32_t& t1,
                               uint32_t& bits) {
+  const uint32_t sm = 0x80008000u;
   asm volatile("v_cvt_pk_bf16_f32 %0, %7, %8\n\tv_cvt_pk_bf16_f32 %1, %9, %10\n\t"
                "v_max_f32 %2, 0, %7\n\tv_max_f32 %3, 0, %8\n\tv_max_f32 %4, 0, %9\n\tv_max_f32 %5, 0, %10\n\t"
-               "v_lshrrev_b32 %6, 1, %6\n\tv_and_b32 %0, 0x80008000, %0\n\t"
-               "v_and_b32 %1, 0x80008000, %1\n\tv_or_b32 %6, %6, %0\n\t"
+               "v_lshrrev_b32 %6, 1, %6\n\tv_and_or_b32 %6, %0, %13, %6\n\t"
                "v_lshrrev_b32 %6, 1, %6\n\tv_cvt_pk_bf16_f32 %0, %2, %3\n\t"
-               "v_or_b32 %6, %6, %1\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+               "v_and_or_b32 %6, %1, %13, %6\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
                "v_accvgpr_write_b32 a[%11], %0\n\tv_accvgpr_write_b32 a[%12], %1"
                : "=&v"(t0), "=&v"(t1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "+v"(bits)
-               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1), "s"(sm));
 }
 SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1) {   // no activation
   asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
@@ -111,10 +110,9 @@ constexpr int XS16_PITCH = 144;
 // LDS-DMA pieces may be in flight (it cannot tell the ring slots from the staging tile) -- at the first staging write of an
 // epilogue that drained the row stores issued two k-steps earlier, a full HBM store round trip per slab.  `lds` = byte offset
 // in LDS (the kernels have no static __shared__: dynamic LDS starts at 0), off = compile-time part.
+// Two separate registers (ds_write2_b32, dword offsets off/4 and off/4 + 1 <= 255): no v_mov pair to build a 64-bit operand.
 SN_DEV void lds_write_b64(unsigned lds, int off, uint32_t lo, uint32_t hi) {
-  typedef unsigned u32x2_lds __attribute__((ext_vector_type(2)));
-  const u32x2_lds v = {lo, hi};
-  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(lds), "v"(v), "n"(off) : "memory");
+  asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(lds), "v"(lo), "v"(hi), "n"(off / 4), "n"(off / 4 + 1) : "memory");
 }
 static_assert(32 * XS16_PITCH <= XPOSE_WAVE_BYTES, "the tile-pair staging fits the fp32 staging tile");
 constexpr int XP16_PITCH = 80;

@@ -128,6 +128,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
   const unsigned xp16_w = (unsigned)(j * XP16_PITCH + 8 * h);                        // incoming activation tile (softplus values)
   const unsigned xp16_r = (unsigned)((lane >> 2) * XP16_PITCH + 16 * (lane & 3));
   const unsigned xs16_w = (unsigned)(j * XS16_PITCH + 8 * h);                        // outgoing gradient tile PAIRS (sn_mlp_bf16.h)
+  const unsigned xs16_lds = (unsigned)(BWD16_TAIL_BYTES + 3 * BWD16_RING_SLOT + wave * (PT * XPOSE_WAVE_BYTES)) + xs16_w;   // ... as an LDS byte address
   const unsigned xs16_r = (unsigned)((lane >> 3) * XS16_PITCH + 16 * (lane & 7));
   const unsigned g16_off = (unsigned)((lane >> 3) * 512 + 16 * (lane & 7));
   char* const xl = smem + BWD16_TAIL_BYTES + 3 * BWD16_RING_SLOT + 4 * PT * XPOSE_WAVE_BYTES + wave * (PT * XP16_WAVE_BYTES);
@@ -235,9 +236,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
     };
     auto stage = [&](int pt, int t, int qq, const float (&v)[4], uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
       if (S16) {
-        uint2 o;
-        o.x = t0; o.y = t1;
-        *reinterpret_cast<uint2*>(xp + pt * XPOSE_WAVE_BYTES + xs16_w + 64 * (t & 1) + 16 * qq) = o;
+        lds_write_b64(xs16_lds + pt * XPOSE_WAVE_BYTES, 64 * (t & 1) + 16 * qq, t0, t1);       // (inline asm: sn_mlp_bf16.h)
       } else {
         f32x4 o;
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];

@@ -171,7 +171,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     };
     auto stage16 = [&](int pt, int t, int qq, uint32_t t0, uint32_t t1) __attribute__((always_inline)) {
       if (STORE == 2) {                          // tile t goes to half t & 1 of the 128-byte staged rows
-        lds_write_b64(xp16_lds, pt * XPOSE_WAVE_BYTES + 64 * (t & 1) + 16 * qq, t0, t1);
+        lds_write_b64(xp16_lds + pt * XPOSE_WAVE_BYTES, 64 * (t & 1) + 16 * qq, t0, t1);    // (ds_write2 offsets reach 1020 B)
       }
     };
     // memory operation k of finished tile t: k = 0..7 row group (pt = k >> 2, i = k & 3), k = 8 the tile's ReLU sign word
