@@ -115,3 +115,58 @@ def test_bf16_backward_blob_table_covers_the_transposed_weights_once():
     assert ((aux >> 30) & 1 == 1).all()
     at, ao = (aux >> 20) & 0x3ff, aux & 0xfffff
     assert sorted(ao[at == 22].tolist()) == list(range(384)) and sorted(ao[at == 20].tolist()) == list(range(256))
+
+
+def test_generated_instruction_streams_are_well_formed(tmp_path):
+    """tools/gen_dw_f32.py / gen_dw_bf16.py / gen_bf16_trunk.py (run by csrc/Makefile): deterministic output, the MFMA count
+    the kernels' tilings imply, every accumulator block touched once per k-step, and the DMA destination set one
+    instruction ahead of its use (m0 -> LDS-DMA needs a wait state hipcc cannot insert into inline asm)."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    def check_m0(body):
+        for i, l in enumerate(body):
+            if l.startswith("global_load_lds"):
+                prev = [k for k in range(i) if body[k].startswith("s_add_u32 m0")]
+                assert prev and i - prev[-1] >= 2, (i, l)                       # at least one instruction in between
+
+    f32 = load("gen_dw_f32").gen()
+    assert f32 == load("gen_dw_f32").gen()
+    mf = [l for l in f32 if l.startswith("v_mfma_f32_32x32x2_f32")]
+    assert len(mf) == 128 and len({re.match(r"v_mfma\S+ a\[(\d+):", l).group(1) for l in mf}) == 16   # 8 k-step pairs x 16 blocks
+    assert sum(l.startswith("global_load_lds") for l in f32) == 8               # A + B tile of a 16-point chunk: 8 x 4 KB
+    check_m0(f32)
+
+    g16 = load("gen_dw_bf16")
+    pair, tail = g16.gen(), g16.gen_tail()
+    assert pair == g16.gen()
+    for body, n_mfma, n_reads, n_dma in ((pair, 32, 32, 8), (tail, 16, 16, 0)):
+        mf = [l for l in body if l.startswith("v_mfma_f32_32x32x16_bf16")]
+        assert len(mf) == n_mfma and len({re.match(r"v_mfma\S+ a\[(\d+):", l).group(1) for l in mf}) == 16
+        assert sum(l.startswith("ds_read_b64_tr_b16") for l in body) == n_reads
+        assert sum(l.startswith("global_load_lds") for l in body) == n_dma
+        check_m0(body)
+        # a fragment set is complete (lgkmcnt(0)) before the first MFMA that reads it
+        first_mfma = next(i for i, l in enumerate(body) if l.startswith("v_mfma"))
+        assert any(l == "s_waitcnt lgkmcnt(0)" for l in body[:first_mfma])
+    assert pair[0] == "s_waitcnt vmcnt(16)" and pair[1] == "s_barrier"          # two chunks landed, four (x 4 pieces) in flight
+
+    out = tmp_path / "trunk.inc"
+    trunk = load("gen_bf16_trunk")
+    import sys
+    argv = sys.argv
+    try:
+        sys.argv = ["gen_bf16_trunk.py", str(out)]
+        trunk.main()
+    finally:
+        sys.argv = argv
+    text = out.read_text()
+    assert text.count("v_mfma_f32_32x32x16_bf16") == 2176                       # 72 slabs of a wave's two point tiles
