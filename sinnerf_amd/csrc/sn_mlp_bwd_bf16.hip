@@ -12,6 +12,9 @@
 // weight-gradient contractions -- and reads the stored fp32 forward activations for the derivative masks:
 //   ReLU (nerf.py:73) [h > 0];  ShiftedSoftplus (act.py:33) 1 - exp(-h2);  WidenedSigmoid (act.py:18) .2505 (1 - t^2).
 #include "sn_mlp_bf16.h"
+#ifndef SN_BF16_COUNTED
+#define SN_BF16_COUNTED 1      // counted vmcnt waits of the bf16-state chain (0: comparison build)
+#endif
 
 namespace snk {
 
@@ -212,7 +215,14 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
       if (S16 && !values) {
         if (k == 0) {
           const char* src = reinterpret_cast<const char*>(acts) + (((long)9 * slot_rows + p_wave + 8 * slot + t) * 256 + 128) * 2;
+#if SN_BF16_COUNTED
+          // inline asm: the WAIT is ours (sign_wait) -- hipcc treats loads and stores in flight as unordered and would drain the
+          // row stores issued behind this load with vmcnt(0) (s_nop 4: SALU write of the base -> its use as a VMEM address)
+          unsigned so = (unsigned)lane * 4u;
+          asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 nt" : "=v"(sign_word) : "v"(so), "s"(src) : "memory");
+#else
           sign_word = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src + lane * 4));
+#endif
         }
       } else if (S16) {
         // row-coalesced: lane -> (row lane>>2 [+16], 16-byte chunk lane&3) of the 32-point x 64-byte tile; 2 loads per
@@ -330,6 +340,13 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
       constexpr int W = decltype(wset)::value;
       constexpr bool SIG = decltype(with_sigma)::value;
       if (!S16) act_turn(false);
+#if SN_BF16_COUNTED
+      // the sign word of tile t was requested in slab t; behind it only the eight row stores of tile t-1 (odd t-1) were issued
+      if (S16) {
+        if (t >= 2 && (t & 1) == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(sign_word));
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(sign_word));
+      }
+#endif
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -366,12 +383,15 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
     // and the DMA pieces, one per k-step: sn_mlp_bf16.h).
 #define SNC_SLAB(T_, NK_, SET_, NB_, EPI_, W_, MASK_)                                                              \
   do {                                                                                                             \
+    /* bf16 state: the eight row stores of an odd finished tile sit behind the DMA pieces (and the sign-word load,  \
+       already waited for) of their slab: the next sync point leaves them in flight (sn_mlp_bf16.h VMW) */            \
+    constexpr int VW_ = (S16 && SN_BF16_COUNTED && (NK_) >= 16 && ((T_) == 0 || (((T_) & 1) && (T_) >= 3))) ? 8 : 0; \
     if (((T_) & 1) == 0)                                                                                           \
-      slab_bf16<NK_, 0, SET_, SET_, 2, 0, NB_>(acc0, acc1, af, SNC_LW_CUR, static_cast<const u32x4*>(nullptr), SNC_LW_NEXT, lds_zero, SNC_SNEXT, h, \
+      slab_bf16<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(acc0, acc1, af, SNC_LW_CUR, static_cast<const u32x4*>(nullptr), SNC_LW_NEXT, lds_zero, SNC_SNEXT, h, \
           ring, [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNC_W(W_), (T_) - 1, acc1); },           \
           [&](int st, int n) __attribute__((always_inline)) { mem_step(out_slot, (T_) - 1, mask_slot, T_, MASK_, st, n); }); \
     else                                                                                                           \
-      slab_bf16<NK_, 0, SET_, SET_, 2, 0, NB_>(acc1, acc0, af, SNC_LW_CUR, static_cast<const u32x4*>(nullptr), SNC_LW_NEXT, lds_zero, SNC_SNEXT, h, \
+      slab_bf16<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(acc1, acc0, af, SNC_LW_CUR, static_cast<const u32x4*>(nullptr), SNC_LW_NEXT, lds_zero, SNC_SNEXT, h, \
           ring, [&]() __attribute__((always_inline)) { EPI_(SNC_W(W_), (T_) - 1, acc0); },                         \
           [&](int st, int n) __attribute__((always_inline)) { mem_step(out_slot, (T_) - 1, mask_slot, T_, MASK_, st, n); }); \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
