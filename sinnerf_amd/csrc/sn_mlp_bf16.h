@@ -182,11 +182,12 @@ constexpr int act_reg(int set, int kstep, int pt) { return set * 128 + (kstep * 
 //              (NK % 4 == 0 everywhere except the four dir_encoding slabs, whose phases 0,2,0,2 are still static).
 //   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead): compile-time -> no DMA branches
 //              (a K = 288 slab ends in a half piece that only waves 0,1 carry).
-//              (Measured and dropped for the bf16-state chain: a COUNTED protocol -- post_sync behind the slab's last DMA piece
-//              with its row stores last, s_waitcnt vmcnt(8) in front of the next epilogue so that the rows stay in flight, a raw
-//              s_barrier, every LDS access near the pieces as inline asm so that hipcc does not guard it with vmcnt(0) --
-//              removed 39 of 74 full drains from the code and changed nothing: 1.04 ms either way.  The waves' parked time
-//              (PMC SQ_WAIT_ANY 44 %) is not the store drain; non-temporal stores are acknowledged by the L2 quickly.)
+//   VMW        counted wait at the sync point: the youngest VMW memory operations (row stores issued behind the previous slab's
+//              DMA pieces) stay in flight; the barrier is then a raw s_barrier (a __syncthreads() fence drains stores).  Together
+//              with the staging writes and the chain's sign-word load as inline asm (hipcc guards LDS writes / mixed loads and
+//              stores with vmcnt(0)) this removes the per-slab store drain: -3 % (forward) / -7 % (chain) GPU cycles, waves
+//              parked 41 -> 36 % in the chain -- the wall time of these launches did not move on the boxes measured (1.0 ms
+//              either way: the first attempt at this, round 2 run 4, was dropped for that reason).
 //   post_sync  (step, n_steps): the memory steps of the training kernels (activation-tile row stores, then the loads of the
 //              next tile's masks), called once per k-step behind the sync point and behind the k-steps that carry the slab's
 //              DMA pieces: the callee deals its operations evenly over the n_steps calls -- one vector-memory instruction
