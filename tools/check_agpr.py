@@ -7,7 +7,9 @@ guarantees are checked on the generated code instead:
   2. no VALU instruction writes a register an MFMA reads within the next 2 wait states (VALU write -> MFMA read hazard);
   3. no VALU / LDS / memory instruction reads an MFMA result before two further MFMAs (or 12 other instructions) have issued
      (MFMA write -> VALU read hazard: 11 wait states for the 8-pass bf16 MFMA, 18 for the 16-pass fp32 one);
-  4. the destination of a global load issued from inline asm is not referenced before the next s_waitcnt vmcnt.
+  4. the destination of a global load issued from inline asm is not referenced before the next s_waitcnt vmcnt;
+  5. a vector-memory instruction inside inline asm does not use an SGPR address within 5 wait states of the SALU instruction
+     that wrote it (hipcc pads this hazard for its own instructions only).
 usage: check_agpr.py file.s"""
 import re, sys
 
@@ -24,6 +26,15 @@ def vregs(tok):
     return out
 
 kern = None; ina = False; ins = []; bad_agpr = []; spills = 0; pend_ld = set(); bad_async = []
+sgpr_written = {}; clock = 0; bad_sgpr = []
+
+def sregs(tok):
+    out = set()
+    for m in re.finditer(r'\bs(\d+)\b|\bs\[(\d+):(\d+)\]', tok):
+        if m.group(1): out.add(int(m.group(1)))
+        else: out |= set(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
 for ln, l in enumerate(open(sys.argv[1]), 1):
     m = re.match(r'^(_Z\S*(?:mlp_(?:fwd_bf16|fwd_bf16_v3|fwd_f32|bwd_chain_bf16|bwd_chain_f32)_kernel|dw_f32_asm_kernel|dw_bf16_asm_kernel)\S*):', l)
     if m: kern = m.group(1); continue
@@ -46,6 +57,13 @@ for ln, l in enumerate(open(sys.argv[1]), 1):
     else:
         dst = set(); src = set().union(*[vregs(p) for p in parts]) if parts else set()
     ins.append((ln, op, dst, src, is_valu, t, reads_regs))
+    # 5. SALU write -> VMEM address inside inline asm
+    if ina and op.startswith(('global_', 'buffer_', 'flat_')) and parts:
+        for r in sregs(' '.join(parts[1:])):
+            if r in sgpr_written and clock - sgpr_written[r] < 6: bad_sgpr.append((ln, t))
+    if op.startswith('s_') and not op.startswith(('s_nop', 's_waitcnt', 's_barrier', 's_cmp', 's_cbranch', 's_branch', 's_endpgm')) and parts:
+        for r in sregs(parts[0]): sgpr_written[r] = clock
+    clock += (int(t.split()[1], 0) + 1) if op == 's_nop' else 8 if op.startswith('v_mfma') else 1
     # 4. destination registers of a global load issued from inline asm (the wait is hand-placed) are not touched by anything
     #    until an s_waitcnt vmcnt has issued
     if op == 's_waitcnt' and 'vmcnt' in args: pend_ld = set()
@@ -73,9 +91,10 @@ for i, (ln, op, dst, src, is_valu, t, _rr) in enumerate(ins):
         j += 1
 
 print(f"compiler-allocated AGPR references: {len(bad_agpr)}; scratch instructions: {spills}; "
-      f"VALU->MFMA read hazards: {len(haz1)}; MFMA->VALU read hazards: {len(haz2)}; early uses of asm loads: {len(bad_async)}")
+      f"VALU->MFMA read hazards: {len(haz1)}; MFMA->VALU read hazards: {len(haz2)}; early uses of asm loads: {len(bad_async)}; SALU->VMEM address hazards in asm: {len(bad_sgpr)}")
+for b in bad_sgpr[:5]: print("  sgpr  line %d: %s" % b)
 for b in bad_async[:5]: print("  async line %d: %s" % b)
 for b in bad_agpr[:5]: print("  agpr  line %d: %s" % b)
 for b in haz1[:5]: print("  haz1  line %d: %s  ->  %s" % b)
 for b in haz2[:5]: print("  haz2  line %d: %s  ->  %s" % b)
-sys.exit(1 if bad_agpr or spills or haz1 or haz2 or bad_async else 0)
+sys.exit(1 if bad_agpr or spills or haz1 or haz2 or bad_async or bad_sgpr else 0)
