@@ -195,12 +195,81 @@ def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2, graph=False):
             "train_rays_per_s_total": world * rays.shape[0] / step_s, "per_rank_tflops": tflop,
             "frac_of_mfma_peak": tflop / PEAK_TFLOPS[dtype],
             "all_reduce_us": float(np.mean(ar_us)) if ar_us else 0.0, "all_reduce_bytes": int(flat.flat.numel() * 4),
-            "all_reduce_backend": (dist.get_backend() if world > 1 else "none (world 1)"),
+            "all_reduce_backend": (dist.get_backend() if world > 1 else "none (world 1)"), "rccl_version": rccl_version(),
             "n_ranks_seen": n_seen, "replicas_identical_after": steps + warmup,
             **({"roofline": train_hbm_roofline(step_s * 1e3, pts)} if dtype == "bf16" else {}),
             "optimizer": "FlatAdam (sn_adam_step, one launch)", "loss": float(out["loss"].detach()),
             "launch": "zero/forward/loss/backward replayed from ONE captured HIP graph; all-reduce + Adam eager" if graph
                       else "eager (every kernel launched from Python)"}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """Self-launch: `python bench.py --gpus N` with no WORLD_SIZE in the environment starts N copies of itself, one rank per
+    process (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set as torchrun would), waits for all of
+    them and returns the worst exit code.  Rank 0 inherits stdout (its ONE JSON line is the job's); the other ranks' stdout
+    goes to stderr.  The torchrun form (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) bypasses
+    this: WORLD_SIZE is then already set."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SN_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, deadline = 0, (time.time() + timeout if timeout else None)
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs) or (deadline and time.time() > deadline):
+                break                                   # one rank died (or time is up): do not leave the others in a rendezvous
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                           # exact PIDs we started, never a pattern
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:                           # noqa: BLE001
+                p.kill()
+            rc = rc or (p.returncode if p.returncode is not None else 1)
+    return rc
+
+
+def launcher_selftest(args, rank, world):
+    """`--selftest-launcher`: the rendezvous half of the bench without a GPU (what tests/test_bench_launcher_cpu.py runs with
+    gloo): every rank joins the process group the way main() does, contributes to one all-reduce and one MAX-reduce of a
+    time, rank 0 prints the JSON line."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(args.dist_backend)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    mx = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "sum_of_ranks_plus_1": float(t.item()), "max_time": float(mx.item()),
+                          "all_reduce_backend": dist.get_backend() if world > 1 else "none (world 1)",
+                          "self_launched": os.environ.get("SN_BENCH_SELF_LAUNCHED") == "1"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def rccl_version():
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                   # noqa: BLE001
+        return None
 
 
 def main():
@@ -215,12 +284,24 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="headline number + roofline only (used by the rocprof passes)")
     ap.add_argument("--cpu-rays", type=int, default=4096)
     ap.add_argument("--dist-backend", default="nccl", help="developer option: 'gloo' lets N ranks share one GPU for testing")
+    ap.add_argument("--selftest-launcher", action="store_true", help="rendezvous + all-reduce only, no GPU work (CPU test)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: be our own launcher (one process per GPU); under torchrun WORLD_SIZE is set
+        if not args.selftest_launcher and args.dist_backend == "nccl":
+            assert torch.cuda.is_available() and torch.cuda.device_count() >= args.gpus, \
+                "--gpus %d needs %d visible devices (found %d); RCCL cannot put two ranks on one device -- use " \
+                "--dist-backend gloo to exercise the N-rank path on fewer devices" % (
+                    args.gpus, args.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}: the two must agree"
+    if args.selftest_launcher:
+        return launcher_selftest(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     if args.dist_backend != "nccl":
         local = local % torch.cuda.device_count()
@@ -328,8 +409,23 @@ def main():
         ncpu = os.cpu_count() or 1
         sample = np.ascontiguousarray(rays_np[:: max(1, n_rays // args.cpu_rays)][:args.cpu_rays])
         from oracle import torch_ref as T
-        tp = [{k: torch.from_numpy(v) for k, v in p.items()} for p in params]
+        from oracle import stage_ref
         srays = torch.from_numpy(sample)
+        if stage_ref.available():
+            # the reference's OWN modules (models/rendering.py:126 render_rays, models/nerf.py NeRF / Embedding), staged
+            # byte-for-byte into the git-ignored oracle/_ref/ by build() where /root/reference exists (oracle/stage_ref.py)
+            ref_rendering, _ = stage_ref.load()
+            ref_models, ref_emb = stage_ref.build_reference_models(params)
+            kind = "reference"
+
+            def cpu_render(r):
+                return ref_rendering.render_rays(ref_models, ref_emb, r, NS, False, 0, 0, NI, 1024 * 32, True)
+        else:
+            tp = [{k: torch.from_numpy(v) for k, v in p.items()} for p in params]
+            kind = "port"
+
+            def cpu_render(r):
+                return T.render(tp, r, NS, NI, True)
         # thread count: torch's intra-op pool with ALL cores of a 256-core host is 10x SLOWER than with a few dozen on this
         # op sequence (measured: 26 rays/s at 256 threads) -- so the count is calibrated on a 256-ray probe and the best one
         # is used and reported as `cores`
@@ -337,26 +433,39 @@ def main():
         with torch.no_grad():
             for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
                 torch.set_num_threads(nt)
-                T.render(tp, srays[:64], NS, NI, True)                                   # warm the pool at this size
+                cpu_render(srays[:64])                                                   # warm the pool at this size
                 t0 = time.perf_counter()
-                T.render(tp, srays[:256], NS, NI, True)
+                cpu_render(srays[:256])
                 cal[nt] = 256 / (time.perf_counter() - t0)
                 if time.perf_counter() - t0 > 8.0:
                     break
             nthreads = max(cal, key=cal.get)
             torch.set_num_threads(nthreads)
             nb = min(sample.shape[0], max(1024, int(cal[nthreads] * 15) // 1024 * 1024))  # ~15 s of CPU work
-            T.render(tp, srays[:256], NS, NI, True)
+            cpu_render(srays[:256])
             t0 = time.perf_counter()
             for i in range(0, nb, 1024):                                                 # eval.py-style ray chunks
-                T.render(tp, srays[i:i + 1024], NS, NI, True)
+                cpu_render(srays[i:i + 1024])
             cdt = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": nb / cdt, "unit": "rays/s", "cores": nthreads, "host_cores": ncpu, "kind": "port",
-                               "sample": "%d rays of the same frame in chunks of 1024, stock torch CPU ops with %d threads "
-                                         "(oracle/torch_ref.py = the reference's op sequence), %.1f s" % (nb, nthreads, cdt),
-                               "thread_calibration_rays_per_s": {str(k): v for k, v in cal.items()},
-                               "note": "survey-time probe of the UNMODIFIED reference render_rays on this container's 8 host "
-                                       "cores: ~1.1 k rays/s (SURVEY.md §6); the reference itself is not present on the GPU box"}
+        res["cpu_baseline"] = {"value": nb / cdt, "unit": "rays/s", "cores": nthreads, "host_cores": ncpu, "kind": kind,
+                               "sample": "%d rays of the same frame in chunks of 1024 (eval.py:84-115), %s, torch CPU with %d "
+                                         "intra-op threads, %.1f s" % (
+                                             nb, "the UNMODIFIED reference render_rays + NeRF modules (oracle/_ref, staged by "
+                                             "oracle/stage_ref.py)" if kind == "reference" else
+                                             "stock torch CPU ops (oracle/torch_ref.py = the reference's op sequence; oracle/_ref "
+                                             "not staged on this box)", nthreads, cdt),
+                               "thread_calibration_rays_per_s": {str(k): v for k, v in cal.items()}}
+        if kind == "reference":                                                          # the port beside it, same sample
+            try:
+                tp = [{k: torch.from_numpy(v) for k, v in p.items()} for p in params]
+                with torch.no_grad():
+                    T.render(tp, srays[:256], NS, NI, True)
+                    t0 = time.perf_counter()
+                    for i in range(0, min(nb, 2048), 1024):
+                        T.render(tp, srays[i:i + 1024], NS, NI, True)
+                res["cpu_baseline"]["port_rays_per_s"] = min(nb, 2048) / (time.perf_counter() - t0)
+            except Exception as e:                  # noqa: BLE001
+                res["cpu_baseline"]["port_rays_per_s"] = repr(e)
         try:
             ns = sample[:1024]
             t0 = time.perf_counter()

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 1
+#define SN_ABI_VERSION 2   /* 2: sn_sample_pdf_bins gained eps, dtype carries SN_DTYPE_CLASSIC_HEADS, sn_mlp_forward flag bits */
 
 #define SN_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32                                          */
 #define SN_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate                    */

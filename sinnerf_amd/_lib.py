@@ -15,6 +15,7 @@ SN_DTYPE_BF16 = 1
 SN_DTYPE_BF16_STATE = 2
 SN_DTYPE_CLASSIC_HEADS = 0x100      # OR-ed into dtype: NeRF(use_new_activation=False) heads (include/sinnerf_hip.h)
 N_RAW_TENSORS = 24
+ABI_VERSION = 2                     # == SN_ABI_VERSION of include/sinnerf_hip.h this binding was written against
 
 c_fp = ctypes.c_void_p      # device float*
 c_vp = ctypes.c_void_p
@@ -72,8 +73,8 @@ def _load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError -> loud failure on a stale .so
         fn.restype, fn.argtypes = res, args
-    if lib.sn_abi_version() != 1:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.sn_abi_version()} != 1; rebuild the extension")
+    if lib.sn_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.sn_abi_version()} != {ABI_VERSION}; rebuild the extension")
     return lib
 
 

@@ -343,8 +343,8 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
 #if SN_BF16_COUNTED
       // the sign word of tile t was requested in slab t; behind it only the eight row stores of tile t-1 (odd t-1) were issued
       if (S16) {
-        if (t >= 2 && (t & 1) == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(sign_word));
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(sign_word));
+        if (t >= 2 && (t & 1) == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(sign_word) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(sign_word) :: "memory");
       }
 #endif
 #pragma unroll

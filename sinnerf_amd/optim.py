@@ -77,15 +77,61 @@ class FlatAdam(torch.optim.Optimizer):
 
     # ---- checkpoint / resume ---------------------------------------------------------------------------------------
     def state_dict(self):
+        """``torch.optim.Adam``'s own layout ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}, per
+        parameter in parameter order), so a checkpoint written here resumes under the reference's optimiser
+        (``utils/__init__.py:19-21``) and the other way round."""
         g = self.param_groups[0]
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_groups": [{k: v for k, v in g.items() if k != "params"}]}
+        params = self.grads.params
+        state, off = {}, 0
+        if self.step_count > 0:
+            for i, p in enumerate(params):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+                off += n
+        group = {k: v for k, v in g.items() if k != "params"}
+        group["params"] = list(range(len(params)))
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, state):
-        if state["exp_avg"].numel() != self.flat.numel():
-            raise ValueError("FlatAdam.load_state_dict: optimizer state belongs to a different parameter set")
-        self.step_count = int(state["step"])
-        self.exp_avg.copy_(state["exp_avg"].to(self.flat.device).reshape(-1))
-        self.exp_avg_sq.copy_(state["exp_avg_sq"].to(self.flat.device).reshape(-1))
-        for k, v in state["param_groups"][0].items():
-            self.param_groups[0][k] = v
+        """Accepts the ``torch.optim.Adam`` layout (the reference's / Lightning's ``optimizer_states`` entry, or
+        ``state_dict()`` above) and the round-2 private layout (top-level ``step`` / ``exp_avg`` / ``exp_avg_sq``).  Shapes are
+        checked per parameter: state of a different or re-ordered parameter set is refused."""
+        params = self.grads.params
+        if "state" in state:
+            st = state["state"]
+            groups = state["param_groups"]
+            ids = [i for g in groups for i in g["params"]]
+            if len(ids) != len(params):
+                raise ValueError("FlatAdam.load_state_dict: optimizer state has %d parameters, this model has %d" % (len(ids), len(params)))
+            if len(st) not in (0, len(params)):
+                raise ValueError("FlatAdam.load_state_dict: partial per-parameter state (%d of %d)" % (len(st), len(params)))
+            steps, off = set(), 0
+            for i, p in zip(ids, params):
+                n = p.numel()
+                if st:
+                    e = st[i] if i in st else st[str(i)]
+                    if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                        raise ValueError("FlatAdam.load_state_dict: state %s has shape %s, parameter has %s -- a different or "
+                                         "re-ordered parameter set" % (i, tuple(e["exp_avg"].shape), tuple(p.shape)))
+                    self.exp_avg[off:off + n].copy_(e["exp_avg"].to(self.flat.device).reshape(-1))
+                    self.exp_avg_sq[off:off + n].copy_(e["exp_avg_sq"].to(self.flat.device).reshape(-1))
+                    steps.add(int(e["step"]))
+                off += n
+            if len(steps) > 1:
+                raise ValueError("FlatAdam.load_state_dict: per-parameter step counts differ (%s): one fused step has one count" % sorted(steps))
+            if not st:
+                self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            self.step_count = steps.pop() if steps else 0
+            src = groups[0]
+        else:
+            if state["exp_avg"].numel() != self.flat.numel():
+                raise ValueError("FlatAdam.load_state_dict: optimizer state belongs to a different parameter set")
+            self.step_count = int(state["step"])
+            self.exp_avg.copy_(state["exp_avg"].to(self.flat.device).reshape(-1))
+            self.exp_avg_sq.copy_(state["exp_avg_sq"].to(self.flat.device).reshape(-1))
+            src = state["param_groups"][0]
+        for k, v in src.items():
+            if k != "params":
+                self.param_groups[0][k] = v

@@ -76,6 +76,8 @@ class SinNeRFSystem(nn.Module):
             # the reference's own optimiser; the render path itself has no CPU form and raises on CPU tensors
             self.optimizer = torch.optim.Adam(params, lr=hp.lr, eps=1e-8, weight_decay=hp.weight_decay)
         scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=hp.decay_step, gamma=hp.decay_gamma)
+        self._schedulers = [scheduler]
+        self.__dict__.pop("_step_graphs", None)      # captured steps bake in the old flat-buffer addresses
         return [self.optimizer], [scheduler]
 
     # ---- losses.py:12-22 (MSE coarse + fine) + SL1Loss of depth_fine and depth_coarse (sinnerf.py:32-42, 310-319):
@@ -105,12 +107,46 @@ class SinNeRFSystem(nn.Module):
         return {"progress_bar": {"val_psnr": mean_psnr}, "log": {"val/psnr": mean_psnr}}
 
     # ---- minimal driver: one optimisation step with the single flat all-reduce -----------------------
+    def _ensure_flat_optimizer(self):
+        """``configure_optimizers`` may have run while the module was still on the host (stock Adam, no flat buffers, NO
+        gradient exchange).  Once the parameters are on the device the optimiser is rebuilt as ``FlatAdam`` -- carrying over
+        the hyper-parameters a scheduler may already have changed -- so that ``train_step`` always ends in the one flat
+        all-reduce.  Adam state accumulated by a host-side optimiser is refused rather than silently dropped."""
+        opt = getattr(self, "optimizer", None)
+        if isinstance(opt, FlatAdam):
+            return opt
+        params = [p for m in self.models for p in m.parameters()]
+        if not params[0].is_cuda:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                raise RuntimeError("SinNeRFSystem: a multi-rank step needs the parameters on a ROCm device (FlatAdam owns the "
+                                   "gradient all-reduce); move the module with .to(device) first")
+            if opt is None:
+                self.configure_optimizers()
+            return self.optimizer
+        if opt is None:
+            self.configure_optimizers()
+            return self.optimizer
+        if any(len(st) for st in opt.state.values()):
+            raise RuntimeError("SinNeRFSystem: the host-side optimiser already holds Adam state; call configure_optimizers() "
+                               "again after .to(device) (or load its state into the new FlatAdam) instead of stepping on")
+        g = opt.param_groups[0]
+        new = FlatAdam(self.models, lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"])
+        if "initial_lr" in g:
+            new.param_groups[0]["initial_lr"] = g["initial_lr"]
+        for sch in getattr(self, "_schedulers", []):          # MultiStepLR keeps a reference to the optimiser it drives
+            sch.optimizer = new
+        self.optimizer, self._flat = new, new.grads
+        self.__dict__.pop("_step_graphs", None)
+        return new
+
     def setup_distributed(self):
         """Replicas start identical (what DDP's constructor does, train.py:51-52); returns the flat gradient buffer whose
         all-reduce is the step's one exchange."""
         broadcast_parameters(self.models)
-        if not hasattr(self, "optimizer"):
-            self.configure_optimizers()          # (an existing FlatAdam already saw the broadcast: its flat buffer IS p.data)
+        self._ensure_flat_optimizer()            # (an existing FlatAdam already saw the broadcast: its flat buffer IS p.data)
+        if self._flat is None:
+            raise RuntimeError("setup_distributed: parameters are on the host; move the module to a ROCm device first")
         return self._flat
 
     def _zero_forward_backward(self, batch):
@@ -127,8 +163,7 @@ class SinNeRFSystem(nn.Module):
         and replayed with the batch copied into static buffers; the exchange step stays eager (one all-reduce + one Adam
         launch), so the same code serves one rank and N ranks.  The returned dict holds the graph's static output tensors
         (overwritten by the next replay)."""
-        if not hasattr(self, "optimizer"):
-            self.configure_optimizers()
+        self._ensure_flat_optimizer()
         if graph:
             out = self._graphed_step(batch)
         else:
@@ -138,7 +173,13 @@ class SinNeRFSystem(nn.Module):
 
     def _graphed_step(self, batch):
         tensors = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
-        key = tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in tensors.items()))
+        hp = self.hparams
+        # a captured step bakes in the flat parameter / gradient buffers and every hyper-parameter the launches read
+        key = (tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in tensors.items())),
+               self.optimizer.flat.data_ptr() if isinstance(self.optimizer, FlatAdam) else None,
+               self._flat.flat.data_ptr() if self._flat is not None else None,
+               hp.N_samples, hp.N_importance, hp.use_disp, hp.perturb, hp.noise_std, hp.chunk, hp.depth_weight,
+               hp.compute_dtype, self.white_back, self.training)
         cache = self.__dict__.setdefault("_step_graphs", {})
         hit = cache.get(key)
         if hit is None:
@@ -168,6 +209,6 @@ class SinNeRFSystem(nn.Module):
     def replica_checksum(self):
         """fp64 sum and sum of squares of the flat parameter buffer: equal on every rank iff the replicas are identical
         (what the bench's multi-GPU training leg asserts after a few steps)."""
-        flat = self.optimizer.flat.double() if hasattr(self, "optimizer") else \
+        flat = self.optimizer.flat.double() if isinstance(getattr(self, "optimizer", None), FlatAdam) else \
             torch.cat([p.detach().reshape(-1) for m in self.models for p in m.parameters()]).double()
         return torch.stack([flat.sum(), (flat * flat).sum()])

@@ -7,7 +7,10 @@ guarantees are checked on the generated code instead:
   2. no VALU instruction writes a register an MFMA reads within the next 2 wait states (VALU write -> MFMA read hazard);
   3. no VALU / LDS / memory instruction reads an MFMA result before two further MFMAs (or 12 other instructions) have issued
      (MFMA write -> VALU read hazard: 11 wait states for the 8-pass bf16 MFMA, 18 for the 16-pass fp32 one);
-  4. the destination of a global load issued from inline asm is not referenced before the next s_waitcnt vmcnt;
+  4. the destination of a global load issued from inline asm is not referenced before an s_waitcnt vmcnt(N) that COVERS it:
+     vmcnt retires in issue order, so vmcnt(N) completes a load only if at least N vector-memory instructions were issued
+     behind it (counted on the generated code -- a compiler that moves one nontemporal store across a counted wait fails
+     the build instead of producing stale masks);
   5. a vector-memory instruction inside inline asm does not use an SGPR address within 5 wait states of the SALU instruction
      that wrote it (hipcc pads this hazard for its own instructions only).
 usage: check_agpr.py file.s"""
@@ -25,7 +28,7 @@ def vregs(tok):
             out |= {('a', r) for r in range(lo, hi + 1)}
     return out
 
-kern = None; ina = False; ins = []; bad_agpr = []; spills = 0; pend_ld = set(); bad_async = []
+kern = None; ina = False; ins = []; bad_agpr = []; spills = 0; pend_ld = {}; bad_async = []; VMEM = ('global_', 'buffer_', 'flat_', 'scratch_')
 sgpr_written = {}; clock = 0; bad_sgpr = []
 
 def sregs(tok):
@@ -66,9 +69,14 @@ for ln, l in enumerate(open(sys.argv[1]), 1):
     clock += (int(t.split()[1], 0) + 1) if op == 's_nop' else 8 if op.startswith('v_mfma') else 1
     # 4. destination registers of a global load issued from inline asm (the wait is hand-placed) are not touched by anything
     #    until an s_waitcnt vmcnt has issued
-    if op == 's_waitcnt' and 'vmcnt' in args: pend_ld = set()
-    elif pend_ld and (vregs(args) & pend_ld): bad_async.append((ln, t))
-    if ina and op.startswith('global_load_dword') and 'lds' not in op: pend_ld |= vregs(parts[0])
+    if op == 's_waitcnt' and 'vmcnt' in args:
+        n = int(re.search(r'vmcnt\((\d+)\)', args).group(1))
+        pend_ld = {r: c for r, c in pend_ld.items() if c < n}          # c ops issued behind the load: retired iff c >= n
+    elif pend_ld and (vregs(args) & set(pend_ld)): bad_async.append((ln, t))
+    if op.startswith(VMEM):
+        for r in pend_ld: pend_ld[r] += 1
+    if ina and op.startswith('global_load_dword') and 'lds' not in op:
+        for r in vregs(parts[0]): pend_ld[r] = 0
 
 haz1 = []; haz2 = []
 for i, (ln, op, dst, src, is_valu, t, _rr) in enumerate(ins):
