@@ -89,7 +89,8 @@ def pmc_traffic(n_points, dtype):
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
         if tj.get("points") == n_points and dtype == "fp32":
-            return tj["hbm_bytes"], "bytes/launch from %s (algorithmic %d)" % (tj["source"], tj["algorithmic_bytes"])
+            return tj["hbm_bytes"], "bytes/launch from %s measured at git %s, NOT by this run (algorithmic %d)" % (
+                tj["source"], tj.get("git_head", "unstamped"), tj["algorithmic_bytes"])
     except Exception:                       # noqa: BLE001
         pass
     return None, None
@@ -129,7 +130,8 @@ def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
 # chain reads the sign words + the 256 B softplus tile (+ 32 B) and writes 10 x 512 B gradients (+ 16 B), the weight-gradient
 # contractions read 11 904 B -- the step is bound by HBM, not by the MFMA rate.
 TRAIN_BF16_BYTES_PER_POINT = (5120 + 256 + 512 + 16) + (256 + 256 + 32 + 5120 + 16) + 11904
-HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/s spec (stock kernels: 6.2 read / 6.7 write / 5.2 copy, tools/hbm_calib.py)
+HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_ACHIEVABLE_TBS = 6.3                            # same guide: ~6.3 TB/s achievable; tools/hbm_calib.py on this pool: 6.2 read / 6.7 write / 5.2 copy
 
 
 def train_hbm_roofline(ms_per_step, n_points):
@@ -139,17 +141,90 @@ def train_hbm_roofline(ms_per_step, n_points):
     try:
         import glob
         path = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_train_pmc.json")))[-1]
-        k = json.load(open(path))["kernels"]
+        pj = json.load(open(path))
+        k = pj["kernels"]
         per_pt = sum(v["bytes_per_point"] for name, v in k.items() if v.get("step", "bf16" if "bf16" in name else "fp32") == "bf16")
         traffic = per_pt * n_points
-        note = "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/%s)" % os.path.basename(path)
+        note = "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/%s, measured at git %s, NOT by this run)" % (
+            os.path.basename(path), pj.get("git_head", "unstamped"))
     except Exception:                               # noqa: BLE001
         pass
     alg = TRAIN_BF16_BYTES_PER_POINT * n_points
     ach = alg / (ms_per_step * 1e-3) / 1e12
     return {"bound": "hbm", "kernel": "bf16 training step: mlp_fwd_bf16_kernel<STORE> + mlp_bwd_chain_bf16_kernel + dw_bf16_asm_kernel + dw_kernel (coarse + fine)",
-            "achieved": ach, "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": ach / HBM_PEAK_TBS, "traffic": traffic,
+            "achieved": ach, "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": ach / HBM_PEAK_TBS,
+            "achievable_peak": HBM_ACHIEVABLE_TBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_TBS, "traffic": traffic,
             "traffic_note": note, "algorithmic_bytes_per_step": alg}
+
+
+TRAIN_CFGS = {
+    # BASELINE configs[1..3] training shapes (SURVEY §8d "Configs restated"): rays per render of the FOUR renders of one step
+    # (models/sinnerf.py:304-307: rays, rays_full, rays_side, rays_proj), white_back of the dataset
+    "train_cfg2": ("nerf_synthetic/lego 400x400 patch_size=64: 4 x 4096 rays/step", True),
+    "train_cfg3": ("llff/room 504x378 patch 63x84 sW=sH=4: 4096 + 5292 + 5292 + 4096 rays/step, white_back=False", False),
+    "train_cfg4": ("dtu scan 640x512 patch 56x70 sW=sH=8: 4096 + 3920 + 3920 + 4096 rays/step (per rank)", True),
+}
+
+
+def train_cfg_batch(O, dev, cfg, seed=0):
+    """Synthetic SinNeRF patch batch of one config: the keys of models/sinnerf.py:277-299 that reach the hot path."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if cfg == "train_cfg2":
+        f = 0.5 * 400 / np.tan(0.5 * 0.6911112)
+        patch = lambda sd: O.patch_rays(400, 400, f, O._look_at_c2w(np.array([2.4 + 0.1 * sd, -2.2, 2.3])), 2.0, 6.0,
+                                        30 + 7 * sd, 40 + 5 * sd, 64, 64, 5, 5)
+        rnd = lambda sd: O.lego_rays(400, 400, seed=seed + sd)[:: 39][:4096]
+        lo, hi = 2.0, 6.0
+    elif cfg == "train_cfg3":
+        patch = lambda sd: O.llff_patch_rays(seed + sd)
+        rnd = lambda sd: O.llff_like_rays(4096, seed + sd)
+        lo, hi = 1.2, 8.0
+    else:
+        patch = lambda sd: O.dtu_patch_rays(seed + sd)
+        rnd = lambda sd: O.dtu_patch_rays(seed + 10 + sd, pw=64, ph=64, sx=7, sy=7)
+        lo, hi = 2.125, 4.525
+    rays, full, side, proj = rnd(0), patch(1), patch(2), rnd(3)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    u = lambda *sh: torch.rand(*sh, generator=g).to(dev)
+    return {"rays": t(rays), "rgbs": u(rays.shape[0], 3), "depth": lo + (hi - lo) * u(rays.shape[0]),
+            "rays_full": t(full), "rgbs_full": u(full.shape[0], 3),
+            "rays_side": t(side), "side_rgb": u(side.shape[0], 3),
+            "rays_proj": t(proj), "depth_proj": lo + (hi - lo) * u(proj.shape[0])}
+
+
+def train_cfg_record(O, dev, dtype, cfg, steps=3, warmup=2):
+    """One optimisation step of the reference's real shape on a BASELINE config: the four renders of sinnerf.py:304-307
+    (perturb=1, noise_std=1, MSE on `rays` and the full patch, SmoothL1 depth on `rays` and the projected rays with
+    depth_weight=1, MSE stand-in for the unseen-view losses that stay on PyTorch), backward of all four, ONE flat all-reduce
+    (no-op at world 1) and the fused Adam -- through SinNeRFSystem.train_step."""
+    from sinnerf_amd.system import SinNeRFSystem
+    what, white_back = TRAIN_CFGS[cfg]
+    torch.manual_seed(7)
+    sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=white_back,
+                         depth_weight=1.0).to(dev)
+    batch = train_cfg_batch(O, dev, cfg)
+    n_rays = sum(batch[k].shape[0] for k in ("rays", "rays_full", "rays_side", "rays_proj"))
+    for _ in range(warmup):
+        out = sysm.train_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = sysm.train_step(batch)
+    torch.cuda.synchronize()
+    step_s = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out["loss"]).item()
+    pts = n_rays * 192
+    tflop = FLOP_PER_POINT_TRAIN * pts / step_s / 1e12
+    rec = {"workload": what, "renders_per_step": 4, "rays_per_step": n_rays, "points_per_step": pts, "dtype": dtype,
+           "losses": "MSE(rays) + MSE(full patch) + SL1 depth(rays) + SL1 depth(proj) + MSE(side patch)",
+           "ms_per_step": step_s * 1e3, "train_rays_per_s": n_rays / step_s, "achieved_tflops": tflop,
+           "frac_of_mfma_peak": tflop / PEAK_TFLOPS[dtype], "loss": float(out["loss"].detach())}
+    if dtype == "bf16":
+        rec["roofline"] = train_hbm_roofline(step_s * 1e3, pts)
+    else:
+        rec["roofline"] = {"bound": "mfma", "kernel": "fp32 training step: mlp_fwd_f32_kernel<STORE> + mlp_bwd_chain_f32_kernel + dw_f32_asm_kernel + dw_kernel (4 renders, coarse + fine)",
+                           "achieved": tflop, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": tflop / PEAK_TFLOPS["fp32"], "traffic": None}
+    return rec
 
 
 def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2, graph=False):
@@ -401,6 +476,14 @@ def main():
                 res[key] = train_step_record(O, dev, dt_name, rays, NS, NI)
             except Exception as e:                  # noqa: BLE001
                 res[key] = {"error": repr(e)}
+        # the reference's real optimisation step (four renders + depth loss) on the BASELINE training shapes
+        for cfg in TRAIN_CFGS:
+            for dt_name in ("bf16", "fp32"):
+                try:
+                    records[cfg + "_" + dt_name] = train_cfg_record(O, dev, dt_name, cfg)
+                except Exception as e:              # noqa: BLE001
+                    records[cfg + "_" + dt_name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the reference's op sequence (models/rendering.py:126-335 + models/nerf.py) as stock torch ops on

@@ -473,7 +473,7 @@ def composite_backward(rgbsigma, z_vals, rays_d, noise, noise_std, white_back, g
 
 
 def render_rays_backward(models, rays, upstream, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
-                         white_back=False, rng=None):
+                         white_back=False, rng=None, operand_round=None):
     """Parameter gradients of ``render_rays`` for upstream gradients ``upstream`` = dict with any of
     ``rgb_coarse, depth_coarse, opacity_coarse, rgb_fine, depth_fine, opacity_fine``.  Returns [grads_coarse,
     grads_fine] (state_dict-keyed, float64).  ``sample_pdf`` is detached (rendering.py:312)."""
@@ -494,7 +494,7 @@ def render_rays_backward(models, rays, upstream, N_samples=64, use_disp=False, p
         g_raw = composite_backward(raw, z, rays_d, noise, noise_std, white_back,
                                    upstream.get("rgb_" + tag, zero3), upstream.get("depth_" + tag, zero1),
                                    upstream.get("opacity_" + tag))
-        return raw, nerf_backward(params, cache, g_raw.reshape(-1, 4))
+        return raw, nerf_backward(params, cache, g_raw.reshape(-1, 4), operand_round=operand_round)
 
     z = coarse_z_vals(rays, N_samples, use_disp, perturb, rng.get("perturb"))
     raw_c, g_c = one(models[0], z, rng.get("noise_coarse"), "coarse")

@@ -88,12 +88,62 @@ class SinNeRFSystem(nn.Module):
         return (total, stats) if with_stats else total
 
     def training_step(self, batch, batch_idx=0, optimizer_idx=0):
+        """One generator step on the accelerated path.
+
+        * ``{"rays", "rgbs"[, "depths"]}``: one render, MSE coarse+fine (+ ``depth_weight`` x SmoothL1 depth) -- the core.
+        * a SinNeRF patch batch (``rays_full`` present, the keys of ``models/sinnerf.py:277-299``): the FOUR renders of
+          ``sinnerf.py:304-307`` -- ``rays`` (random rays of the reference view), ``rays_full`` (the strided patch with
+          ground truth), ``rays_side`` (the patch seen from the unseen view), ``rays_proj`` (rays with projected depth) --
+          with MSE on ``results`` and on the full patch (``patch_loss``, ``sinnerf.py:347``), SmoothL1 depth on
+          ``results`` and ``results_proj`` (``:309-319``, ``useMask=False``), and ``self.side_loss(results_side, batch)`` for
+          the unseen view.  In the reference that last term is the DINO-ViT feature loss / the discriminator, which
+          ``north_star`` keeps on stock PyTorch: plug them in as ``side_loss``; the default (MSE against ``side_rgb``, the
+          warped patch of ``sinnerf.py:300-302``) keeps the render and its backward on the step so that the timed work
+          is the reference's.
+        """
+        if "rays_full" in batch:
+            return self._training_step_patches(batch)
         rays, rgbs = batch["rays"], batch["rgbs"]
         rays, rgbs = rays.reshape(-1, 8), rgbs.reshape(-1, 3)
         results = self(rays)
         loss, stats = self.loss(results, rgbs, batch.get("depths"), with_stats=True)
         p = stats["psnr_fine"] if "rgb_fine" in results else stats["psnr_coarse"]
         return {"loss": loss, "progress_bar": {"train_psnr": p}, "log": {"train/loss": loss.detach(), "train/psnr": p}}
+
+    def side_loss(self, results_side, batch):
+        """Stand-in for the unseen-view losses that stay on PyTorch (DINO-ViT ``sinnerf.py:332-339``, discriminator): MSE of
+        the side render against the warped patch.  Replace by assignment (``system.side_loss = fn``)."""
+        tgt = batch.get("side_rgb")
+        if tgt is None:
+            return None
+        total, _ = render_loss(results_side, tgt.reshape(-1, 3))
+        return total
+
+    def _training_step_patches(self, batch):
+        hp = self.hparams
+        r8 = lambda k: batch[k].reshape(-1, 8)
+        results = self(r8("rays"))                                              # sinnerf.py:304
+        results_full = self(r8("rays_full"))                                    # :305
+        results_side = self(r8("rays_side"))                                    # :306
+        results_proj = self(r8("rays_proj"))                                    # :307
+        wd = hp.depth_weight
+        depth = batch.get("depth")
+        loss, stats = render_loss(results, batch["rgbs"].reshape(-1, 3), depth.reshape(-1) if (depth is not None and wd > 0) else None,
+                                  w_depth=wd)                                    # :316 loss_g + :317-318 depth terms
+        log = {"train/loss_g": loss.detach()}
+        if "rgbs_full" in batch:                                                # :347 patch_loss(results_full, rgbs_full)
+            l_full, _ = render_loss(results_full, batch["rgbs_full"].reshape(-1, 3))
+            loss = loss + l_full
+        if wd > 0 and "depth_proj" in batch:                                    # :309-311 SL1 on the projected rays
+            l_proj, _ = render_loss(results_proj, None, batch["depth_proj"].reshape(-1), w_depth=wd)
+            loss = loss + l_proj
+            log["train/loss_depth_proj"] = l_proj.detach()
+        l_side = self.side_loss(results_side, batch)
+        if l_side is not None:
+            loss = loss + l_side
+        p = stats["psnr_fine"] if "rgb_fine" in results else stats["psnr_coarse"]
+        log.update({"train/loss": loss.detach(), "train/psnr": p})
+        return {"loss": loss, "progress_bar": {"train_psnr": p}, "log": log}
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx=0):

@@ -1,0 +1,214 @@
+"""Round-3 GPU tests: training on the BASELINE config shapes, the ADVICE r2 fixes of the system
+surface, and bench.py as its own launcher."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_np as O                                                            # noqa: E402
+from tests.test_parity_gpu import dev, embeddings, injected_rng, make_model                  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _grads(m):
+    return {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in m.named_parameters()}
+
+
+def test_bf16_training_render_gradients_on_llff_patch_shape():
+    """Gradients of a bf16 TRAINING render on the BASELINE configs[2] patch (llff 63x84 stride 4: N = 5292 rays,
+    white_back=False, perturb=1, noise_std=1, 64+64) against ``oracle_np.render_rays_backward`` with every contraction's
+    operands rounded to bf16 (forward under ``bf16_operands()``, backward with ``operand_round=bf16_round``).  The whole patch
+    goes through the GPU path; the loss weights every third ray (rays are independent: the others contribute exact zeros),
+    so the numpy oracle only has to differentiate 1764 rays.  Same random draws on both sides (injected in the reference's
+    consumption order)."""
+    import sinnerf_amd
+    rays = O.llff_patch_rays(0)
+    n, S, NI = rays.shape[0], 64, 64
+    assert n == 5292
+    sub = np.arange(0, n, 3)
+    r = np.random.RandomState(11)
+    rng = {"perturb": r.uniform(0, 1, (n, S)).astype(np.float32), "noise_coarse": r.standard_normal((n, S)).astype(np.float32),
+           "u": r.uniform(0, 1, (n, NI)).astype(np.float32), "noise_fine": r.standard_normal((n, S + NI)).astype(np.float32)}
+    coef = {k: np.zeros(sh, np.float32) for k, sh in (("rgb_coarse", (n, 3)), ("rgb_fine", (n, 3)), ("depth_coarse", (n,)),
+                                                      ("depth_fine", (n,)))}
+    for k in coef:
+        coef[k][sub] = r.standard_normal(coef[k][sub].shape).astype(np.float32) / len(sub)
+    mc, pc = make_model(0, True, dtype="bf16")
+    mf, pf = make_model(1, True, dtype="bf16")
+    mc.train(); mf.train()
+    order = [("rand", rng["perturb"]), ("randn", rng["noise_coarse"]), ("rand", rng["u"]), ("randn", rng["noise_fine"])]
+    with injected_rng(order) as left:
+        res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays).to(dev()), S, False, 1.0, 1.0, NI, 32768, False)
+        assert not left
+    assert res["rgb_fine"].shape == (n, 3) and all(torch.isfinite(v).all() for v in res.values())
+    sum((res[k] * torch.from_numpy(v).to(dev())).sum() for k, v in coef.items()).backward()
+    got = [_grads(mc), _grads(mf)]
+    rs = {k: v[sub] for k, v in rng.items()}
+    up = {k: v[sub].astype(np.float64) for k, v in coef.items()}
+    with O.bf16_operands():
+        ref16 = O.render_rays_backward([pc, pf], rays[sub], up, S, False, 1.0, 1.0, NI, False, rs, operand_round=O.bf16_round)
+    ref32 = O.render_rays_backward([pc, pf], rays[sub], up, S, False, 1.0, 1.0, NI, False, rs)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    cos = lambda a, b: float((a * b).sum() / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+    for tag, g, r16, r32 in (("coarse", got[0], ref16[0], ref32[0]), ("fine", got[1], ref16[1], ref32[1])):
+        e16 = {k: rel(g[k], r16[k]) for k in r16}
+        e32 = {k: rel(g[k], r32[k]) for k in r32}
+        print(tag, "vs bf16-emulated oracle", {k: "%.1e" % e for k, e in e16.items()})
+        print(tag, "vs fp32 oracle         ", {k: "%.1e" % e for k, e in e32.items()})
+        # same roundings, different accumulation order; ReLU masks / the fine samples' positions (sample_pdf of the coarse
+        # weights) flip for a few points whose pre-activation is within a bf16 ulp of zero: a norm-wise bar, plus direction
+        big = [k for k in r16 if r16[k].size >= 256]
+        assert max(e16[k] for k in big) <= 3e-2, (tag, e16)
+        assert min(cos(g[k], r16[k]) for k in big) >= 0.9995, tag
+        # mixed precision stays close to the fp32 gradient as well (cosine per parameter tensor)
+        assert min(cos(g[k], r32[k]) for k in big) >= 0.999, tag
+
+
+def _patch_batch(cfg):
+    sys.path.insert(0, REPO)
+    import bench
+    return bench.train_cfg_batch(O, dev(), cfg)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_four_render_training_step_equals_the_sum_of_its_renders(dtype):
+    """SinNeRFSystem.training_step on a patch batch = the four renders of sinnerf.py:304-307 with MSE + SmoothL1-depth
+    terms: its loss and its gradients equal what four separate single-render steps accumulate (same seeds)."""
+    from sinnerf_amd.system import SinNeRFSystem
+    from sinnerf_amd.losses import render_loss
+    import sinnerf_amd
+    batch = _patch_batch("train_cfg3")                                   # 4096 + 5292 + 5292 + 4096, white_back=False
+    torch.manual_seed(3)
+    sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=False, depth_weight=0.5).to(dev())
+    sysm.configure_optimizers()
+    sysm.optimizer.zero_grad()
+    torch.manual_seed(100)
+    out = sysm.training_step(batch)
+    out["loss"].backward()
+    g_step = sysm._flat.flat.clone()
+    # the same four renders one by one
+    sysm.optimizer.zero_grad()
+    torch.manual_seed(100)
+    total = 0.0
+    rr = lambda rays: sinnerf_amd.render_rays(sysm.models, sysm.embeddings, rays, 64, False, 1.0, 1.0, 64, 32768, False)
+    r1, r2, r3, r4 = rr(batch["rays"]), rr(batch["rays_full"]), rr(batch["rays_side"]), rr(batch["rays_proj"])
+    for res, rgbs, depths in ((r1, batch["rgbs"], batch["depth"]), (r2, batch["rgbs_full"], None), (r4, None, batch["depth_proj"]),
+                              (r3, batch["side_rgb"], None)):
+        l, _ = render_loss(res, rgbs, depths, w_depth=0.5)
+        l.backward()
+        total += float(l)
+    g_sep = sysm._flat.flat.clone()
+    assert abs(float(out["loss"]) - total) <= 1e-5 * max(1.0, abs(total)), (float(out["loss"]), total)
+    assert float(g_step.abs().max()) > 0
+    err = float((g_step - g_sep).norm() / g_sep.norm())
+    assert err <= (1e-5 if dtype == "fp32" else 1e-5), err              # same kernels, same inputs: accumulation order only
+    # and a few optimisation steps on this batch reduce the loss
+    losses = [float(sysm.train_step(batch)["loss"]) for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+def test_optimizer_configured_on_host_is_upgraded_on_device():
+    """configure_optimizers() before .to(device) builds a stock Adam with no flat buffers; train_step /
+    setup_distributed must not run a step without the flat exchange -- the optimiser is rebuilt as FlatAdam (keeping lr and
+    the scheduler), replica_checksum works, and a stale captured graph is dropped."""
+    from sinnerf_amd.optim import FlatAdam
+    from sinnerf_amd.system import SinNeRFSystem
+    torch.manual_seed(0)
+    sysm = SinNeRFSystem(N_importance=64, lr=3e-4, perturb=1.0, noise_std=0.0)
+    opts, scheds = sysm.configure_optimizers()                           # on the host: torch.optim.Adam
+    assert not isinstance(opts[0], FlatAdam)
+    sysm = sysm.to(dev())
+    flat = sysm.setup_distributed()
+    assert isinstance(sysm.optimizer, FlatAdam) and flat is sysm.optimizer.grads
+    assert abs(sysm.optimizer.param_groups[0]["lr"] - 3e-4) < 1e-12 and scheds[0].optimizer is sysm.optimizer
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::313][:512]).to(dev())
+    batch = {"rays": rays, "rgbs": torch.rand((512, 3), device=dev())}
+    before = sysm.replica_checksum().clone()
+    sysm.train_step(batch)
+    assert not torch.equal(before, sysm.replica_checksum())              # the step really updated the flat parameters
+    # graph cache: a second configure_optimizers() moves the flat buffers; the captured step must not be replayed
+    sysm.train_step(batch, graph=True)
+    assert len(sysm._step_graphs) == 1
+    old_ptr = sysm.optimizer.flat.data_ptr()
+    sysm.configure_optimizers()
+    assert "_step_graphs" not in sysm.__dict__
+    c0 = sysm.replica_checksum().clone()
+    sysm.train_step(batch, graph=True)
+    assert not torch.equal(c0, sysm.replica_checksum())                  # the NEW buffers were updated
+    sysm.hparams.noise_std = 1.0                                          # a hyper-parameter the launches bake in -> new capture
+    sysm.train_step(batch, graph=True)
+    assert len(sysm._step_graphs) == 2
+    del old_ptr
+
+
+def test_flat_adam_state_dict_is_torch_adam_layout_both_ways():
+    """FlatAdam.state_dict() / load_state_dict() speak torch.optim.Adam's layout, so a reference / Lightning
+    checkpoint's optimizer state resumes here and the other way round; state of a re-ordered parameter set is refused."""
+    from sinnerf_amd import NeRF
+    from sinnerf_amd.optim import FlatAdam
+    import sinnerf_amd
+    d = dev()
+    torch.manual_seed(1)
+    a = [NeRF(use_new_activation=True).to(d), NeRF(use_new_activation=True).to(d)]
+    b = [NeRF(use_new_activation=True).to(d), NeRF(use_new_activation=True).to(d)]
+    for x, y in zip(a, b):
+        y.load_state_dict(x.state_dict())
+    opt_t = torch.optim.Adam([p for m in a for p in m.parameters()], lr=5e-4, eps=1e-8)
+    rays = torch.from_numpy(O.lego_rays(400, 400, 0)[::640]).to(d)
+
+    def backward(models):
+        for m in models:
+            m.zero_grad(set_to_none=False)
+        r = sinnerf_amd.render_rays(models, embeddings(), rays, 64, False, 0, 0, 64, 32768, True)
+        (r["rgb_fine"].square().mean() + r["rgb_coarse"].square().mean()).backward()
+    for _ in range(2):
+        backward(a); opt_t.step()
+    # torch Adam state -> FlatAdam on an identical copy of the CURRENT parameters
+    for x, y in zip(a, b):
+        y.load_state_dict(x.state_dict())
+    opt_f = FlatAdam(b, lr=1.0, eps=1e-8)
+    opt_f.load_state_dict(opt_t.state_dict())
+    assert opt_f.step_count == 2 and abs(opt_f.param_groups[0]["lr"] - 5e-4) < 1e-12
+    backward(a); opt_t.step()
+    opt_f.zero_grad(); backward(b); opt_f.step()
+    for x, y in zip(a, b):
+        for (k, va), (_, vb) in zip(x.state_dict().items(), y.state_dict().items()):
+            assert torch.allclose(va, vb, rtol=1e-4, atol=2e-6), (k, (va - vb).abs().max().item())
+    # FlatAdam state -> torch Adam
+    opt_t2 = torch.optim.Adam([p for m in a for p in m.parameters()], lr=1.0, eps=1e-8)
+    opt_t2.load_state_dict(opt_f.state_dict())
+    st = opt_t2.state_dict()["state"]
+    assert len(st) == len(opt_f.grads.params) and int(st[0]["step"]) == 3
+    off = 0
+    for i, p in enumerate(opt_f.grads.params):
+        assert torch.equal(st[i]["exp_avg"].reshape(-1), opt_f.exp_avg[off:off + p.numel()])
+        off += p.numel()
+    # a parameter set in another order is refused (shape check per parameter, not a numel check)
+    sd = opt_f.state_dict()
+    sd["state"][0], sd["state"][2] = sd["state"][2], sd["state"][0]
+    with pytest.raises(ValueError):
+        opt_f.load_state_dict(sd)
+
+
+def test_bench_self_launch_two_gloo_ranks_one_gpu():
+    """`python bench.py --gpus 2 --dist-backend gloo` with NO external launcher on a 1-GPU box: both ranks render, the
+    data-parallel training leg runs its all-reduce across the two ranks and the replicas stay identical."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "1",
+                          "--warmup", "1", "--hw", "120", "120", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    leg = rec["train_dp"]
+    assert leg["n_ranks_seen"] == 2 and leg["all_reduce_backend"] == "gloo" and leg["all_reduce_us"] > 0
+    assert leg["replicas_identical_after"] >= 3

@@ -57,6 +57,7 @@ for name, disp in per.items():
         mode = "bf16" if ("bf16" in name or "shorter" in suffix) else "fp32"      # step the launch belongs to (train_bench.py runs both)
         out["kernels"][name + suffix] = {"step": mode, "fetch_bytes_x2": fetch, "write_bytes": write, "ms": ms,
                                          "hbm_TB_per_s": (fetch + write) / ms / 1e9, "bytes_per_point": (fetch + write) / POINTS}
+out["git_head"] = subprocess.run(["git", "describe", "--always", "--dirty"], capture_output=True, text=True).stdout.strip() or "unknown"
 json.dump(out, open(f"{P}/{tag}_train_pmc.json", "w"), indent=1)
 print("saved", sorted(os.path.basename(p) for p in glob.glob(f"{P}/{tag}_*")))
 for k, v in out["kernels"].items():

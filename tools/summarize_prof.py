@@ -85,5 +85,7 @@ if os.path.exists(p):
                                     "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc}
 json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 if "traffic" in out:
-    json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json"), open("profiles/pmc_traffic.json", "w"), indent=1)
+    import subprocess
+    head = subprocess.run(["git", "describe", "--always", "--dirty"], capture_output=True, text=True).stdout.strip() or "unknown"
+    json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json", git_head=head), open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "dispatches"}, indent=1)[:5000])
