@@ -357,7 +357,7 @@ def main():
     ap.add_argument("--n-importance", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline number + roofline only (used by the rocprof passes)")
-    ap.add_argument("--cpu-rays", type=int, default=4096)
+    ap.add_argument("--cpu-rays", type=int, default=16384)
     ap.add_argument("--dist-backend", default="nccl", help="developer option: 'gloo' lets N ranks share one GPU for testing")
     ap.add_argument("--selftest-launcher", action="store_true", help="rendezvous + all-reduce only, no GPU work (CPU test)")
     args = ap.parse_args()

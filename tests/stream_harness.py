@@ -1,0 +1,182 @@
+"""CPU harness around tools/gcn_sim.py for the generated instruction streams of the bf16 MLP kernels: builds the packed
+weight blob with the library's own pack table (host code, no GPU), the LDS image and the register inputs of one workgroup
+(4 waves x 2 point tiles x 32 points) exactly as the kernel sources set them up, runs the generated asm statement in the
+simulator and hands back registers / memory for comparison with the numpy oracle."""
+import ctypes
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gcn_sim as G                                   # noqa: E402
+from oracle import oracle_np as O                     # noqa: E402
+
+LANE = np.arange(64)
+LJ, LH = LANE & 31, LANE >> 5
+ORDER = [f"xyz_encoding_{i+1}.0" for i in range(8)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"]
+BLOB_BASE, ACTS_BASE, EMB_BASE = 0x10000000, 0x40000000, 0x7000000000
+V3_SLOT_BYTES, V3_SLOTS = 20480, 7
+V3_TAIL_OFF = V3_SLOT_BYTES * V3_SLOTS
+BIAS_FLOATS, AUX_SIGW, TAIL_FLOATS = 76 * 32, 0, 76 * 32 + 648
+
+
+def load_tool(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def acc_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def hid_slot_feature(q, h):
+    return 32 * (q >> 4) + acc_row(q & 15, h)
+
+
+def apply_table(table, raws, nbytes, weight_bytes):
+    """what pack_kernel does (csrc/sn_api.hip): blob[dst] = raw[src], weights rounded to bf16 RNE when weight_bytes == 2,
+    entries flagged fp32 (biases, aux table) stored as fp32"""
+    blob = np.zeros(nbytes, np.uint8)
+    flat = np.concatenate([r.reshape(-1).astype(np.float32) for r in raws])
+    starts = np.cumsum([0] + [r.size for r in raws])[:-1]
+    dst, src = table[:, 0].astype(np.int64), table[:, 1].astype(np.int64)
+    val = np.zeros(len(dst), np.float32)
+    ok = src >= 0
+    tid, off = (src[ok] >> 20) & 0x3FF, src[ok] & 0xFFFFF
+    val[ok] = flat[starts[tid] + off]
+    as_f32 = (src == -2) | (ok & ((src & (1 << 30)) != 0))
+    if weight_bytes == 4:
+        as_f32[:] = True
+    b32 = val.view(np.uint32)
+    for k in range(4):
+        blob[dst[as_f32] + k] = ((b32[as_f32] >> (8 * k)) & 0xFF).astype(np.uint8)
+    w = ~as_f32
+    b16 = G.bf16_rne(val[w])
+    blob[dst[w]] = (b16 & 0xFF).astype(np.uint8)
+    blob[dst[w] + 1] = (b16 >> 8).astype(np.uint8)
+    return blob
+
+
+def forward_blob_bf16(params):
+    from sinnerf_amd import _lib
+    lib = _lib.lib
+    raws = []
+    for k in ORDER:
+        raws += [params[k + ".weight"], params[k + ".bias"]]
+    n = lib.sn_pack_table_entries()
+    table = np.empty((n, 2), np.int32)
+    assert lib.sn_build_pack_table(1, ctypes.c_void_p(table.ctypes.data)) == 0
+    return apply_table(table, raws, lib.sn_packed_weights_bytes(1), 2)
+
+
+def slab_k(s):
+    return 64 if s < 8 else 256 if s < 32 else 320 if s < 40 else 256 if s < 72 else 288
+
+
+def slab_byte_offset(s):
+    return sum(slab_k(i) * 64 for i in range(s))
+
+
+def xyz_lane_slots(x_emb):
+    """(64 points of a wave: [pt][32], 63) embedded xyz -> per point tile the (64 lanes, 32 slots) fp32 values a lane computes"""
+    from sinnerf_amd import _lib
+    out = np.zeros((2, 64, 32), np.float32)
+    for pt in range(2):
+        for e in range(32):
+            for h in (0, 1):
+                c = _lib.lib.sn_layout_xyz_slot_col(h, e)
+                if c >= 0:
+                    out[pt, LH == h, e] = x_emb[pt * 32 + LJ[LH == h], c]
+    return out
+
+
+def pack8(f):
+    """(64, 8) fp32 -> (4, 64) packed bf16 pairs (v_cvt_pk_bf16_f32: low = first)"""
+    b = G.bf16_rne(f)
+    return np.stack([b[:, 2 * i] | (b[:, 2 * i + 1] << 16) for i in range(4)], 0).astype(np.uint32)
+
+
+class TrunkRun:
+    """one workgroup pass of the generated trunk statement"""
+
+    # register binding of the statement's named operands (anything below the statement's own range v128..)
+    BIND = dict(va0="v32", vb="v33", vs="v34", goff="v35", sg0="v36", sg1="v37", blob="s[4:5]", wv1k="s6", em="s[8:9]",
+                **{"xe%d" % i: "v[%d:%d]" % (4 * i, 4 * i + 3) for i in range(8)})
+
+    def __init__(self, params, xyz_points, seed=0, extra_bind=None):
+        """xyz_points: (256, 3) sample positions of the workgroup's point tile (wave w, point tile pt, point j)"""
+        self.params = params
+        self.blob = forward_blob_bf16(params)
+        self.x_emb = O.embedding(xyz_points.astype(np.float32), 10)              # (256, 63)
+        wg = G.Workgroup(4)
+        wg.mem.add("blob", BLOB_BASE, data=self.blob.tobytes(), writable=False)
+        # LDS as the kernel prologue leaves it: slabs 0..4 in ring slots 0..4, bias + aux table behind the ring
+        for s in range(5):
+            o = slab_byte_offset(s)
+            wg.lds.b[s * V3_SLOT_BYTES: s * V3_SLOT_BYTES + 4096] = self.blob[o:o + 4096]
+        tail0 = slab_byte_offset(76)
+        wg.lds.b[V3_TAIL_OFF: V3_TAIL_OFF + TAIL_FLOATS * 4] = self.blob[tail0: tail0 + TAIL_FLOATS * 4]
+        for w, wave in enumerate(wg.waves):
+            slots = xyz_lane_slots(self.x_emb[64 * w: 64 * w + 64])
+            for ks in range(4):
+                for pt in range(2):
+                    i = ks * 2 + pt
+                    wave.v[4 * i: 4 * i + 4] = pack8(slots[pt][:, 8 * ks: 8 * ks + 8])
+            wave.v[32] = LANE * 16
+            wave.v[33] = V3_TAIL_OFF + LH * 64
+            wave.v[34] = V3_TAIL_OFF + (BIAS_FLOATS + AUX_SIGW + LH * 128) * 4
+            wave.v[35] = (w * 64 + LANE) * 16 + 5 * 4096
+            wave.v[36] = 0
+            wave.v[37] = 0
+            wave.s[4], wave.s[5] = BLOB_BASE & 0xFFFFFFFF, BLOB_BASE >> 32
+            wave.s[6] = w * 1024
+            wave.vm = [("store", None)] * 4          # the generator's entry assumption: at most 4 older pieces in flight
+        self.wg = wg
+        self.bind = dict(self.BIND, **(extra_bind or {}))
+
+    def run(self, lines):
+        self.wg.run(G.bind(lines, self.bind))
+        return self
+
+    def activation_set(self, st):
+        """the 256-feature bf16 activation held in AGPR set st after the statement: (256 points, 256 features) fp32"""
+        out = np.zeros((256, 256), np.float32)
+        for w, wave in enumerate(self.wg.waves):
+            for ks in range(16):
+                for pt in range(2):
+                    base = st * 128 + (ks * 2 + pt) * 4
+                    for i in range(4):
+                        word = wave.a[base + i]
+                        for e, bits in enumerate((word & 0xFFFF, word >> 16)):
+                            q = 8 * ks + 2 * i + e
+                            for h in (0, 1):
+                                sel = LH == h
+                                out[64 * w + 32 * pt + LJ[sel], hid_slot_feature(q, h)] = G.bf16_to_f32(bits[sel])
+        return out
+
+    def sigma(self):
+        """sigma head as the kernel finishes it: both lane halves' partial sums + bias"""
+        tail0 = slab_byte_offset(76)
+        aux = self.blob[tail0 + BIAS_FLOATS * 4: tail0 + TAIL_FLOATS * 4].view(np.float32)
+        out = np.zeros(256, np.float32)
+        for w, wave in enumerate(self.wg.waves):
+            for pt, reg in ((0, 36), (1, 37)):
+                sg = wave.v[reg].view(np.float32)
+                out[64 * w + 32 * pt + np.arange(32)] = sg[:32] + sg[32:] + aux[640]
+        return out
+
+
+def oracle_trunk(params, x_emb):
+    """bf16-operand forward of the trunk in numpy: returns (h8 after ReLU (fp32), final, sigma) with the kernel's roundings"""
+    cache = {}
+    x = np.concatenate([x_emb, np.zeros((x_emb.shape[0], 27), np.float32)], 1)
+    with O.bf16_operands():
+        O.nerf_forward(params, x, cache=cache)
+    sig = cache["h8"].astype(np.float64) @ params["sigma.weight"].astype(np.float64).T + params["sigma.bias"]
+    return cache, sig[:, 0].astype(np.float32)
