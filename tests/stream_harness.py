@@ -180,3 +180,72 @@ def oracle_trunk(params, x_emb):
         O.nerf_forward(params, x, cache=cache)
     sig = cache["h8"].astype(np.float64) @ params["sigma.weight"].astype(np.float64).T + params["sigma.bias"]
     return cache, sig[:, 0].astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# STORE MODE (training forward, tools/gen_bf16_trunk.py store=1 / csrc/sn_mlp_fwd_bf16_t.hip)
+T_SLOTS = 4
+T_TAIL_OFF = T_SLOTS * V3_SLOT_BYTES                    # 81920
+T_STAGE_OFF = 94464                                     # 256-byte aligned behind the bias / aux table
+T_STAGE_WAVE = 9216
+SLOT_ROWS = 256
+
+
+class TrainTrunkRun(TrunkRun):
+    BIND = dict(TrunkRun.BIND, stw="v38", str0="v39", str1="v40", vo="v41", vsg="v42", sm="s10", aplo="s12", aphi="s13",
+                sglo="s14", sghi="s15", srlo="s16", srhi="s17")
+
+    def __init__(self, params, xyz_points):
+        self.params = params
+        self.blob = forward_blob_bf16(params)
+        self.x_emb = O.embedding(xyz_points.astype(np.float32), 10)
+        wg = G.Workgroup(4)
+        wg.mem.add("blob", BLOB_BASE, data=self.blob.tobytes(), writable=False)
+        self.acts = wg.mem.add("acts", ACTS_BASE, nbytes=10 * SLOT_ROWS * 512)
+        self.acts[:] = 0xEE
+        for s in range(3):                               # slabs 0..2 staged by the previous tile's dir section / the prologue
+            o = slab_byte_offset(s)
+            wg.lds.b[s * V3_SLOT_BYTES: s * V3_SLOT_BYTES + 4096] = self.blob[o:o + 4096]
+        tail0 = slab_byte_offset(76)
+        wg.lds.b[T_TAIL_OFF: T_TAIL_OFF + TAIL_FLOATS * 4] = self.blob[tail0: tail0 + TAIL_FLOATS * 4]
+        g, k = LANE >> 3, LANE & 7
+        b3, hh, e = k >> 2, (k >> 1) & 1, k & 1
+        for w, wave in enumerate(wg.waves):
+            slots = xyz_lane_slots(self.x_emb[64 * w: 64 * w + 64])
+            for ks in range(4):
+                for pt in range(2):
+                    i = ks * 2 + pt
+                    wave.v[4 * i: 4 * i + 4] = pack8(slots[pt][:, 8 * ks: 8 * ks + 8])
+            sb = T_STAGE_OFF + w * T_STAGE_WAVE
+            wave.v[32] = LANE * 16
+            wave.v[33] = T_TAIL_OFF + LH * 64
+            wave.v[34] = T_TAIL_OFF + (BIAS_FLOATS + AUX_SIGW + LH * 128) * 4
+            wave.v[35] = (w * 64 + LANE) * 16 + 3 * 4096
+            wave.v[36] = 0
+            wave.v[37] = 0
+            wave.v[38] = sb + LJ * 32 + 16 * (LH ^ ((LJ >> 3) & 1))
+            wave.v[39] = sb + b3 * 2304 + e * 1152 + g * 32 + 16 * hh
+            wave.v[40] = sb + b3 * 2304 + e * 1152 + g * 32 + 16 * (hh ^ 1)
+            wave.v[41] = g * 512 + 16 * k
+            wave.v[42] = LANE * 4
+            wave.s[4], wave.s[5] = BLOB_BASE & 0xFFFFFFFF, BLOB_BASE >> 32
+            wave.s[6] = w * 1024
+            wave.s[10] = 0x80008000
+            ap = ACTS_BASE + (64 * w) * 512
+            sg = ACTS_BASE + ((9 * SLOT_ROWS + 64 * w) * 256 + 128) * 2
+            wave.s[12], wave.s[13] = ap & 0xFFFFFFFF, ap >> 32
+            wave.s[14], wave.s[15] = sg & 0xFFFFFFFF, sg >> 32
+            wave.s[16], wave.s[17] = (SLOT_ROWS * 512) & 0xFFFFFFFF, (SLOT_ROWS * 512) >> 32
+            wave.vm = [("store", None)] * 2
+        self.wg = wg
+        self.bind = dict(self.BIND)
+
+    def stored(self, slot):
+        """acts[slot] as fp32: (256 points, 256 features)"""
+        a = self.acts.view(np.uint16).reshape(10, SLOT_ROWS, 256)[slot].astype(np.uint32)
+        return G.bf16_to_f32(a)
+
+    def sign_words(self):
+        """(256 points -> wave, 64 rows = 8 layer + tile, 64 lanes) uint32"""
+        a = self.acts.view(np.uint32).reshape(10, SLOT_ROWS, 128)[9][:, 64:]            # columns 128..255 of slot 9 as dwords
+        return a.reshape(4, 64, 64)

@@ -292,6 +292,18 @@ class Wave:
             self.wr(d, u32(out))
             return None
         # ---- VALU
+        if op == "v_permlane32_swap_b32":                    # vdst lanes 32..63 <-> src0 lanes 0..31 (both registers are written)
+            d, s0 = _parse_reg(args[0]), _parse_reg(args[1])
+            x, y = self.rd(d).copy(), self.rd(s0).copy()
+            if self.wg.swap_rev:
+                x, y = y, x
+            xh = x[32:].copy()
+            x[32:] = y[:32]
+            y[:32] = xh
+            if self.wg.swap_rev:
+                x, y = y, x
+            self.wr(d, x); self.wr(s0, y)
+            return None
         if op.startswith("v_"):
             d = _parse_reg(args[0])
             S = [self.rd(_parse_reg(a)) for a in args[1:]]
@@ -454,6 +466,7 @@ class Workgroup:
         self.waves = [Wave(self, w) for w in range(n_waves)]
         self.interval = 0
         self.n_store_bytes = 0
+        self.swap_rev = False                   # v_permlane32_swap_b32 operand roles (tools/ubench/permlane_probe.hip decides)
 
     def run(self, programs):
         """programs: one instruction list per wave (or one list for all).  Waves run one barrier interval at a time, in turn."""

@@ -44,10 +44,14 @@ KNOBS = dict(prefetch=4,        # A-fragment prefetch distance in k-steps (ring 
              setprio=0,
              dma_exec=0,        # experiment: 1 = every DMA runs with EXEC = %[em] (a mask the kernel supplies), WRONG results
              dma_thin=1,        # experiment: issue only every dma_thin-th piece (WRONG results)
-             tmp_pairs=2)       # epilogue temporaries: pairs of v[240:247] used in rotation (2 = v[240:243]; the registers a
+             tmp_pairs=2,       # epilogue temporaries: pairs of v[240:247] used in rotation (2 = v[240:243]; the registers a
                                 # shorter rotation does not name go back to the compiler, see the clobber list)
+             store=0,           # 1 = TRAINING forward (sn_mlp_fwd_bf16_t.hip): every output tile is also written to acts[] as bf16
+                                # (whole 128-byte rows, non-temporal) together with the ReLU sign words -- see STORE MODE below
+             swap_rev=0)        # store mode: operand order of v_permlane32_swap_b32 (probed on the device: tools/ubench/permlane_probe.hip)
 
-V_FIRST = 128                                  # first physical VGPR the statement owns (clobbers v[V_FIRST:255])
+STORE_KNOBS = dict(store=1, cap=6.0)            # the build of sn_mlp_fwd_bf16_t.hip (csrc/Makefile passes the same)
+V_FIRST = 128                                  # first physical VGPR the statement owns (clobbers v[V_FIRST:255]); store mode: 96
 ACC = lambda st, pt: 128 + st * 32 + pt * 16   # v[128:191]
 BIAS = 192                                     # v[192:207]
 RING0 = 208                                    # v[208:235]: up to 7 fragment-ring entries
@@ -67,9 +71,31 @@ SLOT_BYTES = 20480
 DMA_DIST = 6
 SLOTS_PER_BASE = 3                             # ds_read offsets are 16 bit: one address VGPR per 3 slots (va0, va1, va2)
 
-def staged_at(s):
+# ---- STORE MODE (training forward, bf16 state) -----------------------------------------------------------------
+# Ring: 4 slots, distance 3, no virtual slab (76 = 0 mod 4): 80 KB instead of 140, which leaves room for the staging tiles.
+# The slab time of the training kernel is bounded by its HBM stores, not by the MFMAs: a shorter DMA lead is affordable.
+# Registers:  v[96:111] four 4-register rows in flight (staging read -> global store), v[112:127] the packed output words of
+# the tile being finalised, [point tile][8], laid out so that after four v_permlane32_swap_b32 each half holds two
+# consecutive 4-register groups = two 16-byte chunks of its point row; v232 the ReLU sign word; s[84:85] running pointer into
+# acts[layer] (+ slot_rows * 512 B per layer), s[86:87] pointer to the sign-word rows.
+# Staging tile of a wave (LDS, 9216 B): [point tile: 4608][b3 = tile parity: 2304][e = which of the lane's two chunks: 1152]
+# [point row j: 32 B][16 * (h ^ ((j >> 3) & 1))] -- the 16-byte chunk m = 4 b3 + 2 h + e of the 128-byte row of a tile PAIR.
+#   write (ds_write_b128, lane = point row): 16 lanes of a group hit 16 distinct 16-byte bank groups (rows j and j + 8 of a
+#   group differ in (j >> 3) & 1);  read (ds_read_b128, lane = (g, k): row 8 i + g, chunk k): (8 e + 2 g + (h ^ (i & 1))) mod 16
+#   is a bijection on every 16-lane group.  Both conflict-free (tools/gcn_sim.py counts them).  One lane-address VGPR for the
+#   writes, two for the reads (i even / odd), supplied by the kernel.
+ST_RO, ST_PK, ST_SB = 96, 112, 232
+ST_PT, ST_B3, ST_E = 4608, 2304, 1152
+ST_SGPR_ACTS, ST_SGPR_SIGN = 84, 86
+ST_N_SLOTS, ST_DMA_DIST = 4, 3
+
+def staged_at(s, store=0):
     """real slabs whose pieces are issued behind the barrier of trunk slab s (virtual indices s + DMA_DIST; slab 0 also does the
-    virtual slab's duty: index 76 + DMA_DIST - 77 = 5)"""
+    virtual slab's duty: index 76 + DMA_DIST - 77 = 5).  Store mode: slab s + 3, always of the same point tile (the dir section
+    of the kernel stages slab 75 and the next tile's slabs 0..2)."""
+    if store:
+        assert s + ST_DMA_DIST < N_SLABS
+        return [s + ST_DMA_DIST]
     out = []
     if s == 0:
         out.append(5)
@@ -113,6 +139,10 @@ class Gen:
         self.lgkm = []                # outstanding LDS reads (tags) in issue order
         self.vm = [1, 2, 3, 4]        # outstanding LDS-DMA pieces (issue-order tags) on entry: at most the single pieces of
                                       # slabs 1..4, issued by the previous tile's dir_encoding section / the prologue
+        if knobs["store"]:
+            self.vm = [1, 2]          # ... store mode (distance 3): slabs 1, 2.  Older memory operations of the kernel that are
+                                      # still in flight only make the first counted waits stricter (vmcnt retires in order)
+        self.last_salu_write = {}     # SGPR -> wait-state clock of the SALU instruction that wrote it (SALU -> VMEM address: 5 states)
         self.last_valu_write = {}     # reg -> index in self.out of the VALU instruction that wrote it
         self.n_states = 0             # wait states issued so far (every instruction = 1, s_nop n = n + 1)
         self.state_at = []            # wait-state clock of each emitted instruction
@@ -146,6 +176,19 @@ class Gen:
         if need > 0:
             self.nop(need)
 
+    def pad_valu_to_swap(self, regs):
+        """VALU write -> v_permlane32_swap_b32 read of the same register: 2 wait states (what hipcc inserts for its own code)."""
+        self.pad_valu_to_mfma(regs)
+
+    def pad_salu_to_vmem(self, sregs):
+        need = 0
+        for r in sregs:
+            w = self.last_salu_write.get(r)
+            if w is not None:
+                need = max(need, 6 - (self.n_states - w))
+        if need > 0:
+            self.nop(need)
+
     def wait_lgkm(self, tags):
         """counted wait: every LDS read carrying one of `tags` has returned (LDS reads return in order)."""
         pos = -1
@@ -169,6 +212,22 @@ class Gen:
             if f.tag is not None:                        # needs LDS data (sigma weights)
                 self.wait_lgkm({f.tag})
             self.emit(f.text, writes=f.writes, valu=True)
+        elif k == "ds_write":
+            self.emit(f.text)
+            self.lgkm.append(("stw",))
+        elif k == "swap":
+            self.pad_valu_to_swap(f.reads)
+            self.emit(f.text, writes=f.writes, valu=True)
+        elif k == "salu":
+            self.emit(f.text)
+            for r in f.writes:
+                self.last_salu_write[r] = self.n_states - 1
+        elif k == "vstore":
+            if f.tag is not None:                        # the staged row has arrived in its registers
+                self.wait_lgkm({f.tag})
+            self.pad_salu_to_vmem(f.reads)
+            self.emit(f.text)
+            self.vm.append(10 ** 9)                      # never the target of a counted wait: only ever counts as "younger"
         elif k == "m0":
             self.emit(f.text)
             self.last_m0 = self.n_states - 1
@@ -230,8 +289,12 @@ def gen(knobs):
         fillers.append(f)
 
     assert R <= 7, "fragment ring: 7 entries of registers"
+    STORE = K["store"]
+    n_slots = ST_N_SLOTS if STORE else N_SLOTS
+    dma_dist = ST_DMA_DIST if STORE else DMA_DIST
+    assert not STORE or R <= 6, "store mode keeps v232..v235 for itself"
     def frag_addr(s, ks):
-        slot = s % N_SLOTS
+        slot = s % n_slots
         return ("%[va0]", "v%d" % VA1, "v%d" % VA2)[slot // SLOTS_PER_BASE], (slot % SLOTS_PER_BASE) * SLOT_BYTES + ks * 1024
 
     # ---- A fragments ------------------------------------------------------------------------------------------------
@@ -265,25 +328,108 @@ def gen(knobs):
                        K["lds_cost"], r, dl, "ds_read", tag=("bias", s)))
 
     # ---- epilogue of slab s, run inside slab s+1 (the last one is flushed after the backbone) ---------------------------
-    epi_tail = []
-    for s in range(N_SLABS_TRUNK):
-        if not K["epi"]:
-            break
+    # items: (kind, text, writes, tag, cls[, reads]);  cls "acc" = reads the slab's accumulator set (deadline: before slab s+2
+    # overwrites it), "post" = works on packed words / LDS / memory only (deadline one slab later; same-deadline items keep their
+    # program order, so a slab's post items still run before the next slab's accumulator items)
+    def store_epilogue(s):
+        L, t = layer_of(s), s % 8
+        W, st = WRITE_SET[L], s & 1
+        relu, sigma, copy = L <= 6, L == 7, L == 8
+        PKR = lambda pt, n: ST_PK + 8 * pt + n
+        # block i of a point tile -> its two packed words; after the swaps PK[0:3] = chunk e=0, PK[4:7] = chunk e=1 of the lane
+        slot_of = {0: (0, 1), 2: (2, 3), 1: (4, 5), 3: (6, 7)}
+        sigw = lambda i: SIGW + 4 * (i & 1)
+        items = []
+        def sig_load(i):
+            items.append(("ds_read", "ds_read_b128 v[%d:%d], %%[vs] offset:%d" % (sigw(i), sigw(i) + 3, (16 * t + 4 * i) * 4), (), ("sigw", s, i), "acc"))
+        step = [0]
+        def sign(word):
+            if step[0] == 0:
+                items.append(("valu", "v_and_b32 v%d, %%[sm], v%d" % (ST_SB, word), (ST_SB,), None, "acc"))
+            else:
+                items.append(("valu", "v_lshrrev_b32 v%d, 1, v%d" % (ST_SB, ST_SB), (ST_SB,), None, "acc"))
+                items.append(("valu", "v_and_or_b32 v%d, v%d, %%[sm], v%d" % (ST_SB, word, ST_SB), (ST_SB,), None, "acc"))
+            step[0] += 1
+        def block(pt, i):
+            a = ACC(st, pt) + 4 * i
+            t0, t1 = PKR(pt, slot_of[i][0]), PKR(pt, slot_of[i][1])
+            q = 2 * i
+            r0 = act_reg(W, 2 * t + (q >> 2), pt) + (q & 3)
+            items.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t0, a, a + 1), (t0,), None, "acc"))
+            items.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t1, a + 2, a + 3), (t1,), None, "acc"))
+            if not copy:
+                sign(t0)
+                items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t0, t0), (t0,), None, "acc"))
+                sign(t1)
+                items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t1, t1), (t1,), None, "acc"))
+            items.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0, t0), (("a", r0),), None, "acc"))
+            items.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0 + 1, t1), (("a", r0 + 1),), None, "acc"))
+            if sigma:                                        # sigma head from the fp32 ReLU outputs (nerf.py:136), as in inference
+                for e in range(4):
+                    items.append(("valu", "v_max_f32 v%d, 0, v%d" % (a + e, a + e), (a + e,), None, "acc"))
+                for e in range(4):
+                    items.append(("valu", "v_fmac_f32 %%[sg%d], v%d, v%d" % (pt, sigw(i) + e, a + e), (), ("sigw", s, i), "acc"))
+        def finish_pt(pt):
+            pairs = [(PKR(pt, 0), PKR(pt, 2)), (PKR(pt, 1), PKR(pt, 3)), (PKR(pt, 4), PKR(pt, 6)), (PKR(pt, 5), PKR(pt, 7))]
+            for x, y in pairs:
+                if K["swap_rev"]:
+                    x, y = y, x
+                items.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (x, y), (x, y), None, "post", (x, y)))
+            for e in range(2):
+                off = pt * ST_PT + (t & 1) * ST_B3 + e * ST_E
+                items.append(("ds_write", "ds_write_b128 %%[stw], v[%d:%d] offset:%d" % (PKR(pt, 4 * e), PKR(pt, 4 * e) + 3, off), (), None, "post"))
+        if sigma:                                            # q outermost, both point tiles share a quad's sigma weights
+            sig_load(0); sig_load(1)
+            for i in range(4):
+                for pt in range(2):
+                    block(pt, i)
+                if i + 2 < 4:
+                    sig_load(i + 2)
+            finish_pt(0); finish_pt(1)
+        else:                                                # point tile outermost: the sign-word step order of the chain
+            for pt in range(2):
+                for i in range(4):
+                    block(pt, i)
+                finish_pt(pt)
+        if not copy:                                         # the tile's ReLU sign word: 256 contiguous bytes per wave
+            items.append(("vstore", "global_store_dword %%[vsg], v%d, s[%d:%d] nt" % (ST_SB, ST_SGPR_SIGN, ST_SGPR_SIGN + 1), (), None, "post",
+                          (ST_SGPR_SIGN, ST_SGPR_SIGN + 1)))
+            items.append(("valu", "v_add_u32 %[vsg], 512, %[vsg]", ("vsg",), None, "post"))
+        if t & 1:                                            # tiles t-1, t of both point tiles leave as whole 128-byte rows
+            tp = t >> 1
+            rows = [(pt, i) for pt in range(2) for i in range(4)]
+            def rd(n):
+                pt, i = rows[n]
+                ro = ST_RO + 4 * (n % 4)
+                items.append(("ds_read", "ds_read_b128 v[%d:%d], %%[str%d] offset:%d" % (ro, ro + 3, i & 1, pt * ST_PT + 256 * i), (), ("ro", s, n), "post"))
+            def stw(n):
+                ro = ST_RO + 4 * (n % 4)
+                items.append(("vstore", "global_store_dwordx4 %%[vo], v[%d:%d], s[%d:%d] offset:%d nt" % (ro, ro + 3, ST_SGPR_ACTS, ST_SGPR_ACTS + 1, 128 * tp),
+                              (), ("ro", s, n), "post", (ST_SGPR_ACTS, ST_SGPR_ACTS + 1)))
+                if n < 7:
+                    items.append(("valu", "v_add_u32 %[vo], 4096, %[vo]", ("vo",), None, "post"))
+                else:
+                    items.append(("valu", "v_subrev_u32 %[vo], 28672, %[vo]", ("vo",), None, "post"))
+            rd(0); rd(1)
+            for n in range(8):
+                stw(n)
+                if n + 2 < 8:
+                    rd(n + 2)
+            if t == 7:                                       # next layer: acts[L + 1]
+                items.append(("salu", "s_add_u32 s%d, s%d, %%[srlo]" % (ST_SGPR_ACTS, ST_SGPR_ACTS), (ST_SGPR_ACTS,), None, "post"))
+                items.append(("salu", "s_addc_u32 s%d, s%d, %%[srhi]" % (ST_SGPR_ACTS + 1, ST_SGPR_ACTS + 1), (ST_SGPR_ACTS + 1,), None, "post"))
+        return items
+
+    def plain_epilogue(s):
         L, t = layer_of(s), s % 8
         W = WRITE_SET[L]
         st = s & 1
-        if s + 1 < N_SLABS_TRUNK:
-            rel0 = first[s + 1] + 1                      # two MFMAs after the slab's last one: results readable
-            n_gaps = first[s + 2] - first[s + 1] if s + 2 <= N_SLABS_TRUNK else 32
-            hard_dl = first[s + 2] - 1 if s + 2 < N_SLABS_TRUNK else len(mf) - 1   # accumulator set is overwritten by slab s+2
-        else:
-            rel0 = None
         sigma = (L == 7) and K["sigma"]
         copy = (L == 8)
         groups = []
         sigw = lambda i: SIGW + 4 * (i & 1)
         def sig_load(i):                                 # sigma-head weights of quad i of this tile (both point tiles share them)
-            return [("ds", "ds_read_b128 v[%d:%d], %%[vs] offset:%d" % (sigw(i), sigw(i) + 3, (16 * t + 4 * i) * 4), ("sigw", s, i))]
+            return [("ds_read", "ds_read_b128 v[%d:%d], %%[vs] offset:%d" % (sigw(i), sigw(i) + 3, (16 * t + 4 * i) * 4), (), ("sigw", s, i), "acc")]
         if sigma:
             groups.append(sig_load(0)); groups.append(sig_load(1))
         for i in range(4):
@@ -295,23 +441,45 @@ def gen(knobs):
                 ins = []
                 if sigma:
                     for e in range(4):
-                        ins.append(("v", "v_max_f32 v%d, 0, v%d" % (a + e, a + e), (a + e,), None))
+                        ins.append(("valu", "v_max_f32 v%d, 0, v%d" % (a + e, a + e), (a + e,), None, "acc"))
                     for e in range(4):
-                        ins.append(("v", "v_fmac_f32 %%[sg%d], v%d, v%d" % (pt, sigw(i) + e, a + e), (), ("sigw", s, i)))
-                    ins.append(("v", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t0, a, a + 1), (t0,), None))
-                    ins.append(("v", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t1, a + 2, a + 3), (t1,), None))
+                        ins.append(("valu", "v_fmac_f32 %%[sg%d], v%d, v%d" % (pt, sigw(i) + e, a + e), (), ("sigw", s, i), "acc"))
+                    ins.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t0, a, a + 1), (t0,), None, "acc"))
+                    ins.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t1, a + 2, a + 3), (t1,), None, "acc"))
                 else:
-                    ins.append(("v", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t0, a, a + 1), (t0,), None))
-                    ins.append(("v", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t1, a + 2, a + 3), (t1,), None))
+                    ins.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t0, a, a + 1), (t0,), None, "acc"))
+                    ins.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t1, a + 2, a + 3), (t1,), None, "acc"))
                     if not copy:
-                        ins.append(("v", "v_pk_max_i16 v%d, v%d, 0" % (t0, t0), (t0,), None))
-                        ins.append(("v", "v_pk_max_i16 v%d, v%d, 0" % (t1, t1), (t1,), None))
-                ins.append(("v", "v_accvgpr_write_b32 a%d, v%d" % (r0, t0), (("a", r0),), None))
-                ins.append(("v", "v_accvgpr_write_b32 a%d, v%d" % (r0 + 1, t1), (("a", r0 + 1),), None))
+                        ins.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t0, t0), (t0,), None, "acc"))
+                        ins.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t1, t1), (t1,), None, "acc"))
+                ins.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0, t0), (("a", r0),), None, "acc"))
+                ins.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0 + 1, t1), (("a", r0 + 1),), None, "acc"))
                 groups.append(ins)
             if sigma and i + 2 < 4:                      # the buffer quad i used is free once its fmacs have issued (in order)
                 groups.append(sig_load(i + 2))
-        flat = [x for grp in groups for x in grp]
+        return [x for grp in groups for x in grp]
+
+    COST = {"ds_read": K["lds_cost"], "ds_write": K["lds_cost"], "valu": K["valu_cost"], "swap": K["valu_cost"],
+            "vstore": K["dma_cost"], "salu": K["salu_cost"]}
+    def as_filler(item, rel, dl):
+        kind, text, writes, tag, _cls = item[:5]
+        reads = item[5] if len(item) > 5 else ()
+        return Filler(text, COST[kind], rel, dl, kind, reads=reads, writes=writes, tag=tag)
+
+    epi_tail = []
+    epi_fillers = []
+    for s in range(N_SLABS_TRUNK):
+        if not K["epi"]:
+            break
+        L, t = layer_of(s), s % 8
+        if s + 1 < N_SLABS_TRUNK:
+            rel0 = first[s + 1] + 1                      # two MFMAs after the slab's last one: results readable
+            n_gaps = first[s + 2] - first[s + 1] if s + 2 <= N_SLABS_TRUNK else 32
+            hard_dl = first[s + 2] - 1 if s + 2 < N_SLABS_TRUNK else len(mf) - 1   # accumulator set is overwritten by slab s+2
+            post_dl = first[s + 3] - 1 if s + 3 < N_SLABS_TRUNK else len(mf) - 1
+        else:
+            rel0 = None
+        flat = store_epilogue(s) if STORE else plain_epilogue(s)
         if rel0 is None:
             epi_tail = flat
             continue
@@ -327,10 +495,18 @@ def gen(knobs):
             dl = min(dl, idx_of[(nxt_first_slab, ks_needed, 0)] - 2)
         for j, item in enumerate(flat):
             rel = rel0 + j // per_gap
-            if item[0] == "ds":
-                add(Filler(item[1], K["lds_cost"], min(rel, dl), dl, "ds_read", tag=item[2]))
-            else:
-                add(Filler(item[1], K["valu_cost"], min(rel, dl), dl, "valu", writes=item[2], tag=item[3]))
+            d = dl if item[4] == "acc" else max(dl, post_dl)
+            f = as_filler(item, min(rel, d), d)
+            add(f)
+            epi_fillers.append(f)
+    if STORE:
+        # the epilogue stream is ONE program-ordered sequence (packed-word registers, the sign word, the staging tile and the
+        # running store offset are reused from tile to tile): deadlines must not decrease along it, or the list scheduler
+        # (earliest deadline first) would let a later tile's conversions overtake an earlier tile's staging writes
+        for a, b in zip(reversed(epi_fillers[:-1]), reversed(epi_fillers[1:])):
+            if a.deadline > b.deadline:
+                a.deadline = b.deadline
+                a.release = min(a.release, a.deadline)
 
     # ---- barrier + weight stream: at slab s, barrier (slab s+1 visible), then DMA of slab s+3 ------------------------------
     for s in range(N_SLABS_TRUNK):
@@ -338,18 +514,18 @@ def gen(knobs):
         if K["bar"]:
             add(Filler("", 0.5, b, b, "bar", tag=s + 1))
         if K["dma"]:
-            targets = staged_at(s)
+            targets = staged_at(s, STORE)
             plist = []                                    # (lds byte offset, goff bump, tag)
             for tgt in targets:
                 real = tgt - 1000 if tgt >= 1000 else tgt
                 nbytes = slab_k(real) * 64
                 pieces = -(-nbytes // 4096)
-                slot = real % N_SLOTS
+                slot = real % n_slots
                 for p in range(pieces):
                     bump = min(4096, nbytes - p * 4096)
                     if tgt >= 1000 and real == 0 and p == 0:
                         bump = None                       # the stream wraps: goff restarts at tid*16 (+4096 behind this piece)
-                    plist.append((slot * SLOT_BYTES + p * 4096, bump, s + DMA_DIST if tgt != 5 else 5))
+                    plist.append((slot * SLOT_BYTES + p * 4096, bump, s + dma_dist if (tgt != 5 or STORE) else 5))
             n_g = first[s + 1] - first[s]
             gaps_avail = max(1, n_g - K["bar_gap"] - 3)
             stride = max(1, gaps_avail // max(1, len(plist)))
@@ -372,7 +548,12 @@ def gen(knobs):
         g.emit("s_setprio %d" % K["setprio"])
     # preamble: address registers, first D fragments + bias of slab 0
     g.emit("v_add_u32 v%d, %d, %%[va0]" % (VA1, SLOTS_PER_BASE * SLOT_BYTES))
-    g.emit("v_add_u32 v%d, %d, %%[va0]" % (VA2, 2 * SLOTS_PER_BASE * SLOT_BYTES))
+    if not STORE:
+        g.emit("v_add_u32 v%d, %d, %%[va0]" % (VA2, 2 * SLOTS_PER_BASE * SLOT_BYTES))
+    else:                                                # running pointers of the statement (physical SGPRs, declared as clobbers)
+        for dst, src in ((ST_SGPR_ACTS, "aplo"), (ST_SGPR_ACTS + 1, "aphi"), (ST_SGPR_SIGN, "sglo"), (ST_SGPR_SIGN + 1, "sghi")):
+            g.emit("s_mov_b32 s%d, %%[%s]" % (dst, src))
+            g.last_salu_write[dst] = g.n_states - 1
     for q in range(4):
         g.emit("ds_read_b128 v[%d:%d], %%[vb] offset:%d" % (BIAS + 4 * q, BIAS + 4 * q + 3, q * 16)); g.lgkm.append(("bias", 0))
     if K["frag"]:
@@ -445,14 +626,10 @@ def gen(knobs):
         g.run_filler(f)
     g.nop(12)
     for item in epi_tail:
-        if item[0] == "ds":
-            g.emit(item[1]); g.lgkm.append(item[2])
-        else:
-            if item[3] is not None:
-                g.wait_lgkm({item[3]})
-            g.emit(item[1], writes=item[2], valu=True)
+        g.run_filler(as_filler(item, 0, 0))
     if g.lgkm:
         g.emit("s_waitcnt lgkmcnt(0)")
+        g.lgkm = []
     g.nop(2)                                             # accvgpr_write -> the compiler's first dir_encoding MFMA
     if K["setprio"]:
         g.emit("s_setprio 0")
@@ -487,8 +664,15 @@ def main():
                 used.update(range(int(m.group(1)), int(m.group(2)) + 1))
             for m in re.finditer(r"\bv(\d+)\b", line):
                 used.add(int(m.group(1)))
-        assert used and min(used) >= V_FIRST, "the statement only names registers of its own range"
+        assert used and min(used) >= (ST_RO if knobs["store"] else V_FIRST), "the statement only names registers of its own range"
+        sused = set()
+        for line in g.out:
+            for m in re.finditer(r"\bs\[(\d+):(\d+)\]", line):
+                sused.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            for m in re.finditer(r"\bs(\d+)\b", line):
+                sused.add(int(m.group(1)))
         f.write("#define SN_BF16_TRUNK_CLOBBERS " + ", ".join('"v%d"' % r for r in sorted(used)) + ", "
+                + "".join('"s%d", ' % r for r in sorted(sused))
                 + ", ".join('"a%d"' % r for r in range(256)) + ', "memory", "scc"\n')
     print("trunk: %d MFMAs, %d other (%.2f / MFMA), nops %d, waits %d, forced %d"
           % (g.mfma_count, n_other, n_other / g.mfma_count, g.stats["nop"], g.stats["wait"], g.stats["forced"]))
