@@ -28,6 +28,10 @@ extern "C" {
  * ShiftedSoftplus / WidenedSigmoid heads both reference call sites ask for (models/nerf.py:81-90, models/activations.py).
  * Blobs, training state and every other entry point are the same for both.                                          */
 #define SN_DTYPE_CLASSIC_HEADS 0x100
+/* OR-ed into `dtype` of sn_mlp_forward_train / sn_mlp_backward_chain (SN_DTYPE_BF16_STATE): run the compiler-scheduled kernels
+ * (csrc/sn_mlp_fwd_bf16.hip, csrc/sn_mlp_bwd_bf16.hip) instead of the hand-scheduled ones (csrc/sn_mlp_fwd_bf16_t.hip, ...).
+ * Same arithmetic, same stored state bit for bit; kept for A/B timing and the bit-identity tests. */
+#define SN_DTYPE_COMPILER_SCHEDULED 0x200
 
 #define SN_E_BADARG (-1)
 #define SN_E_TOOLARGE (-2)

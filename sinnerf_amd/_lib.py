@@ -14,6 +14,7 @@ SN_DTYPE_F32 = 0
 SN_DTYPE_BF16 = 1
 SN_DTYPE_BF16_STATE = 2
 SN_DTYPE_CLASSIC_HEADS = 0x100      # OR-ed into dtype: NeRF(use_new_activation=False) heads (include/sinnerf_hip.h)
+SN_DTYPE_COMPILER_SCHEDULED = 0x200 # OR-ed into dtype of the bf16-state training entries: the compiler-scheduled kernels (A/B, tests)
 N_RAW_TENSORS = 24
 ABI_VERSION = 2                     # == SN_ABI_VERSION of include/sinnerf_hip.h this binding was written against
 

@@ -16,6 +16,15 @@ from . import _lib
 from .nerf import dtype_code
 
 
+# developer switch (A/B timing, bit-identity tests): run the compiler-scheduled bf16-state training kernels instead of the
+# hand-scheduled ones -- same arithmetic and stored state
+COMPILER_SCHEDULED = bool(int(__import__("os").environ.get("SINNERF_COMPILER_SCHEDULED", "0")))
+
+
+def _sched_flag():
+    return _lib.SN_DTYPE_COMPILER_SCHEDULED if COMPILER_SCHEDULED else 0
+
+
 def _state_code(model, acts):
     """C-ABI dtype of the stored training state: fp32 MFMAs, bf16 operands on fp32 state, or bf16 operands on bf16 state."""
     if dtype_code(model.compute_dtype) != _lib.SN_DTYPE_BF16:
@@ -102,7 +111,7 @@ class _MLPFn(torch.autograd.Function):
             # blocks that _weight_grads slices away ([:, :63], [:, :27]) -- a contraction's output column depends on its own
             # X column only
             emb = torch.empty((rows, 128), dtype=torch.float32, device=dev)
-            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code), _lib.ptr(rays), _lib.ptr(z_vals), n, s,
+            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code) | _sched_flag(), _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                                      _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
                        "sn_mlp_forward_train")
         ctx.model = model

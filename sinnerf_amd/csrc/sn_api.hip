@@ -43,6 +43,10 @@ int sn_mlp_forward_bf16_v3_launch(const void* blob, const float* rays, const flo
                                   float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_v3_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
                                   float* out, hipStream_t stream);
+int sn_mlp_forward_bf16_t_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples, float* out,
+                                 float* acts, float* emb, long slot_rows, hipStream_t stream);
+int sn_mlp_forward_bf16_t_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
+                                         float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
                                  const float* g_depth, const float* g_w, float* g_raw, hipStream_t stream);
@@ -179,11 +183,14 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
                          float* out, float* acts, float* emb, long slot_rows, void* stream) {
   if (!blob || !rays || !z_vals || !out || !acts || !emb || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   const bool classic = dtype & SN_DTYPE_CLASSIC_HEADS;
-  dtype &= ~SN_DTYPE_CLASSIC_HEADS;
+  const bool compiler_scheduled = dtype & SN_DTYPE_COMPILER_SCHEDULED;
+  dtype &= ~(SN_DTYPE_CLASSIC_HEADS | SN_DTYPE_COMPILER_SCHEDULED);
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
   const long n_points = n_rays * (long)n_samples;
   const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are stored
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
+  if (dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256)         // the hand-scheduled kernel
+    return SN_HEADS(classic, sn_mlp_forward_bf16_t)(blob, rays, z_vals, n_points, n_samples, out, acts, emb, slot_rows, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32)
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
                                                   dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);

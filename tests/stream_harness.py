@@ -192,8 +192,8 @@ SLOT_ROWS = 256
 
 
 class TrainTrunkRun(TrunkRun):
-    BIND = dict(TrunkRun.BIND, stw="v38", str0="v39", str1="v40", vo="v41", vsg="v42", sm="s10", aplo="s12", aphi="s13",
-                sglo="s14", sghi="s15", srlo="s16", srhi="s17")
+    BIND = dict(TrunkRun.BIND, stw="v38", str0="v39", vo="v41", sm="s10", aplo="s12", aphi="s13",
+                sglo="s14", sghi="s15", srlo="s16", srhi="s17", vsk="s18")
 
     def __init__(self, params, xyz_points):
         self.params = params
@@ -231,6 +231,7 @@ class TrainTrunkRun(TrunkRun):
             wave.s[4], wave.s[5] = BLOB_BASE & 0xFFFFFFFF, BLOB_BASE >> 32
             wave.s[6] = w * 1024
             wave.s[10] = 0x80008000
+            wave.s[18] = (4 * BIAS_FLOATS - 7 * T_TAIL_OFF) & 0xFFFFFFFF
             ap = ACTS_BASE + (64 * w) * 512
             sg = ACTS_BASE + ((9 * SLOT_ROWS + 64 * w) * 256 + 128) * 2
             wave.s[12], wave.s[13] = ap & 0xFFFFFFFF, ap >> 32

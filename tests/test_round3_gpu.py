@@ -212,3 +212,54 @@ def test_bench_self_launch_two_gloo_ranks_one_gpu():
     leg = rec["train_dp"]
     assert leg["n_ranks_seen"] == 2 and leg["all_reduce_backend"] == "gloo" and leg["all_reduce_us"] > 0
     assert leg["replicas_identical_after"] >= 3
+
+
+def _train_forward(model, rays_t, z_t, flag):
+    """sn_mlp_forward_train (SN_DTYPE_BF16_STATE) through the C ABI; flag = 0 (hand-scheduled) or SN_DTYPE_COMPILER_SCHEDULED"""
+    from sinnerf_amd import _lib
+    n, s = z_t.shape
+    P = n * s
+    rows = -(-P // 256) * 256
+    d = rays_t.device
+    out = torch.zeros((n, s, 4), dtype=torch.float32, device=d)
+    acts = torch.full((10, rows, 256), float("nan"), dtype=torch.bfloat16, device=d)
+    emb = torch.full((rows, 128), float("nan"), dtype=torch.float32, device=d)
+    _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(_lib.SN_DTYPE_BF16_STATE) | flag, _lib.ptr(rays_t),
+                                             _lib.ptr(z_t), n, s, _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
+               "sn_mlp_forward_train")
+    torch.cuda.synchronize()
+    return out, acts, emb
+
+
+@pytest.mark.parametrize("n_rays,S", [(60, 37), (700, 64), (4096, 128)])
+def test_hand_scheduled_training_forward_equals_compiler_scheduled_bit_for_bit(n_rays, S):
+    """csrc/sn_mlp_fwd_bf16_t.hip (generated trunk, conflict-free staging planes, 4-slot ring) against the compiler-scheduled
+    mlp_fwd_bf16_kernel<false, 0, 2>: output, every stored activation row, the ReLU sign words and the embedded inputs are the
+    SAME BITS (same operands, same fp32 accumulation order).  2220 points = a ragged last tile; 4096 x 128 = the fine pass of a
+    training step (every workgroup walks several tiles: the weight ring wraps)."""
+    from sinnerf_amd import _lib
+    model, p = make_model(3, True, dtype="bf16")
+    rays = O.lego_rays(400, 400, seed=0)[:: max(1, 160000 // n_rays)][:n_rays]
+    z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (rays.shape[0], S)).astype(np.float32))
+    rays_t, z_t = torch.from_numpy(rays).to(dev()), torch.from_numpy(z).to(dev())
+    new = _train_forward(model, rays_t, z_t, 0)
+    old = _train_forward(model, rays_t, z_t, _lib.SN_DTYPE_COMPILER_SCHEDULED)
+    P = rays.shape[0] * S
+    assert torch.equal(new[0], old[0])
+    a_new, a_old = new[1].view(torch.int16), old[1].view(torch.int16)
+    rows = a_new.shape[1]
+    # rows of whole tiles are written by both kernels (pad rows: copies of the last point); compare everything both define
+    for l in range(10):
+        if not torch.equal(a_new[l], a_old[l]):
+            bad = (a_new[l] != a_old[l]).nonzero()
+            raise AssertionError(("acts slot", l, "first mismatches", bad[:5].tolist(), "count", int(bad.shape[0]), "rows", rows, "P", P))
+    e_new, e_old = new[2].view(torch.int32), old[2].view(torch.int32)
+    cols = torch.cat([torch.arange(0, 63), torch.arange(64, 91)]).to(dev())         # pad columns are never written
+    assert torch.equal(e_new[:, cols], e_old[:, cols])
+    # and against the oracle: the forward output at the 1e-3-class bf16 bar of the other bf16 tests
+    xin = np.concatenate([O.embedding(O._points(rays, z).reshape(-1, 3), 10), np.repeat(O.embedding(rays[:, 3:6], 4), S, 0)], 1)
+    if P <= 50000:
+        with O.bf16_operands():
+            ref = O.nerf_forward(p, xin)
+        got = new[0].cpu().numpy().reshape(-1, 4)
+        assert np.abs(got - ref).max() <= 6e-3 * np.abs(ref).max()

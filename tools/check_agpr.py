@@ -12,7 +12,9 @@ guarantees are checked on the generated code instead:
      behind it (counted on the generated code -- a compiler that moves one nontemporal store across a counted wait fails
      the build instead of producing stale masks);
   5. a vector-memory instruction inside inline asm does not use an SGPR address within 5 wait states of the SALU instruction
-     that wrote it (hipcc pads this hazard for its own instructions only).
+     that wrote it (hipcc pads this hazard for its own instructions only);
+  6. a v_permlane32_swap_b32 does not read a register a VALU instruction wrote within the previous 2 wait states (hipcc inserts
+     s_nop 1 for its own code).
 usage: check_agpr.py file.s"""
 import re, sys
 
@@ -39,7 +41,7 @@ def sregs(tok):
     return out
 
 for ln, l in enumerate(open(sys.argv[1]), 1):
-    m = re.match(r'^(_Z\S*(?:mlp_(?:fwd_bf16|fwd_bf16_v3|fwd_f32|bwd_chain_bf16|bwd_chain_f32)_kernel|dw_f32_asm_kernel|dw_bf16_asm_kernel)\S*):', l)
+    m = re.match(r'^(_Z\S*(?:mlp_(?:fwd_bf16|fwd_bf16_v3|fwd_bf16_t|fwd_f32|bwd_chain_bf16|bwd_chain_f32)_kernel|dw_f32_asm_kernel|dw_bf16_asm_kernel)\S*):', l)
     if m: kern = m.group(1); continue
     if kern is None: continue
     if re.match(r'^\s*s_endpgm', l): kern = None; continue
@@ -80,6 +82,15 @@ for ln, l in enumerate(open(sys.argv[1]), 1):
 
 haz1 = []; haz2 = []
 for i, (ln, op, dst, src, is_valu, t, _rr) in enumerate(ins):
+    if op.startswith('v_permlane32_swap'):
+        ws = 0; j = i - 1
+        while j >= 0 and ws < 2:
+            if ins[j][1] == 's_nop': ws += int(ins[j][5].split()[1], 0) + 1
+            else:
+                if ins[j][4] and (ins[j][2] & (src | dst)): haz1.append((ln, ins[j][5], t))
+                ws += 8 if ins[j][1].startswith('v_mfma') else 1
+            j -= 1
+        continue
     if not op.startswith('v_mfma'): continue
     # leading s_nop N inside the same asm statement shows up as the previous instruction
     ws = 0; j = i - 1

@@ -51,7 +51,7 @@ KNOBS = dict(prefetch=4,        # A-fragment prefetch distance in k-steps (ring 
              swap_rev=0)        # store mode: operand order of v_permlane32_swap_b32 (probed on the device: tools/ubench/permlane_probe.hip)
 
 STORE_KNOBS = dict(store=1, cap=6.0)            # the build of sn_mlp_fwd_bf16_t.hip (csrc/Makefile passes the same)
-V_FIRST = 128                                  # first physical VGPR the statement owns (clobbers v[V_FIRST:255]); store mode: 96
+V_FIRST = 128                                  # first physical VGPR the statement owns (clobbers v[V_FIRST:255])
 ACC = lambda st, pt: 128 + st * 32 + pt * 16   # v[128:191]
 BIAS = 192                                     # v[192:207]
 RING0 = 208                                    # v[208:235]: up to 7 fragment-ring entries
@@ -74,17 +74,22 @@ SLOTS_PER_BASE = 3                             # ds_read offsets are 16 bit: one
 # ---- STORE MODE (training forward, bf16 state) -----------------------------------------------------------------
 # Ring: 4 slots, distance 3, no virtual slab (76 = 0 mod 4): 80 KB instead of 140, which leaves room for the staging tiles.
 # The slab time of the training kernel is bounded by its HBM stores, not by the MFMAs: a shorter DMA lead is affordable.
-# Registers:  v[96:111] four 4-register rows in flight (staging read -> global store), v[112:127] the packed output words of
-# the tile being finalised, [point tile][8], laid out so that after four v_permlane32_swap_b32 each half holds two
-# consecutive 4-register groups = two 16-byte chunks of its point row; v232 the ReLU sign word; s[84:85] running pointer into
-# acts[layer] (+ slot_rows * 512 B per layer), s[86:87] pointer to the sign-word rows.
+# Registers: NO extra VGPRs over the inference statement.  The packed output words of the tile being finalised are written over
+# the accumulator registers they were converted from -- blocks 0 and 1 of each point tile's 16 accumulators receive
+# [t0_0 t1_0 t0_2 t1_2] and [t0_1 t1_1 t0_3 t1_3], laid out so that after four v_permlane32_swap_b32 each lane half holds two
+# consecutive 4-register groups = two 16-byte chunks of its point row (every conversion reads its sources before a later one
+# overwrites them); they are swapped and written to LDS before slab s+2 re-uses the accumulator set.  v[240:247] two 4-register
+# rows in flight (staging read -> global store), v238/v239 conversion temporaries of layer 8 (whose fp32 ReLU outputs also feed
+# the sigma head), v232 the ReLU sign word, v233..v235 derived lane addresses; s[84:85] running pointer into acts[layer]
+# (+ slot_rows * 512 B per layer), s[86:87] pointer to the sign-word rows.
 # Staging tile of a wave (LDS, 9216 B): [point tile: 4608][b3 = tile parity: 2304][e = which of the lane's two chunks: 1152]
 # [point row j: 32 B][16 * (h ^ ((j >> 3) & 1))] -- the 16-byte chunk m = 4 b3 + 2 h + e of the 128-byte row of a tile PAIR.
 #   write (ds_write_b128, lane = point row): 16 lanes of a group hit 16 distinct 16-byte bank groups (rows j and j + 8 of a
 #   group differ in (j >> 3) & 1);  read (ds_read_b128, lane = (g, k): row 8 i + g, chunk k): (8 e + 2 g + (h ^ (i & 1))) mod 16
 #   is a bijection on every 16-lane group.  Both conflict-free (tools/gcn_sim.py counts them).  One lane-address VGPR for the
 #   writes, two for the reads (i even / odd), supplied by the kernel.
-ST_RO, ST_PK, ST_SB = 96, 112, 232
+ST_RO, ST_T0, ST_SB = 240, 238, 232
+ST_VS, ST_STR1, ST_VSG = 233, 234, 235      # derived inside the statement: sigma-weight address, odd-row read address, sign-store offset
 ST_PT, ST_B3, ST_E = 4608, 2304, 1152
 ST_SGPR_ACTS, ST_SGPR_SIGN = 84, 86
 ST_N_SLOTS, ST_DMA_DIST = 4, 3
@@ -335,13 +340,13 @@ def gen(knobs):
         L, t = layer_of(s), s % 8
         W, st = WRITE_SET[L], s & 1
         relu, sigma, copy = L <= 6, L == 7, L == 8
-        PKR = lambda pt, n: ST_PK + 8 * pt + n
+        PKR = lambda pt, n: ACC(st, pt) + n              # packed word n of the point tile: over accumulator blocks 0, 1
         # block i of a point tile -> its two packed words; after the swaps PK[0:3] = chunk e=0, PK[4:7] = chunk e=1 of the lane
         slot_of = {0: (0, 1), 2: (2, 3), 1: (4, 5), 3: (6, 7)}
         sigw = lambda i: SIGW + 4 * (i & 1)
         items = []
         def sig_load(i):
-            items.append(("ds_read", "ds_read_b128 v[%d:%d], %%[vs] offset:%d" % (sigw(i), sigw(i) + 3, (16 * t + 4 * i) * 4), (), ("sigw", s, i), "acc"))
+            items.append(("ds_read", "ds_read_b128 v[%d:%d], v%d offset:%d" % (sigw(i), sigw(i) + 3, ST_VS, (16 * t + 4 * i) * 4), (), ("sigw", s, i), "acc"))
         step = [0]
         def sign(word):
             if step[0] == 0:
@@ -355,29 +360,38 @@ def gen(knobs):
             t0, t1 = PKR(pt, slot_of[i][0]), PKR(pt, slot_of[i][1])
             q = 2 * i
             r0 = act_reg(W, 2 * t + (q >> 2), pt) + (q & 3)
-            items.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t0, a, a + 1), (t0,), None, "acc"))
-            items.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t1, a + 2, a + 3), (t1,), None, "acc"))
-            if not copy:
-                sign(t0)
-                items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t0, t0), (t0,), None, "acc"))
-                sign(t1)
-                items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t1, t1), (t1,), None, "acc"))
-            items.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0, t0), (("a", r0),), None, "acc"))
-            items.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0 + 1, t1), (("a", r0 + 1),), None, "acc"))
-            if sigma:                                        # sigma head from the fp32 ReLU outputs (nerf.py:136), as in inference
+            if sigma:
+                # layer 8: signs from the packed raw values, sigma head from the fp32 ReLU outputs (nerf.py:136, as in inference),
+                # ReLU of the packed pair lands in the point tile's packed-word registers (pk_max(cvt(x), 0) == cvt(max(x, 0)))
+                c0, c1 = ST_T0, ST_T0 + 1
+                items.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (c0, a, a + 1), (c0,), None, "acc"))
+                items.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (c1, a + 2, a + 3), (c1,), None, "acc"))
+                sign(c0); sign(c1)
                 for e in range(4):
                     items.append(("valu", "v_max_f32 v%d, 0, v%d" % (a + e, a + e), (a + e,), None, "acc"))
                 for e in range(4):
                     items.append(("valu", "v_fmac_f32 %%[sg%d], v%d, v%d" % (pt, sigw(i) + e, a + e), (), ("sigw", s, i), "acc"))
+                items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t0, c0), (t0,), None, "acc"))
+                items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t1, c1), (t1,), None, "acc"))
+            else:
+                items.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t0, a, a + 1), (t0,), None, "acc"))
+                items.append(("valu", "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (t1, a + 2, a + 3), (t1,), None, "acc"))
+                if not copy:
+                    sign(t0)
+                    items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t0, t0), (t0,), None, "acc"))
+                    sign(t1)
+                    items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t1, t1), (t1,), None, "acc"))
+            items.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0, t0), (("a", r0),), None, "acc"))
+            items.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0 + 1, t1), (("a", r0 + 1),), None, "acc"))
         def finish_pt(pt):
             pairs = [(PKR(pt, 0), PKR(pt, 2)), (PKR(pt, 1), PKR(pt, 3)), (PKR(pt, 4), PKR(pt, 6)), (PKR(pt, 5), PKR(pt, 7))]
             for x, y in pairs:
                 if K["swap_rev"]:
                     x, y = y, x
-                items.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (x, y), (x, y), None, "post", (x, y)))
+                items.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (x, y), (x, y), None, "acc", (x, y)))
             for e in range(2):
                 off = pt * ST_PT + (t & 1) * ST_B3 + e * ST_E
-                items.append(("ds_write", "ds_write_b128 %%[stw], v[%d:%d] offset:%d" % (PKR(pt, 4 * e), PKR(pt, 4 * e) + 3, off), (), None, "post"))
+                items.append(("ds_write", "ds_write_b128 %%[stw], v[%d:%d] offset:%d" % (PKR(pt, 4 * e), PKR(pt, 4 * e) + 3, off), (), None, "acc"))
         if sigma:                                            # q outermost, both point tiles share a quad's sigma weights
             sig_load(0); sig_load(1)
             for i in range(4):
@@ -392,18 +406,19 @@ def gen(knobs):
                     block(pt, i)
                 finish_pt(pt)
         if not copy:                                         # the tile's ReLU sign word: 256 contiguous bytes per wave
-            items.append(("vstore", "global_store_dword %%[vsg], v%d, s[%d:%d] nt" % (ST_SB, ST_SGPR_SIGN, ST_SGPR_SIGN + 1), (), None, "post",
+            items.append(("vstore", "global_store_dword v%d, v%d, s[%d:%d] nt" % (ST_VSG, ST_SB, ST_SGPR_SIGN, ST_SGPR_SIGN + 1), (), None, "post",
                           (ST_SGPR_SIGN, ST_SGPR_SIGN + 1)))
-            items.append(("valu", "v_add_u32 %[vsg], 512, %[vsg]", ("vsg",), None, "post"))
+            items.append(("valu", "v_add_u32 v%d, 512, v%d" % (ST_VSG, ST_VSG), (ST_VSG,), None, "post"))
         if t & 1:                                            # tiles t-1, t of both point tiles leave as whole 128-byte rows
             tp = t >> 1
             rows = [(pt, i) for pt in range(2) for i in range(4)]
             def rd(n):
                 pt, i = rows[n]
-                ro = ST_RO + 4 * (n % 4)
-                items.append(("ds_read", "ds_read_b128 v[%d:%d], %%[str%d] offset:%d" % (ro, ro + 3, i & 1, pt * ST_PT + 256 * i), (), ("ro", s, n), "post"))
+                ro = ST_RO + 4 * (n % 2)
+                src = "v%d" % ST_STR1 if (i & 1) else "%[str0]"
+                items.append(("ds_read", "ds_read_b128 v[%d:%d], %s offset:%d" % (ro, ro + 3, src, pt * ST_PT + 256 * i), (), ("ro", s, n), "post"))
             def stw(n):
-                ro = ST_RO + 4 * (n % 4)
+                ro = ST_RO + 4 * (n % 2)
                 items.append(("vstore", "global_store_dwordx4 %%[vo], v[%d:%d], s[%d:%d] offset:%d nt" % (ro, ro + 3, ST_SGPR_ACTS, ST_SGPR_ACTS + 1, 128 * tp),
                               (), ("ro", s, n), "post", (ST_SGPR_ACTS, ST_SGPR_ACTS + 1)))
                 if n < 7:
@@ -554,6 +569,11 @@ def gen(knobs):
         for dst, src in ((ST_SGPR_ACTS, "aplo"), (ST_SGPR_ACTS + 1, "aphi"), (ST_SGPR_SIGN, "sglo"), (ST_SGPR_SIGN + 1, "sghi")):
             g.emit("s_mov_b32 s%d, %%[%s]" % (dst, src))
             g.last_salu_write[dst] = g.n_states - 1
+        # lane addresses derived from the kernel's: vb = TAIL + 64 h -> sigma weights at TAIL + 4 (BIAS_FLOATS + 128 h) = 8 vb - 7 TAIL
+        # + 4 BIAS_FLOATS (%[vsk] = that constant); the odd-row staging read address = str0 ^ 16; the sign-store offset = lane * 4
+        g.emit("v_lshl_add_u32 v%d, %%[vb], 3, %%[vsk]" % ST_VS)
+        g.emit("v_xor_b32 v%d, 16, %%[str0]" % ST_STR1)
+        g.emit("v_lshrrev_b32 v%d, 2, %%[va0]" % ST_VSG)
     for q in range(4):
         g.emit("ds_read_b128 v[%d:%d], %%[vb] offset:%d" % (BIAS + 4 * q, BIAS + 4 * q + 3, q * 16)); g.lgkm.append(("bias", 0))
     if K["frag"]:
@@ -664,7 +684,7 @@ def main():
                 used.update(range(int(m.group(1)), int(m.group(2)) + 1))
             for m in re.finditer(r"\bv(\d+)\b", line):
                 used.add(int(m.group(1)))
-        assert used and min(used) >= (ST_RO if knobs["store"] else V_FIRST), "the statement only names registers of its own range"
+        assert used and min(used) >= V_FIRST, "the statement only names registers of its own range"
         sused = set()
         for line in g.out:
             for m in re.finditer(r"\bs\[(\d+):(\d+)\]", line):
