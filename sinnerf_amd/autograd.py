@@ -134,7 +134,7 @@ class _MLPFn(torch.autograd.Function):
             code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
             if acts.dtype == torch.bfloat16:
                 code = _lib.SN_DTYPE_BF16_STATE
-            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(model.compute_dtype)), model.kernel_dtype(code),
+            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(model.compute_dtype)), model.kernel_dtype(code) | _sched_flag(),
                                                       _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")
             needs = ctx.needs_input_grad[3:]

@@ -47,6 +47,10 @@ int sn_mlp_forward_bf16_t_launch(const void* blob, const float* rays, const floa
                                  float* acts, float* emb, long slot_rows, hipStream_t stream);
 int sn_mlp_forward_bf16_t_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
                                          float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
+int sn_mlp_backward_chain_bf16_t_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw, long n_points,
+                                        long slot_rows, float* G, float* g_out, hipStream_t stream);
+int sn_mlp_backward_chain_bf16_t_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                                long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_composite_backward_launch(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  float noise_std, long n_rays, int n_samples, int white_back, const float* g_rgb,
                                  const float* g_depth, const float* g_w, float* g_raw, hipStream_t stream);
@@ -218,10 +222,13 @@ int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, co
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream) {
   if (!blob_bwd || !acts || !out_raw || !g_raw || !g_acts || !g_out || n_points < 0) return SN_E_BADARG;
   const bool classic = dtype & SN_DTYPE_CLASSIC_HEADS;
-  dtype &= ~SN_DTYPE_CLASSIC_HEADS;
+  const bool compiler_scheduled = dtype & SN_DTYPE_COMPILER_SCHEDULED;
+  dtype &= ~(SN_DTYPE_CLASSIC_HEADS | SN_DTYPE_COMPILER_SCHEDULED);
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
   const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are written
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
+  if (dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256)         // the hand-scheduled kernel
+    return SN_HEADS(classic, sn_mlp_backward_chain_bf16_t)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32)
     return SN_HEADS(classic, sn_mlp_backward_chain_bf16)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
                                                          dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);

@@ -250,3 +250,92 @@ class TrainTrunkRun(TrunkRun):
         """(256 points -> wave, 64 rows = 8 layer + tile, 64 lanes) uint32"""
         a = self.acts.view(np.uint32).reshape(10, SLOT_ROWS, 128)[9][:, 64:]            # columns 128..255 of slot 9 as dwords
         return a.reshape(4, 64, 64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BACKWARD CHAIN (tools/gen_bf16_chain.py / csrc/sn_mlp_bwd_bf16_t.hip)
+C_SLOT_BYTES, C_SLOTS = 16384, 4
+C_TAIL_OFF = C_SLOT_BYTES * C_SLOTS                     # 65536
+C_STAGE_OFF = 77312                                     # behind the 11776-byte tail (zeros + aux), 256-byte aligned
+BB_ZERO_FLOATS, BB_AUX_SIGT, BB_TAIL_FLOATS = 72 * 32, 384, 72 * 32 + 640
+G_BASE = 0x50000000
+
+
+def backward_blob_bf16(params):
+    from sinnerf_amd import _lib
+    lib = _lib.lib
+    raws = []
+    for k in ORDER:
+        raws += [params[k + ".weight"], params[k + ".bias"]]
+    n = lib.sn_pack_table_entries_bwd_bf16()
+    table = np.empty((n, 2), np.int32)
+    assert lib.sn_build_pack_table_bwd_bf16(ctypes.c_void_p(table.ctypes.data)) == 0
+    return apply_table(table, raws, lib.sn_packed_weights_bytes_bwd_bf16(), 2)
+
+
+def chain_slab_bytes(s):
+    return (8 if s < 8 else 16) * 1024
+
+
+class ChainRun:
+    BIND = dict(va0="v32", stw="v38", str0="v39", vo="v41", goff="v35", gs0="v36", gs1="v37", vst="v34", blob="s[4:5]", wv1k="s6",
+                c01="s10", gplo="s12", gphi="s13", sglo="s14", sghi="s15", srlo="s16", srhi="s17")
+
+    def __init__(self, params, acts_bytes, g_y2, g_sigma):
+        """acts_bytes: the forward's acts buffer (sign words in the upper half of slot 9); g_y2: (256, 128) fp32 pre-activation
+        gradient of dir_encoding (the kernel's C++ prologue computes it; packed RNE into AGPR set 0); g_sigma: (256,)"""
+        self.blob = backward_blob_bf16(params)
+        wg = G.Workgroup(4)
+        wg.mem.add("bblob", BLOB_BASE, data=self.blob.tobytes(), writable=False)
+        wg.mem.add("acts", ACTS_BASE, data=acts_bytes.tobytes(), writable=False)
+        self.G = wg.mem.add("G", G_BASE, nbytes=10 * SLOT_ROWS * 512)
+        self.G[:] = 0xEE
+        off = 0
+        for s in range(3):
+            wg.lds.b[s * C_SLOT_BYTES: s * C_SLOT_BYTES + chain_slab_bytes(s)] = self.blob[off: off + chain_slab_bytes(s)]
+            off += chain_slab_bytes(s)
+        tail0 = sum(chain_slab_bytes(s) for s in range(72))
+        wg.lds.b[C_TAIL_OFF: C_TAIL_OFF + BB_TAIL_FLOATS * 4] = self.blob[tail0: tail0 + BB_TAIL_FLOATS * 4]
+        g, k = LANE >> 3, LANE & 7
+        b3, hh, e = k >> 2, (k >> 1) & 1, k & 1
+        gb = G.bf16_rne(g_y2)                                                    # (256, 128) bf16 bits
+        for w, wave in enumerate(wg.waves):
+            for ks in range(8):
+                for pt in range(2):
+                    base = (ks * 2 + pt) * 4                                     # set 0
+                    for i in range(4):
+                        word = np.zeros(64, np.uint32)
+                        for ee in range(2):
+                            q = 8 * ks + 2 * i + ee
+                            for h in (0, 1):
+                                sel = LH == h
+                                word[sel] |= gb[64 * w + 32 * pt + LJ[sel], hid_slot_feature(q, h)] << (16 * ee)
+                        wave.a[base + i] = word
+            sb = C_STAGE_OFF + w * T_STAGE_WAVE
+            wave.v[32] = LANE * 16
+            wave.v[34] = C_TAIL_OFF + (BB_ZERO_FLOATS + BB_AUX_SIGT + LH * 128) * 4
+            wave.v[35] = (w * 64 + LANE) * 16 + sum(chain_slab_bytes(s) for s in range(3))
+            for pt, reg in ((0, 36), (1, 37)):
+                wave.v[reg] = np.asarray(g_sigma[64 * w + 32 * pt + LJ], np.float32).view(np.uint32)
+            wave.v[38] = sb + LJ * 32 + 16 * (LH ^ ((LJ >> 3) & 1))
+            wave.v[39] = sb + b3 * 2304 + e * 1152 + g * 32 + 16 * hh
+            wave.v[41] = g * 512 + 16 * k
+            wave.s[4], wave.s[5] = BLOB_BASE & 0xFFFFFFFF, BLOB_BASE >> 32
+            wave.s[6] = w * 1024
+            wave.s[10] = 0x00010001
+            gp = G_BASE + (8 * SLOT_ROWS + 64 * w) * 512
+            sg = ACTS_BASE + ((9 * SLOT_ROWS + 64 * w) * 256 + 128) * 2
+            wave.s[12], wave.s[13] = gp & 0xFFFFFFFF, gp >> 32
+            wave.s[14], wave.s[15] = sg & 0xFFFFFFFF, sg >> 32
+            wave.s[16], wave.s[17] = (SLOT_ROWS * 512) & 0xFFFFFFFF, (SLOT_ROWS * 512) >> 32
+            wave.vm = [("store", None)] * 4
+        self.wg = wg
+        self.bind = dict(self.BIND)
+
+    def run(self, lines):
+        self.wg.run(G.bind(lines, self.bind))
+        return self
+
+    def stored(self, slot):
+        a = self.G.view(np.uint16).reshape(10, SLOT_ROWS, 256)[slot].astype(np.uint32)
+        return G.bf16_to_f32(a)

@@ -84,3 +84,32 @@ def test_training_trunk_stream_stores_state_and_sign_words(setup):
                                 a = act[64 * w + 32 * pt + j, feat]
                                 assert not (bit & (a > 0)).any()        # a stored positive activation never carries a sign bit
                                 assert ((bit == 0) & (a == 0)).mean() <= 0.02   # zero without sign bit: only an exact +0 pre-activation
+
+
+def test_backward_chain_stream_matches_oracle(setup):
+    """tools/gen_bf16_chain.py (csrc/sn_mlp_bwd_bf16_t.hip): the 72-slab statement consumes what the simulated training forward
+    stored (sign words, activations) and writes G[slot] = bf16 pre-activation gradients; against ``nerf_backward`` with both
+    operands of every contraction rounded to bf16 (masks from the forward's stored values, as on the GPU)."""
+    params, pts = setup
+    gen = H.load_tool("gen_bf16_trunk"); genc = H.load_tool("gen_bf16_chain")
+    fwd = H.TrainTrunkRun(params, pts).run(gen.gen(dict(gen.KNOBS, **gen.STORE_KNOBS)).out)
+    cache, _ = H.oracle_trunk(params, fwd.x_emb)
+    for l in range(8):
+        cache["h%d" % (l + 1)] = fwd.stored(l)
+    cache["final"] = fwd.stored(8)
+    g_out = np.random.RandomState(1).standard_normal((256, 4)).astype(np.float32)
+    gy = {}
+    O.nerf_backward(params, cache, g_out, gy_out=gy, operand_round=O.bf16_round)
+    run = H.ChainRun(params, fwd.acts, gy["dir"].astype(np.float32), g_out[:, 3]).run(genc.gen(dict(genc.KNOBS)).out)
+    raw = run.G.view(np.uint16).reshape(10, H.SLOT_ROWS, 256)
+    names = {8: "final", **{l: "l%d" % (l + 1) for l in range(8)}}
+    for slot in range(9):
+        assert not (raw[slot] == 0xEEEE).any(), slot
+        got, want = run.stored(slot), O.bf16_round(gy[names[slot]].astype(np.float32))
+        bad = got != want
+        assert bad.mean() <= 1e-2, (slot, bad.mean())                         # bf16-ulp flips + a few exact-zero mask cases
+        assert np.abs(got - want).max() <= 2.0 ** -6 * np.abs(want).max(), slot
+    for kind in ("ds_read_b128", "ds_write_b128"):
+        n, cyc, mn = run.wg.lds.stats[kind]
+        assert cyc == 4 * n, kind
+    assert run.wg.n_store_bytes == 4 * 9 * 64 * 512

@@ -255,7 +255,7 @@ class Wave:
         if op == "s_barrier":
             return "barrier"
         # ---- SALU
-        if op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_mov_b32", "s_and_b32", "s_lshl_b32", "s_mul_i32"):
+        if op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_subb_u32", "s_mov_b32", "s_and_b32", "s_lshl_b32", "s_mul_i32"):
             d = _parse_reg(args[0])
             srcs = [self.rds(_parse_reg(a)) for a in args[1:]]
             if op == "s_add_u32":
@@ -264,6 +264,8 @@ class Wave:
                 r = srcs[0] + srcs[1] + self.scc; self.scc = int(r > 0xFFFFFFFF)
             elif op == "s_sub_u32":
                 r = srcs[0] - srcs[1]; self.scc = int(r < 0)
+            elif op == "s_subb_u32":
+                r = srcs[0] - srcs[1] - self.scc; self.scc = int(r < 0)
             elif op == "s_mov_b32":
                 r = srcs[0]
             elif op == "s_and_b32":
@@ -277,8 +279,9 @@ class Wave:
         # ---- MFMA
         if op == "v_mfma_f32_32x32x16_bf16":
             d, a_, b_, c_ = (_parse_reg(x) for x in args)
-            assert d[2] == 16 and a_[2] == 4 and b_[2] == 4 and c_[2] == 16, text
-            A = self.rd(a_); B = self.rd(b_); C = f32(self.rd(c_)).copy()
+            assert d[2] == 16 and a_[2] == 4 and b_[2] == 4 and (c_[2] == 16 or c_ == ("lit", 0, 0)), text
+            A = self.rd(a_); B = self.rd(b_)
+            C = f32(self.rd(c_)).copy() if c_[0] != "lit" else np.zeros((16, 64), np.float32)
             unpack = lambda R: np.stack([bf16_to_f32(R[q] & 0xFFFF) if e == 0 else bf16_to_f32(R[q] >> 16) for q in range(4) for e in (0, 1)], 0)  # (8, 64)
             Ae, Be = unpack(A), unpack(B)
             Am = np.zeros((32, 16), np.float32); Bm = np.zeros((16, 32), np.float32)

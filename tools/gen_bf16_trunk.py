@@ -48,7 +48,13 @@ KNOBS = dict(prefetch=4,        # A-fragment prefetch distance in k-steps (ring 
                                 # shorter rotation does not name go back to the compiler, see the clobber list)
              store=0,           # 1 = TRAINING forward (sn_mlp_fwd_bf16_t.hip): every output tile is also written to acts[] as bf16
                                 # (whole 128-byte rows, non-temporal) together with the ReLU sign words -- see STORE MODE below
-             swap_rev=0)        # store mode: operand order of v_permlane32_swap_b32 (probed on the device: tools/ubench/permlane_probe.hip)
+             swap_rev=0,        # store mode: operand order of v_permlane32_swap_b32 (0 = vdst lanes 32..63 <-> src lanes 0..31, confirmed by
+                                # the bit-identity test against the compiler-scheduled kernel on the device)
+             nt=1,              # store mode: non-temporal hint on the row stores
+             dma_early=0,       # 1: a slab's DMA pieces in consecutive gaps right behind the sync point (in FRONT of the slab's row stores)
+             spread=1,          # store mode: row stores dealt into the next tile's epilogue (0: burst behind the odd tile)
+             abl_vstore=1, abl_stage=1, abl_sign=1)   # store mode timing ablations (0 = leave out: WRONG results): the global stores, the
+                                # staging round trip (swaps + LDS writes / reads + stores), the sign-word arithmetic
 
 STORE_KNOBS = dict(store=1, cap=6.0)            # the build of sn_mlp_fwd_bf16_t.hip (csrc/Makefile passes the same)
 V_FIRST = 128                                  # first physical VGPR the statement owns (clobbers v[V_FIRST:255])
@@ -208,14 +214,31 @@ class Gen:
         self.stats["wait"] += 1
         del self.lgkm[:pos + 1]
 
+    def wait_vm(self, tag):
+        """counted wait on the vector-memory queue (retires in issue order): the operation carrying `tag` has completed.  The count
+        field has 6 bits: a target with more than 63 younger operations is covered by vmcnt(63) (at most the 63 youngest remain)."""
+        if tag not in self.vm:
+            return
+        pos = max(i for i, t in enumerate(self.vm) if t == tag)
+        self.emit("s_waitcnt vmcnt(%d)" % min(63, len(self.vm) - 1 - pos))
+        self.stats["wait"] += 1
+        del self.vm[:pos + 1]
+
     def run_filler(self, f):
         k = f.kind
         if k == "ds_read":
             self.emit(f.text)
             self.lgkm.append(f.tag)
+        elif k == "vload":                               # global load into registers of the statement (waited for with wait_vm)
+            self.pad_salu_to_vmem(f.reads)
+            self.emit(f.text)
+            self.vm.append(f.tag)
         elif k == "valu":
-            if f.tag is not None:                        # needs LDS data (sigma weights)
-                self.wait_lgkm({f.tag})
+            if f.tag is not None:                        # needs LDS data (sigma weights) / a loaded register (("vm", tag))
+                if f.tag[0] == "vm":
+                    self.wait_vm(f.tag[1])
+                else:
+                    self.wait_lgkm({f.tag})
             self.emit(f.text, writes=f.writes, valu=True)
         elif k == "ds_write":
             self.emit(f.text)
@@ -252,7 +275,7 @@ class Gen:
             nxt = f.tag
             pos = -1
             for i, t in enumerate(self.vm):
-                if t <= nxt:
+                if isinstance(t, int) and t <= nxt:
                     pos = i
             if pos >= 0:
                 self.emit("s_waitcnt vmcnt(%d)" % (len(self.vm) - 1 - pos))
@@ -383,15 +406,16 @@ def gen(knobs):
                     items.append(("valu", "v_pk_max_i16 v%d, v%d, 0" % (t1, t1), (t1,), None, "acc"))
             items.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0, t0), (("a", r0),), None, "acc"))
             items.append(("valu", "v_accvgpr_write_b32 a%d, v%d" % (r0 + 1, t1), (("a", r0 + 1),), None, "acc"))
+        fin = []                                             # packed words -> staging planes (both point tiles), behind everything else
         def finish_pt(pt):
             pairs = [(PKR(pt, 0), PKR(pt, 2)), (PKR(pt, 1), PKR(pt, 3)), (PKR(pt, 4), PKR(pt, 6)), (PKR(pt, 5), PKR(pt, 7))]
             for x, y in pairs:
                 if K["swap_rev"]:
                     x, y = y, x
-                items.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (x, y), (x, y), None, "acc", (x, y)))
+                fin.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (x, y), (x, y), None, "acc", (x, y)))
             for e in range(2):
                 off = pt * ST_PT + (t & 1) * ST_B3 + e * ST_E
-                items.append(("ds_write", "ds_write_b128 %%[stw], v[%d:%d] offset:%d" % (PKR(pt, 4 * e), PKR(pt, 4 * e) + 3, off), (), None, "acc"))
+                fin.append(("ds_write", "ds_write_b128 %%[stw], v[%d:%d] offset:%d" % (PKR(pt, 4 * e), PKR(pt, 4 * e) + 3, off), (), None, "acc"))
         if sigma:                                            # q outermost, both point tiles share a quad's sigma weights
             sig_load(0); sig_load(1)
             for i in range(4):
@@ -399,17 +423,18 @@ def gen(knobs):
                     block(pt, i)
                 if i + 2 < 4:
                     sig_load(i + 2)
-            finish_pt(0); finish_pt(1)
         else:                                                # point tile outermost: the sign-word step order of the chain
             for pt in range(2):
                 for i in range(4):
                     block(pt, i)
-                finish_pt(pt)
+        finish_pt(0); finish_pt(1)
         if not copy:                                         # the tile's ReLU sign word: 256 contiguous bytes per wave
             items.append(("vstore", "global_store_dword v%d, v%d, s[%d:%d] nt" % (ST_VSG, ST_SB, ST_SGPR_SIGN, ST_SGPR_SIGN + 1), (), None, "post",
                           (ST_SGPR_SIGN, ST_SGPR_SIGN + 1)))
             items.append(("valu", "v_add_u32 v%d, 512, v%d" % (ST_VSG, ST_VSG), (ST_VSG,), None, "post"))
+        readout = []
         if t & 1:                                            # tiles t-1, t of both point tiles leave as whole 128-byte rows
+            main_items, items = items, readout
             tp = t >> 1
             rows = [(pt, i) for pt in range(2) for i in range(4)]
             def rd(n):
@@ -419,8 +444,11 @@ def gen(knobs):
                 items.append(("ds_read", "ds_read_b128 v[%d:%d], %s offset:%d" % (ro, ro + 3, src, pt * ST_PT + 256 * i), (), ("ro", s, n), "post"))
             def stw(n):
                 ro = ST_RO + 4 * (n % 2)
-                items.append(("vstore", "global_store_dwordx4 %%[vo], v[%d:%d], s[%d:%d] offset:%d nt" % (ro, ro + 3, ST_SGPR_ACTS, ST_SGPR_ACTS + 1, 128 * tp),
-                              (), ("ro", s, n), "post", (ST_SGPR_ACTS, ST_SGPR_ACTS + 1)))
+                if K["abl_vstore"]:
+                    items.append(("vstore", "global_store_dwordx4 %%[vo], v[%d:%d], s[%d:%d] offset:%d%s" % (ro, ro + 3, ST_SGPR_ACTS, ST_SGPR_ACTS + 1, 128 * tp, " nt" if K["nt"] else ""),
+                                  (), ("ro", s, n), "post", (ST_SGPR_ACTS, ST_SGPR_ACTS + 1)))
+                else:                                        # timing ablation: the staged row is still waited for, nothing leaves
+                    items.append(("valu", "s_nop 0", (), ("ro", s, n), "post"))
                 if n < 7:
                     items.append(("valu", "v_add_u32 %[vo], 4096, %[vo]", ("vo",), None, "post"))
                 else:
@@ -433,7 +461,35 @@ def gen(knobs):
             if t == 7:                                       # next layer: acts[L + 1]
                 items.append(("salu", "s_add_u32 s%d, s%d, %%[srlo]" % (ST_SGPR_ACTS, ST_SGPR_ACTS), (ST_SGPR_ACTS,), None, "post"))
                 items.append(("salu", "s_addc_u32 s%d, s%d, %%[srhi]" % (ST_SGPR_ACTS + 1, ST_SGPR_ACTS + 1), (ST_SGPR_ACTS + 1,), None, "post"))
-        return items
+            items = main_items
+        if not K["abl_stage"]:
+            fin, readout = [], []
+        if not K["abl_sign"]:
+            items = [it for it in items if ("v%d" % ST_SB) not in it[1]]
+        return items, fin, readout
+
+    def interleave(a, b):
+        """deal list b evenly into list a (both keep their own order)"""
+        if not b:
+            return list(a)
+        out, j = [], 0
+        for i, x in enumerate(a):
+            out.append(x)
+            while j < len(b) and (j + 1) * len(a) <= (i + 1) * len(b):
+                out.append(b[j]); j += 1
+        return out + b[j:]
+
+    def store_flat(s):
+        """epilogue stream of slab s in store mode.  The row stores of a finished tile PAIR are not issued as a burst behind the odd
+        tile's epilogue: they are dealt evenly into the NEXT (even) tile's epilogue, in front of its staging writes (which re-use
+        the planes) -- one store per ~4 MFMAs instead of eight within a few gaps.  A wave whose store cannot issue (the CU's address
+        path is full) cannot issue its MFMAs either: without the staging round trip the kernel ran 0.51 ms, with it 0.72."""
+        items, fin, readout = store_epilogue(s)
+        prev = store_epilogue(s - 1)[2] if (s > 0 and K["spread"]) else []
+        out = interleave(items, prev) + fin
+        if not K["spread"] or s == N_SLABS_TRUNK - 1:
+            out += readout                                   # (the last pair of the trunk: behind the backbone)
+        return out
 
     def plain_epilogue(s):
         L, t = layer_of(s), s % 8
@@ -494,7 +550,7 @@ def gen(knobs):
             post_dl = first[s + 3] - 1 if s + 3 < N_SLABS_TRUNK else len(mf) - 1
         else:
             rel0 = None
-        flat = store_epilogue(s) if STORE else plain_epilogue(s)
+        flat = store_flat(s) if STORE else plain_epilogue(s)
         if rel0 is None:
             epi_tail = flat
             continue
@@ -544,6 +600,8 @@ def gen(knobs):
             n_g = first[s + 1] - first[s]
             gaps_avail = max(1, n_g - K["bar_gap"] - 3)
             stride = max(1, gaps_avail // max(1, len(plist)))
+            if K["dma_early"]:
+                stride = 1
             for p, (lds_off, bump, tag) in enumerate(plist):
                 rel = b + 1 + p * stride
                 dl = first[s + 1] - 1
@@ -654,6 +712,35 @@ def gen(knobs):
     if K["setprio"]:
         g.emit("s_setprio 0")
     return g
+
+
+def write_inc(out_path, g, prefix, header):
+    """the emitted stream as a C string macro <prefix>_ASM + the clobber list <prefix>_CLOBBERS (every physical register the text
+    names, and the whole AGPR file)"""
+    import re
+    n_other = len(g.out) - g.mfma_count
+    with open(out_path, "w") as f:
+        f.write("// GENERATED by %s -- do not edit.\n" % header)
+        f.write("// %d MFMAs, %d other instructions (%.2f per MFMA): %d s_nop, %d counted waits\n"
+                % (g.mfma_count, n_other, n_other / g.mfma_count, g.stats["nop"], g.stats["wait"]))
+        f.write("#define %s_ASM \\\n" % prefix)
+        for line in g.out:
+            f.write('  "%s\\n\\t" \\\n' % line)
+        f.write('  ""\n')
+        used, sused = set(), set()
+        for line in g.out:
+            for m in re.finditer(r"\bv\[(\d+):(\d+)\]", line):
+                used.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            for m in re.finditer(r"\bv(\d+)\b", line):
+                used.add(int(m.group(1)))
+            for m in re.finditer(r"\bs\[(\d+):(\d+)\]", line):
+                sused.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            for m in re.finditer(r"\bs(\d+)\b", line):
+                sused.add(int(m.group(1)))
+        assert used and min(used) >= V_FIRST, "the statement only names registers of its own range"
+        f.write("#define %s_CLOBBERS " % prefix + ", ".join('"v%d"' % r for r in sorted(used)) + ", "
+                + "".join('"s%d", ' % r for r in sorted(sused))
+                + ", ".join('"a%d"' % r for r in range(256)) + ', "memory", "scc"\n')
 
 
 def main():
