@@ -17,9 +17,12 @@ Per output tile (slab s, tile t of a layer) the deferred epilogue, run inside sl
   * the masked pairs ARE the pre-activation gradients g_y the weight-gradient kernels read: four v_permlane32_swap_b32, two
     conflict-free ds_write_b128 into the wave's staging planes, every second tile eight ds_read_b128 + global_store_dwordx4 of
     whole 128-byte rows of G[slot] (non-temporal).
-Sign words: one dword per lane and tile, loaded ONE LAYER AHEAD into a 16-register file (v[240:255]): the counted vmcnt wait in
-front of a tile's mask arithmetic then only ever asks for operations more than eight slabs old (the compiler-scheduled kernel
-loaded each word one slab ahead and drained the row stores behind it: waves parked 45 % of the time).
+Sign words: one dword per lane and tile, ALL 64 of a point tile loaded at the top of the statement into a register file
+(v[64:127]) behind which the eight short dir_encoding^T slabs run before the first mask is needed.  Loads inside the slab loop --
+even a layer ahead of their use -- sit in the same issue-ordered vmcnt queue as the weight DMA: every barrier's counted wait for
+the next slab's pieces then also waits for the youngest sign-word load in front of them, an HBM read queued behind 4 TB/s of row
+stores (measured: the chain lost 0.23 ms to its stores, the forward -- no loads in its trunk -- 0.13; TCP->TCC write latency is
+only ~320 cycles, so it is not the stores themselves that hold the queue).
 
 Weight ring: 4 slots of 16 KB (the widest transposed slab), slab s in slot s % 4 (72 = 0 mod 4: static), staged 3 slabs ahead,
 slabs 69..71 stage the next point tile's slabs 0..2 (the stream wraps).  No bias: the first k-step of a slab takes C = 0.
@@ -27,7 +30,7 @@ slabs 69..71 stage the next point tile's slabs 0..2 (the stream wraps).  No bias
 Register plan inside the statement (v[128:255] declared as clobbers where named):
   v[128:191] accumulators [set][point tile][16]      v[192:199] two 4-register rows in flight (staging read -> global store)
   v[200:207] sigma^T weights (2 x 4, double-buffered)  v[208:231] A-fragment ring (6 entries)
-  v232/v233 mask temporaries   v234 sign-load offset   v235 odd-row staging read address   v[240:255] sign-word file [layer parity][tile]
+  v232/v233 mask temporaries   v234 sign-load offset   v235 odd-row staging read address   v[64:127] sign-word file [acts slot][tile]
   s[84:85] running pointer into G[slot] (- slot_rows * 512 B per layer), s[86:87] pointer to the sign-word rows
 
 usage: gen_bf16_chain.py out.inc [knob=value ...]
@@ -43,7 +46,7 @@ KNOBS = dict(prefetch=4, cap=6.0, dma_cost=2.0, valu_cost=1.0, lds_cost=1.0, sal
 
 N_SLABS = 72
 N_SLOTS, SLOT_BYTES, DMA_DIST = 4, 16384, 3
-RO, SIGT, M0, VSG, STR1, SWF = 192, 200, 232, 234, 235, 240
+RO, SIGT, M0, VSG, STR1, SWF = 192, 200, 232, 234, 235, 64
 SGPR_G, SGPR_SIGN = 84, 86
 ACC, RING0, act_reg = T.ACC, T.RING0, T.act_reg
 ST_PT, ST_B3, ST_E = T.ST_PT, T.ST_B3, T.ST_E
@@ -55,6 +58,7 @@ def slab_bytes(s): return nk_of(s) * 1024
 def read_set(L): return 0 if L == 0 else 1 if L == 1 else (0 if (9 - L) & 1 else 1)
 def write_set(L): return 1 - read_set(L)
 def out_slot(L): return 8 if L == 0 else 7 if L == 1 else 8 - L       # G slot the layer writes = acts slot of its ReLU mask
+T_out_slot = out_slot
 TOTAL_BYTES = sum(slab_bytes(s) for s in range(N_SLABS))
 
 
@@ -103,19 +107,8 @@ def gen(knobs):
         add(T.Filler("ds_read_b128 v[%d:%d], %%[va0] offset:%d" % (ring(kidx), ring(kidx) + 3, frag_addr(s, ks)), K["lds_cost"], rel,
                      use - 1, "ds_read", tag=("frag", kidx)))
 
-    # ---- sign words: (layer L >= 1, tile t) -> v[SWF + 8 (L & 1) + t], loaded during slab (L - 1, t) = one layer ahead
-    swreg = lambda L, t: SWF + 8 * (L & 1) + t
-    if K["abl_mask"]:
-        for s in range(N_SLABS - 8):
-            L, t = layer_of(s) + 1, s % 8                  # the word of the NEXT layer's tile t
-            rel = first[s] + K["bar_gap"] + 1
-            dl = first[s + 1] - 1
-            add(T.Filler("global_load_dword v%d, v%d, s[%d:%d] nt" % (swreg(L, t), VSG, SGPR_SIGN, SGPR_SIGN + 1), K["dma_cost"], rel, dl,
-                         "vload", reads=(SGPR_SIGN, SGPR_SIGN + 1), writes=(swreg(L, t),), tag=("sw", L, t)))
-            # rows of a layer's 8 tiles ascend; the next layer's (slot - 1) sit 8 rows lower: +1 row, or -15 after tile 7
-            txt = "v_add_u32 v%d, 512, v%d" % (VSG, VSG) if t < 7 else "v_subrev_u32 v%d, %d, v%d" % (VSG, 15 * 512, VSG)
-            add(T.Filler(txt, K["valu_cost"], rel, dl, "valu", writes=(VSG,)))
-
+    # ---- sign words: the word of (chain layer L >= 1, tile t) = acts slot 8 - L ... v[SWF + 8 slot + t], loaded in the preamble
+    swreg = lambda L, t: SWF + 8 * T_out_slot(L) + t
     # ---- epilogue of slab s (run inside slab s+1)
     def epilogue(s):
         L, t = layer_of(s), s % 8
@@ -140,7 +133,7 @@ def gen(knobs):
             if not copy and K["abl_mask"]:
                 j0 = (4 * i + 2 * pt) if sig else (8 * pt + 2 * i)
                 sw = swreg(L, t)
-                items.append(("valu", "v_lshrrev_b32 v%d, %d, v%d" % (M0, j0, sw), (M0,), ("vm", ("sw", L, t)), "acc"))
+                items.append(("valu", "v_lshrrev_b32 v%d, %d, v%d" % (M0, j0, sw), (M0,), ("vm", ("sw", out_slot(L), t)), "acc"))
                 items.append(("valu", "v_lshrrev_b32 v%d, %d, v%d" % (M0 + 1, j0 + 1, sw), (M0 + 1,), None, "acc"))
                 items.append(("valu", "v_and_b32 v%d, %%[c01], v%d" % (M0, M0), (M0,), None, "acc"))
                 items.append(("valu", "v_and_b32 v%d, %%[c01], v%d" % (M0 + 1, M0 + 1), (M0 + 1,), None, "acc"))
@@ -286,7 +279,14 @@ def gen(knobs):
         g.last_salu_write[dst] = g.n_states - 1
     g.emit("v_xor_b32 v%d, 16, %%[str0]" % STR1)
     g.emit("v_lshrrev_b32 v%d, 2, %%[va0]" % VSG)
-    g.emit("v_add_u32 v%d, %d, v%d" % (VSG, 56 * 512, VSG))                     # sign words of slot 7 first: rows p_wave + 56 + t
+    if K["abl_mask"]:
+        g.nop(4)                                                                  # SALU write of the sign pointer -> VMEM address
+        for slot in range(8):                                                    # rows p_wave + 8 slot + t, 512 B each
+            for t in range(8):
+                g.emit("global_load_dword v%d, v%d, s[%d:%d] offset:%d nt" % (SWF + 8 * slot + t, VSG, SGPR_SIGN, SGPR_SIGN + 1, 512 * t))
+                g.vm.append(("sw", slot, t))
+            if slot < 7:
+                g.emit("v_add_u32 v%d, 4096, v%d" % (VSG, VSG))
     for kidx in range(D):
         s, ks = kstep_list[kidx]
         g.emit("ds_read_b128 v[%d:%d], %%[va0] offset:%d" % (ring(kidx), ring(kidx) + 3, frag_addr(s, ks))); g.lgkm.append(("frag", kidx))
@@ -348,7 +348,7 @@ def main():
         k, v = kv.split("=")
         knobs[k] = float(v) if isinstance(KNOBS[k], float) else int(v)
     g = gen(knobs)
-    T.write_inc(out_path, g, "SN_BF16_CHAIN", "tools/gen_bf16_chain.py " + " ".join(sys.argv[2:]))
+    T.write_inc(out_path, g, "SN_BF16_CHAIN", "tools/gen_bf16_chain.py " + " ".join(sys.argv[2:]), v_first=64)
     n_other = len(g.out) - g.mfma_count
     print("chain: %d MFMAs, %d other (%.2f / MFMA), nops %d, waits %d, forced %d"
           % (g.mfma_count, n_other, n_other / g.mfma_count, g.stats["nop"], g.stats["wait"], g.stats["forced"]))

@@ -278,7 +278,7 @@ class Gen:
                 if isinstance(t, int) and t <= nxt:
                     pos = i
             if pos >= 0:
-                self.emit("s_waitcnt vmcnt(%d)" % (len(self.vm) - 1 - pos))
+                self.emit("s_waitcnt vmcnt(%d)" % min(63, len(self.vm) - 1 - pos))   # (6-bit field: a larger count only waits for more)
                 del self.vm[:pos + 1]
             self.emit("s_barrier")
         else:
@@ -714,7 +714,7 @@ def gen(knobs):
     return g
 
 
-def write_inc(out_path, g, prefix, header):
+def write_inc(out_path, g, prefix, header, v_first=V_FIRST):
     """the emitted stream as a C string macro <prefix>_ASM + the clobber list <prefix>_CLOBBERS (every physical register the text
     names, and the whole AGPR file)"""
     import re
@@ -737,7 +737,7 @@ def write_inc(out_path, g, prefix, header):
                 sused.update(range(int(m.group(1)), int(m.group(2)) + 1))
             for m in re.finditer(r"\bs(\d+)\b", line):
                 sused.add(int(m.group(1)))
-        assert used and min(used) >= V_FIRST, "the statement only names registers of its own range"
+        assert used and min(used) >= v_first, "the statement only names registers of its own range"
         f.write("#define %s_CLOBBERS " % prefix + ", ".join('"v%d"' % r for r in sorted(used)) + ", "
                 + "".join('"s%d", ' % r for r in sorted(sused))
                 + ", ".join('"a%d"' % r for r in range(256)) + ', "memory", "scc"\n')
