@@ -170,3 +170,50 @@ def test_generated_instruction_streams_are_well_formed(tmp_path):
         sys.argv = argv
     text = out.read_text()
     assert text.count("v_mfma_f32_32x32x16_bf16") == 2176                       # 72 slabs of a wave's two point tiles
+
+
+def test_training_streams_are_deterministic_and_complete():
+    """tools/gen_bf16_trunk.py store=1 and tools/gen_bf16_chain.py (the training forward / backward chain statements): deterministic
+    output, all 2176 MFMAs of a wave's two point tiles, every row of state leaves through exactly one global_store_dwordx4, every
+    LDS-DMA destination is set one instruction ahead of its use, counted waits stay inside their fields, and the inference trunk's
+    text did not change under the store-mode additions."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        import sys
+        sys.path.insert(0, os.path.join(root, "tools"))
+        spec.loader.exec_module(mod)
+        return mod
+
+    T, C = load("gen_bf16_trunk"), load("gen_bf16_chain")
+    fwd = T.gen(dict(T.KNOBS, **T.STORE_KNOBS)).out
+    assert fwd == T.gen(dict(T.KNOBS, **T.STORE_KNOBS)).out
+    chain = C.gen(dict(C.KNOBS)).out
+    assert chain == C.gen(dict(C.KNOBS)).out
+    for body, n_sign_st, n_sign_ld in ((fwd, 64, 0), (chain, 0, 64)):
+        assert sum(l.startswith("v_mfma_f32_32x32x16_bf16") for l in body) == 2176
+        assert sum(l.startswith("global_store_dwordx4") for l in body) == 9 * 4 * 8          # 9 layers x 4 tile pairs x 8 row groups
+        assert sum(l.startswith("global_store_dword ") for l in body) == n_sign_st
+        assert sum(l.startswith("global_load_dword ") for l in body) == n_sign_ld
+        assert sum(l.startswith("v_permlane32_swap_b32") for l in body) == 72 * 8
+        assert sum(l.startswith("ds_write_b128") for l in body) == 72 * 4
+        for i, l in enumerate(body):
+            if l.startswith("global_load_lds"):
+                prev = [k for k in range(i) if body[k].startswith("s_add_u32 m0")]
+                assert prev and i - prev[-1] >= 2, (i, l)
+            m = re.match(r"s_waitcnt (lgkmcnt|vmcnt)\((\d+)\)", l)
+            if m:
+                assert int(m.group(2)) <= (15 if m.group(1) == "lgkmcnt" else 63), l
+    # the statements stay inside the registers they declare: v128.. (forward), v64.. (chain: the sign-word file)
+    for body, lo in ((fwd, 128), (chain, 64)):
+        regs = set()
+        for l in body:
+            regs |= {int(x) for x in re.findall(r"\bv(\d+)\b", l)}
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", l):
+                regs |= set(range(int(a), int(b) + 1))
+        assert min(regs) >= lo, min(regs)
