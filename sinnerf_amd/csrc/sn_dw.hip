@@ -106,8 +106,12 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   // Ring depth: as many chunks as the 128 KB of LDS hold, at most 16 (fp32 256x256: 4 x 32 KB as before; bf16 state: 8 x 16 KB;
   // the narrow problems 16 x 5..9 KB).  One CU streams (NBUF-1) chunks per HBM latency: with the bf16 tiles at depth 4 the
   // narrow problems ran at 8 GB/s per CU (15 KB in flight), latency-bound far below their share of the HBM rate.
-  constexpr int NBUF = (LDSB / BUF >= 16) ? 16 : (LDSB / BUF >= 8) ? 8 : 4;
-  static_assert(NBUF * BUF <= LDSB, "ring fits the LDS allocation");
+  // (round 3: the depth is no longer rounded down to a power of two -- a 12 KB chunk in 64 KB of LDS got a 4-deep ring, 36 KB in
+  //  flight per workgroup, and the narrow bf16-state problems ran latency-bound at 4.7 TB/s; slots are tracked by running indices)
+  constexpr int NFIT = LDSB / BUF >= 16 ? 16 : LDSB / BUF;
+  constexpr int SY0 = (BF16 && NFIT >= 8) ? (NFIT >= 16 ? 4 : 2) : 1;
+  constexpr int NBUF = NFIT / SY0 * SY0;
+  static_assert(NBUF >= 4 && NBUF * BUF <= LDSB, "ring fits the LDS allocation");
   // DMA instructions per thread per chunk.  A 32-wide A tile (variants 4/5) is only 128 16-byte pieces: waves 2,3 issue
   // none of it, so their vmcnt budget is one instruction per chunk smaller (the wait must be exact per wave).
   constexpr int CH_A = KB * WA * EA / 16, CH_B = KB * WB * EB / 16;
@@ -139,7 +143,8 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   // bf16 modes with a deep ring meet at the barrier every SY-th chunk only (SY chunks are waited for and SY slots restaged per
   // sync point): at 16 points per chunk the fixed cost of a sync point (counted wait, barrier skew between the four waves) is
   // as long as the chunk's share of the HBM stream
-  constexpr int SY = (BF16 && NBUF >= 8) ? NBUF / 4 : 1;      // ring of 8: every 2nd chunk, ring of 16 (narrow problems): every 4th
+  constexpr int SY = SY0;                                     // ring of 8..15: every 2nd chunk, ring of 16 (narrow problems): every 4th
+  static_assert(NBUF % SY == 0 && NBUF >= 2 * SY, "sync period divides the ring");
   // prologue: NBUF-SY chunks in flight (chunks past the end are staged as clamped copies and never consumed)
 #pragma unroll
   for (int c = 0; c < NBUF - SY; ++c) {
@@ -166,8 +171,9 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
       }
     }
     const bool want_bias = t.bias != nullptr && wc == 0;
-    for (int c = 0; c <= n_chunks; ++c) {
-      char* bc = smem + (c % NBUF) * BUF;
+    int slot_c = 0;                                  // = c % NBUF (NBUF need not be a power of two)
+    for (int c = 0; c <= n_chunks; ++c, slot_c = (slot_c + 1 == NBUF) ? 0 : slot_c + 1) {
+      char* bc = smem + slot_c * BUF;
       if (c < n_chunks && c % SY == 0) {
         // sync point, every SY-th chunk: chunks c .. c+SY-1 have landed for every wave (the NBUF-2*SY younger ones may still be
         // in flight), chunks c-SY .. c-1 are fully gathered -> their slots are restaged with chunks c+NBUF-SY .. c+NBUF-1
@@ -178,7 +184,8 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int u = 0; u < SY; ++u) {
-          char* bn = smem + ((c + NBUF - SY + u) % NBUF) * BUF;
+          const int sn = slot_c + NBUF - SY + u;     // < 2 NBUF
+          char* bn = smem + (sn >= NBUF ? sn - NBUF : sn) * BUF;
           sa.stage(t.a, t.lda, k + (long)(NBUF - SY + u) * KB, k1, bn, tid);
           sb.stage(t.b, t.ldb, k + (long)(NBUF - SY + u) * KB, k1, bn + A_BYTES, tid);
         }
@@ -252,19 +259,20 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
       }
     }
   } else {
-    for (int c = 0; c < n_chunks; ++c) {
+    int slot_c = 0;                                  // = c % NBUF
+    for (int c = 0; c < n_chunks; ++c, slot_c = (slot_c + 1 == NBUF) ? 0 : slot_c + 1) {
       const long k = k0 + (long)c * KB;
       // chunk c was issued NBUF-1 chunks ago: everything but the (NBUF-2) younger chunks must have landed
       if (PART_A != 0 && wave >= PART_A) wait_vmcnt<(NBUF - 2) * (IT_A - 1 + IT_B)>();
       else wait_vmcnt<(NBUF - 2) * (IT_A + IT_B)>();
       __builtin_amdgcn_s_barrier();               // all waves' pieces of chunk c landed; chunk c-1 fully consumed
       {
-        const int slot = (c + NBUF - 1) % NBUF;   // = slot of chunk c-1
+        const int slot = slot_c == 0 ? NBUF - 1 : slot_c - 1;   // = slot of chunk c-1
         char* bn = smem + slot * BUF;
         sa.stage(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, bn, tid);
         sb.stage(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, bn + A_BYTES, tid);
       }
-      char* bc = smem + (c % NBUF) * BUF;
+      char* bc = smem + slot_c * BUF;
       const float* la = reinterpret_cast<const float*>(bc) + h * WA + m0 + i;
       const float* lb = reinterpret_cast<const float*>(bc + A_BYTES) + h * WB + n0 + i;
       // (measured and rejected: requesting the fragments of pair s+1 ahead of the MFMAs of pair s behind scheduling fences --
@@ -340,7 +348,10 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks,
 
 // The narrow problems of the bf16-state mode in a kernel of their own: half the LDS and at most 256 registers per wave, so that
 // TWO workgroups share a CU -- these problems are latency-bound (few MFMAs per chunk), a second set of waves fills the stalls.
-constexpr int DW_NARROW_LDS_BYTES = 65536;
+#ifndef SN_DW_NARROW_LDS
+#define SN_DW_NARROW_LDS 81920                      // two workgroups share the CU's 160 KB (timing builds: 65536, 73728)
+#endif
+constexpr int DW_NARROW_LDS_BYTES = SN_DW_NARROW_LDS;
 __global__ void __launch_bounds__(256, 2) dw_narrow_bf16_kernel(const Plan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Task t = task_of(plan, (int)blockIdx.x);
@@ -376,8 +387,19 @@ __global__ void __launch_bounds__(256) dw_finish_kernel(const Segs segs) {
   const int l = e - g.first;
   const int r = l / g.cols, c = l - r * g.cols;
   const float* src = g.src + (long)(g.src_row0 + r) * g.src_ld + g.src_col0 + c;
+  // fixed summation order (run-to-run deterministic), but the loads of eight partials are issued together: as a dependent chain
+  // of ns ~ 32 strided loads per thread the kernel ran at 1.5 TB/s (50 us per network, 2.5 % of a bf16 training step)
   float acc = 0.0f;
-  for (int j = 0; j < g.ns; ++j) acc += src[(long)j * g.stride];       // fixed order: run-to-run deterministic
+  const long st = g.stride;
+  int j = 0;
+  for (; j + 8 <= g.ns; j += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (long)(j + u) * st);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; j < g.ns; ++j) acc += src[(long)j * st];
   float* d = g.dst + (long)r * g.dst_ld + g.dst_col0 + c;
   *d = segs.accumulate ? *d + acc : acc;
 }
