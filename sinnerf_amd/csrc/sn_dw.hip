@@ -111,7 +111,7 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   constexpr int NFIT = LDSB / BUF >= 16 ? 16 : LDSB / BUF;
   constexpr int SY0 = (BF16 && NFIT >= 8) ? (NFIT >= 16 ? 4 : 2) : 1;
   constexpr int NBUF = NFIT / SY0 * SY0;
-  static_assert(NBUF >= 4 && NBUF * BUF <= LDSB, "ring fits the LDS allocation");
+  static_assert(NBUF >= 3 && NBUF * BUF <= LDSB, "ring fits the LDS allocation");
   // DMA instructions per thread per chunk.  A 32-wide A tile (variants 4/5) is only 128 16-byte pieces: waves 2,3 issue
   // none of it, so their vmcnt budget is one instruction per chunk smaller (the wait must be exact per wave).
   constexpr int CH_A = KB * WA * EA / 16, CH_B = KB * WB * EB / 16;
@@ -365,6 +365,24 @@ __global__ void __launch_bounds__(256, 2) dw_narrow_bf16_kernel(const Plan plan)
   }
 }
 
+// ... and the narrow problems of the fp32 step the same way (round 3): their compiler-scheduled loop leaves the MFMA pipe 67 % busy
+// with the waves parked 21 % of the time; none of the narrow variants needs more than 128 accumulator registers.
+#ifndef SN_DW_NARROW_F32_2WG
+#define SN_DW_NARROW_F32_2WG 1
+#endif
+__global__ void __launch_bounds__(256, 2) dw_narrow_f32_kernel(const Plan plan) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Task t = task_of(plan, (int)blockIdx.x);
+  const int tid = threadIdx.x;
+  switch (t.variant & 0xff) {
+    case 1: run_task<4, 1, 2, 2, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    case 2: run_task<2, 4, 2, 2, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    case 3: run_task<2, 1, 2, 2, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    case 4: run_task<1, 2, 1, 4, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    default: run_task<1, 1, 1, 4, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+  }
+}
+
 // ---- finish: deterministic sum of the K-split partials, written straight into the parameter-shaped gradients -------------
 struct Seg {                                    // dst[r][dst_col0 + c] (+)= sum_j src[j*stride + (src_row0 + r)*src_ld + src_col0 + c]
   float* dst;
@@ -479,7 +497,7 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
     for (int i = 0; i < n; ++i) if (group[i] == gsel) tot += cost[pr[i].var];
     if (tot == 0) continue;
     // (the bf16-state narrow problems run two workgroups per CU: dw_narrow_bf16_kernel)
-    const int target = (gsel == 1 && dtype == 2 && SN_DW_NARROW_2WG) ? 2 * TARGET_WGS : TARGET_WGS;
+    const int target = (gsel == 1 && ((dtype == 2 && SN_DW_NARROW_2WG) || (dtype == 0 && SN_DW_NARROW_F32_2WG))) ? 2 * TARGET_WGS : TARGET_WGS;
     double frac[MAX_PROBS];
     int sum = 0;
     for (int i = 0; i < n; ++i) {
@@ -555,6 +573,9 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
     if (dtype == 2 && SN_DW_NARROW_2WG) {
       SN_ENSURE_DYN_LDS(dw_narrow_bf16_kernel, DW_NARROW_LDS_BYTES);
       hipLaunchKernelGGL(dw_narrow_bf16_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_NARROW_LDS_BYTES, stream, pb);
+    } else if (dtype == 0 && SN_DW_NARROW_F32_2WG) {
+      SN_ENSURE_DYN_LDS(dw_narrow_f32_kernel, DW_NARROW_LDS_BYTES);
+      hipLaunchKernelGGL(dw_narrow_f32_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_NARROW_LDS_BYTES, stream, pb);
     } else {
       hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, pb);
     }
