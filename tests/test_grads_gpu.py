@@ -266,7 +266,8 @@ def test_bf16_forward_training_trajectory():
 
 
 def test_bf16_backward_chain_close_to_fp32_chain():
-    """sn_mlp_backward_chain with bf16 operands against the fp32 chain on the same stored activations: every slot of the
+    """REGRESSION test (HIP against HIP -- not parity evidence; the parity test of this path against the oracle is
+    test_bf16_mlp_backward_vs_bf16_emulated_oracle): sn_mlp_backward_chain with bf16 operands against the fp32 chain on the same stored activations: every slot of the
     pre-activation gradients G agrees to bf16 accuracy (relative Frobenius error < 2 %), pad rows are exact zeros and the
     head gradients g_out are identical (they are fp32 VALU work in both)."""
     import sinnerf_amd
@@ -341,7 +342,8 @@ def test_bf16_backward_chain_close_to_fp32_chain():
 
 
 def test_bf16_weight_gradient_launch_close_to_fp32():
-    """sn_dw_gemm with bf16 operands (variant | 0x100) against the fp32 launch on the same random matrices, every problem
+    """REGRESSION test (HIP against HIP -- not parity evidence; the weight-gradient entry is held to fp64 contractions in
+    test_weight_grads_entry_*): sn_dw_gemm with bf16 operands (variant | 0x100) against the fp32 launch on the same random matrices, every problem
     of a network including the narrow rgb / sigma ones: relative Frobenius error < 5e-3 (bf16 rounding of the operands,
     fp32 accumulation), bias gradients (fp32 column sums in both) within 1e-5."""
     from sinnerf_amd import _lib
