@@ -109,7 +109,10 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   // (round 3: the depth is no longer rounded down to a power of two -- a 12 KB chunk in 64 KB of LDS got a 4-deep ring, 36 KB in
   //  flight per workgroup, and the narrow bf16-state problems ran latency-bound at 4.7 TB/s; slots are tracked by running indices)
   constexpr int NFIT = LDSB / BUF >= 16 ? 16 : LDSB / BUF;
-  constexpr int SY0 = (BF16 && NFIT >= 8) ? (NFIT >= 16 ? 4 : 2) : 1;
+#ifndef SN_DW_SY_MIN
+#define SN_DW_SY_MIN 8                               // rings at least this deep meet every 2nd chunk only (timing builds: 6)
+#endif
+  constexpr int SY0 = (BF16 && NFIT >= SN_DW_SY_MIN) ? (NFIT >= 16 ? 4 : 2) : 1;
   constexpr int NBUF = NFIT / SY0 * SY0;
   static_assert(NBUF >= 3 && NBUF * BUF <= LDSB, "ring fits the LDS allocation");
   // DMA instructions per thread per chunk.  A 32-wide A tile (variants 4/5) is only 128 16-byte pieces: waves 2,3 issue
@@ -432,7 +435,10 @@ static const int COST_F32[6] = {512, 161, 260, 95, 101, 59};
 static const int COST_BF16[6] = {512, 189, 226, 126, 138, 125};          // bf16 operands, fp32 state
 // bf16 operands, bf16 state (transpose-read fragments, a sync point every 2nd / 4th chunk): the 256x256 problems run at their
 // share of the HBM rate (52 ns per point per CU = 1 KB / 19.7 GB/s), the narrower ones at 19..35 ns per point
-static const int COST_BF16_STATE[6] = {512, 343, 348, 226, 296, 190};
+#ifndef SN_DW_COST_STATE
+#define SN_DW_COST_STATE 512, 343, 348, 226, 296, 190
+#endif
+static const int COST_BF16_STATE[6] = {SN_DW_COST_STATE};
 constexpr int TARGET_WGS = 256;                 // one workgroup per CU
 
 struct HostPlan {
