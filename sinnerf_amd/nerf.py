@@ -72,19 +72,17 @@ class NeRF(nn.Module):
     """``NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False)``.
 
     Reference ``models/nerf.py:46-148``.  The HIP kernels implement the layer configuration both reference call sites
-    construct (``sinnerf.py:137,140``, ``eval.py:136-137``): D=8, W=256, 63/27 inputs, skips=[4]; other layer
-    configurations raise ``NotImplementedError`` at construction.  Both head variants of ``nerf.py:77-100`` are built:
-    ``use_new_activation=True`` (ShiftedSoftplus / WidenedSigmoid, what SinNeRF uses) and the constructor's default
+    construct (``sinnerf.py:137,140``, ``eval.py:136-137``): D=8, W=256, 63/27 inputs, skips=[4] (``self.fused``).  Any other
+    configuration the reference's constructor accepts is built too and runs the same op sequence as stock PyTorch-ROCm ops on
+    the device (``sinnerf_amd/generic.py``: eager speed, differentiable, fp32).  Both head variants of ``nerf.py:77-100`` are
+    built: ``use_new_activation=True`` (ShiftedSoftplus / WidenedSigmoid, what SinNeRF uses) and the constructor's default
     ``False`` (ReLU / Sigmoid).
     """
 
     def __init__(self, D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False,
                  compute_dtype="fp32"):
         super().__init__()
-        if (D, W, in_channels_xyz, in_channels_dir, list(skips)) != (8, 256, 63, 27, [4]):
-            raise NotImplementedError(
-                "sinnerf_amd.NeRF implements the SinNeRF layer configuration NeRF(D=8, W=256, 63, 27, skips=[4]) "
-                "(models/sinnerf.py:137,140)")
+        self.fused = (D, W, in_channels_xyz, in_channels_dir, list(skips)) == (8, 256, 63, 27, [4])
         self.use_new_activation = bool(use_new_activation)
         self.D, self.W = D, W
         self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
@@ -114,8 +112,14 @@ class NeRF(nn.Module):
         return code if self.use_new_activation else code | _lib.SN_DTYPE_CLASSIC_HEADS
 
     # ---- packed weights -------------------------------------------------------------------------------
+    def _need_fused(self):
+        if not self.fused:
+            raise NotImplementedError("the packed-weight kernels exist for NeRF(D=8, W=256, 63, 27, skips=[4]) only; this "
+                                      "configuration runs through sinnerf_amd.generic")
+
     def raw_tensors(self):
         """The 24 parameter tensors in the order of ``include/sinnerf_hip.h`` (= state_dict order)."""
+        self._need_fused()
         out = []
         for i in range(self.D):
             lin = getattr(self, f"xyz_encoding_{i+1}")[0]
@@ -129,6 +133,8 @@ class NeRF(nn.Module):
         return (self._pack_generation,) + tuple((t.data_ptr(), t._version) for t in raws)
 
     def invalidate_packed(self):
+        if not getattr(self, "fused", True):
+            return
         """Mark the MFMA-packed weight blobs stale.  ``packed()`` notices in-place updates of the parameters through
         ``Parameter._version`` (optimizer steps, ``load_state_dict``, ``p.mul_()`` under ``no_grad``) and replaced storage
         through ``data_ptr``; a write THROUGH ``p.data`` (``dist.broadcast(p.data)``, ``p.data.copy_()``, EMA / clipping code,
@@ -202,6 +208,9 @@ class NeRF(nn.Module):
         need = self.in_channels_xyz if sigma_only else self.in_channels_xyz + self.in_channels_dir
         if x.dim() != 2 or x.shape[1] != need:
             raise RuntimeError(f"expected input of shape (B, {need}), got {tuple(x.shape)}")
+        if not self.fused:
+            from .generic import mlp_generic
+            return mlp_generic(self, x.float(), sigma_only)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import mlp_embedded_autograd
             return mlp_embedded_autograd(self, x, sigma_only)

@@ -26,14 +26,24 @@ __all__ = ["render_rays", "sample_pdf"]
 PROFILE = None
 
 
-def _check_embeddings(embeddings):
+MAX_FUSED_SAMPLES = 1024       # samples per ray the per-ray kernels (compositor, sampler) hold in one wave
+
+
+def _fused_embeddings(embeddings):
+    """the kernels fuse Embedding(3, 10) / Embedding(3, 4) (logscale) into the MLP (sinnerf.py:133-134, eval.py:134-135)"""
     ex, ed = embeddings[0], embeddings[1]
-    ok = (getattr(ex, "in_channels", None) == 3 and getattr(ex, "N_freqs", None) == 10 and
-          getattr(ed, "in_channels", None) == 3 and getattr(ed, "N_freqs", None) == 4 and
-          getattr(ex, "logscale", True) and getattr(ed, "logscale", True))
-    if not ok:
-        raise NotImplementedError("sinnerf_amd.render_rays fuses Embedding(3,10) / Embedding(3,4) (logscale) into "
-                                  "the MLP kernel (sinnerf.py:133-134, eval.py:134-135); other embeddings are unsupported")
+    return (getattr(ex, "in_channels", None) == 3 and getattr(ex, "N_freqs", None) == 10 and
+            getattr(ed, "in_channels", None) == 3 and getattr(ed, "N_freqs", None) == 4 and
+            getattr(ex, "logscale", True) and getattr(ed, "logscale", True))
+
+
+def _check_embeddings(embeddings):
+    if not _fused_embeddings(embeddings):
+        raise NotImplementedError("this entry point takes Embedding(3,10) / Embedding(3,4) (logscale); render_rays routes other "
+                                  "embeddings through sinnerf_amd.generic")
+
+# developer switch / tests: run render_rays through the general torch-op path (sinnerf_amd/generic.py) even for the fused configuration
+FORCE_GENERIC = False
 
 
 def _mlp(model, rays, z_vals, sigma_only, flags=0):
@@ -155,8 +165,15 @@ def render_rays(models,
                             "the reference NeRF; load reference weights with load_state_dict)")
     if N_importance > 0 and len(models) < 2:
         raise IndexError("list index out of range")          # models[1], rendering.py:321
-    _check_embeddings(embeddings)
     rays = rays.contiguous().float()
+    # the reference's general configurations (other layer shapes / embeddings, more samples than the per-ray kernels hold):
+    # same op sequence as stock PyTorch-ROCm ops on the device -- sinnerf_amd/generic.py
+    if (FORCE_GENERIC or not all(m.fused for m in models) or not _fused_embeddings(embeddings)
+            or N_samples + N_importance > MAX_FUSED_SAMPLES):
+        from .generic import render_generic
+        with torch.cuda.device(rays.device):
+            return render_generic(models, embeddings, rays, N_samples, use_disp, perturb, noise_std, N_importance, chunk, white_back,
+                                  test_time, detach_coarse)
     needs_grad = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
     with torch.cuda.device(rays.device):
         if needs_grad and rays.shape[0] > 0:

@@ -419,14 +419,17 @@ def test_empty_batch_and_unsupported_sizes():
     with torch.no_grad():                            # 600 samples per ray (10 per lane) render fine ...
         r600 = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.rand((4, 8), device=dev()) + 1, 600, False, 0, 0, 0, 32768, True)
     assert r600["opacity_coarse"].shape == (4, 600) and torch.isfinite(r600["rgb_coarse"]).all()
-    with pytest.raises(SinnerfHipError):            # ... > 16 samples per lane (1024 per ray): the compositor refuses loudly
-        with torch.no_grad():
-            sinnerf_amd.render_rays([mc, mf], embeddings(), torch.rand((4, 8), device=dev()) + 1, 1100, False, 0, 0, 0, 32768, True)
-    with pytest.raises(NotImplementedError):
-        sinnerf_amd.NeRF(D=4, W=128, use_new_activation=True)
-    with pytest.raises(NotImplementedError):
-        sinnerf_amd.render_rays([mc, mf], [sinnerf_amd.Embedding(3, 6), sinnerf_amd.Embedding(3, 4)],
-                                torch.rand((4, 8), device=dev()), 64)
+    from sinnerf_amd import _lib                     # ... > 16 samples per lane (1024 per ray): the C-ABI compositor refuses loudly
+    z = torch.sort(torch.rand((4, 1100), device=dev()) * 4 + 2, -1)[0].contiguous()
+    raw = torch.rand((4, 1100, 4), device=dev())
+    o = [torch.empty((4, 3), device=dev()), torch.empty((4,), device=dev()), torch.empty((4, 1100), device=dev())]
+    rc = _lib.lib.sn_composite_forward(_lib.ptr(raw), 1, _lib.ptr(z), _lib.ptr(torch.rand((4, 8), device=dev())), None, 0.0, 4, 1100, 1,
+                                       _lib.ptr(o[0]), _lib.ptr(o[1]), _lib.ptr(o[2]), _lib.stream_ptr())
+    assert rc != 0
+    with pytest.raises(SinnerfHipError):
+        _lib.check(rc, "sn_composite_forward")
+    # ... while render_rays itself takes such a call (and other layer / embedding configurations) through the general torch-op
+    # path on the device: tests/test_round3_gpu.py::test_general_configurations_*
 
 
 def test_bf16_hand_scheduled_kernel_equals_compiler_scheduled():
