@@ -355,7 +355,10 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks,
 #define SN_DW_NARROW_LDS 81920                      // two workgroups share the CU's 160 KB (timing builds: 65536, 73728)
 #endif
 constexpr int DW_NARROW_LDS_BYTES = SN_DW_NARROW_LDS;
-__global__ void __launch_bounds__(256, 2) dw_narrow_bf16_kernel(const Plan plan) {
+#ifndef SN_DW_NARROW_WGS
+#define SN_DW_NARROW_WGS 2
+#endif
+__global__ void __launch_bounds__(256, SN_DW_NARROW_WGS) dw_narrow_bf16_kernel(const Plan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Task t = task_of(plan, (int)blockIdx.x);
   const int tid = threadIdx.x;
@@ -373,16 +376,17 @@ __global__ void __launch_bounds__(256, 2) dw_narrow_bf16_kernel(const Plan plan)
 #ifndef SN_DW_NARROW_F32_2WG
 #define SN_DW_NARROW_F32_2WG 1
 #endif
+constexpr int DW_NARROW_F32_LDS_BYTES = 81920;
 __global__ void __launch_bounds__(256, 2) dw_narrow_f32_kernel(const Plan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Task t = task_of(plan, (int)blockIdx.x);
   const int tid = threadIdx.x;
   switch (t.variant & 0xff) {
-    case 1: run_task<4, 1, 2, 2, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
-    case 2: run_task<2, 4, 2, 2, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
-    case 3: run_task<2, 1, 2, 2, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
-    case 4: run_task<1, 2, 1, 4, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
-    default: run_task<1, 1, 1, 4, 0, DW_NARROW_LDS_BYTES>(t, smem, tid); break;
+    case 1: run_task<4, 1, 2, 2, 0, DW_NARROW_F32_LDS_BYTES>(t, smem, tid); break;
+    case 2: run_task<2, 4, 2, 2, 0, DW_NARROW_F32_LDS_BYTES>(t, smem, tid); break;
+    case 3: run_task<2, 1, 2, 2, 0, DW_NARROW_F32_LDS_BYTES>(t, smem, tid); break;
+    case 4: run_task<1, 2, 1, 4, 0, DW_NARROW_F32_LDS_BYTES>(t, smem, tid); break;
+    default: run_task<1, 1, 1, 4, 0, DW_NARROW_F32_LDS_BYTES>(t, smem, tid); break;
   }
 }
 
@@ -503,7 +507,8 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
     for (int i = 0; i < n; ++i) if (group[i] == gsel) tot += cost[pr[i].var];
     if (tot == 0) continue;
     // (the bf16-state narrow problems run two workgroups per CU: dw_narrow_bf16_kernel)
-    const int target = (gsel == 1 && ((dtype == 2 && SN_DW_NARROW_2WG) || (dtype == 0 && SN_DW_NARROW_F32_2WG))) ? 2 * TARGET_WGS : TARGET_WGS;
+    const int target = (gsel == 1 && dtype == 2 && SN_DW_NARROW_2WG) ? SN_DW_NARROW_WGS * TARGET_WGS
+                       : (gsel == 1 && dtype == 0 && SN_DW_NARROW_F32_2WG) ? 2 * TARGET_WGS : TARGET_WGS;
     double frac[MAX_PROBS];
     int sum = 0;
     for (int i = 0; i < n; ++i) {
@@ -580,8 +585,8 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
       SN_ENSURE_DYN_LDS(dw_narrow_bf16_kernel, DW_NARROW_LDS_BYTES);
       hipLaunchKernelGGL(dw_narrow_bf16_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_NARROW_LDS_BYTES, stream, pb);
     } else if (dtype == 0 && SN_DW_NARROW_F32_2WG) {
-      SN_ENSURE_DYN_LDS(dw_narrow_f32_kernel, DW_NARROW_LDS_BYTES);
-      hipLaunchKernelGGL(dw_narrow_f32_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_NARROW_LDS_BYTES, stream, pb);
+      SN_ENSURE_DYN_LDS(dw_narrow_f32_kernel, DW_NARROW_F32_LDS_BYTES);
+      hipLaunchKernelGGL(dw_narrow_f32_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_NARROW_F32_LDS_BYTES, stream, pb);
     } else {
       hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, pb);
     }
