@@ -558,6 +558,15 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
 
 extern "C" int sn_dw_f32_asm_launch(const snd::Plan* plan_host, hipStream_t stream);      // sn_dw_f32.hip
 extern "C" int sn_dw_bf16_asm_launch(const snd::Plan* plan_host, hipStream_t stream);     // sn_dw_bf16.hip
+extern "C" int sn_dw_narrow_bf16_asm_launch(const snd::Plan* plan_host, hipStream_t stream);   // sn_dw_narrow_bf16.hip
+#ifndef SN_DW_NARROW_ASM
+#define SN_DW_NARROW_ASM 1      // bf16-state narrow problems on the generated instruction streams (0: comparison build)
+#endif
+// SINNERF_DW_NARROW_COMPILER=1 in the environment keeps the compiler-scheduled narrow kernel (A/B runs; read once)
+static bool narrow_compiler_scheduled() {
+  static const bool v = [] { const char* e = getenv("SINNERF_DW_NARROW_COMPILER"); return e != nullptr && e[0] == '1'; }();
+  return v;
+}
 
 extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype) {
   snd::HostPlan hp;
@@ -581,7 +590,10 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
     const Plan pa = group_plan(hp, 0), pb = group_plan(hp, 1);
     rc = dtype == 0 ? sn_dw_f32_asm_launch(&pa, stream) : sn_dw_bf16_asm_launch(&pa, stream);
     if (rc) return rc;
-    if (dtype == 2 && SN_DW_NARROW_2WG) {
+    if (dtype == 2 && SN_DW_NARROW_ASM && !narrow_compiler_scheduled()) {
+      rc = sn_dw_narrow_bf16_asm_launch(&pb, stream);
+      if (rc) return rc;
+    } else if (dtype == 2 && SN_DW_NARROW_2WG) {
       SN_ENSURE_DYN_LDS(dw_narrow_bf16_kernel, DW_NARROW_LDS_BYTES);
       hipLaunchKernelGGL(dw_narrow_bf16_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_NARROW_LDS_BYTES, stream, pb);
     } else if (dtype == 0 && SN_DW_NARROW_F32_2WG) {
