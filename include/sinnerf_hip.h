@@ -17,12 +17,14 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 2   /* 2: sn_sample_pdf_bins gained eps, dtype carries SN_DTYPE_CLASSIC_HEADS, sn_mlp_forward flag bits */
+#define SN_ABI_VERSION 3   /* 2: sn_sample_pdf_bins gained eps, dtype carries SN_DTYPE_CLASSIC_HEADS, sn_mlp_forward flag bits
+                            * 3: dtype carries SN_DTYPE_COMPILER_SCHEDULED and SN_DTYPE_EMB_BF16 */
 
 #define SN_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32                                          */
 #define SN_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate                    */
 #define SN_DTYPE_BF16_STATE 2 /* training entries only: SN_DTYPE_BF16 arithmetic AND acts / g_acts stored as bf16
-                               * (same shapes; the float* parameters then point at bf16 arrays; emb stays fp32)   */
+                               * (same shapes; the float* parameters then point at bf16 arrays; emb stays fp32
+                               * unless SN_DTYPE_EMB_BF16 is OR-ed in)                                             */
 /* OR-ed into `dtype` of the sn_mlp_* entry points: the network was built as NeRF(use_new_activation=False), the
  * constructor's default (models/nerf.py:47-50, :91-100) -- ReLU after dir_encoding, Sigmoid after rgb -- instead of the
  * ShiftedSoftplus / WidenedSigmoid heads both reference call sites ask for (models/nerf.py:81-90, models/activations.py).
@@ -32,6 +34,13 @@ extern "C" {
  * (csrc/sn_mlp_fwd_bf16.hip, csrc/sn_mlp_bwd_bf16.hip) instead of the hand-scheduled ones (csrc/sn_mlp_fwd_bf16_t.hip, ...).
  * Same arithmetic, same stored state bit for bit; kept for A/B timing and the bit-identity tests. */
 #define SN_DTYPE_COMPILER_SCHEDULED 0x200
+/* OR-ed into `dtype` (SN_DTYPE_BF16_STATE, hand-scheduled kernels) of sn_mlp_forward_train, sn_weight_grads and
+ * sn_weight_grads_workspace_bytes -- all three or none: `emb` is a bf16 array (slot_rows, 128) holding the embedded inputs as the
+ * MFMA operands the forward builds, in its K-slot order instead of the reference's column order: positions [0, 64) =
+ * Embedding(xyz) (lane half h, slot e at 32 h + e), [64, 96) = Embedding(dir) (16 h + e), [96, 128) never written.  192 B per point
+ * instead of 360 B written, half the bytes read by the three contractions that use it; sn_weight_grads returns the same gradients bit
+ * for bit (it contracts the same bf16 values in the same order and permutes the 63 / 27 columns back).              */
+#define SN_DTYPE_EMB_BF16 0x400
 
 #define SN_E_BADARG (-1)
 #define SN_E_TOOLARGE (-2)

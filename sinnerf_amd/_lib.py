@@ -16,7 +16,8 @@ SN_DTYPE_BF16_STATE = 2
 SN_DTYPE_CLASSIC_HEADS = 0x100      # OR-ed into dtype: NeRF(use_new_activation=False) heads (include/sinnerf_hip.h)
 SN_DTYPE_COMPILER_SCHEDULED = 0x200 # OR-ed into dtype of the bf16-state training entries: the compiler-scheduled kernels (A/B, tests)
 N_RAW_TENSORS = 24
-ABI_VERSION = 2                     # == SN_ABI_VERSION of include/sinnerf_hip.h this binding was written against
+SN_DTYPE_EMB_BF16 = 0x400           # ... emb stored as bf16 in K-slot order (hand-scheduled bf16-state kernels only)
+ABI_VERSION = 3                     # == SN_ABI_VERSION of include/sinnerf_hip.h this binding was written against
 
 c_fp = ctypes.c_void_p      # device float*
 c_vp = ctypes.c_void_p

@@ -19,17 +19,22 @@ from .nerf import dtype_code
 # developer switch (A/B timing, bit-identity tests): run the compiler-scheduled bf16-state training kernels instead of the
 # hand-scheduled ones -- same arithmetic and stored state
 COMPILER_SCHEDULED = bool(int(__import__("os").environ.get("SINNERF_COMPILER_SCHEDULED", "0")))
+EMB_BF16 = not bool(int(__import__("os").environ.get("SINNERF_EMB_FP32", "0")))    # A/B: keep the fp32 column-order emb
 
 
 def _sched_flag():
     return _lib.SN_DTYPE_COMPILER_SCHEDULED if COMPILER_SCHEDULED else 0
 
 
-def _state_code(model, acts):
-    """C-ABI dtype of the stored training state: fp32 MFMAs, bf16 operands on fp32 state, or bf16 operands on bf16 state."""
+def _state_code(model, acts, emb=None):
+    """C-ABI dtype of the stored training state: fp32 MFMAs, bf16 operands on fp32 state, or bf16 operands on bf16 state
+    (| SN_DTYPE_EMB_BF16 when the embedded inputs were stored as bf16 operands too)."""
     if dtype_code(model.compute_dtype) != _lib.SN_DTYPE_BF16:
         return _lib.SN_DTYPE_F32
-    return _lib.SN_DTYPE_BF16_STATE if acts.dtype == torch.bfloat16 else _lib.SN_DTYPE_BF16
+    code = _lib.SN_DTYPE_BF16_STATE if acts.dtype == torch.bfloat16 else _lib.SN_DTYPE_BF16
+    if emb is not None and emb.dtype == torch.bfloat16:
+        code |= _lib.SN_DTYPE_EMB_BF16
+    return code
 
 
 def _sink_of(model, raws, needs):
@@ -52,7 +57,7 @@ def _weight_grads(model, acts, emb, G, needs):
     parameters' shapes.  Returns the list autograd expects (order of ``NeRF.raw_tensors()``)."""
     import ctypes
     dev = acts.device
-    code = _state_code(model, acts)
+    code = _state_code(model, acts, emb)
     rows = acts.shape[1]
     nbytes = _lib.lib.sn_weight_grads_workspace_bytes(rows, code)
     if nbytes < 0:
@@ -110,8 +115,11 @@ class _MLPFn(torch.autograd.Function):
             # of EVERY row of the whole point tiles; the pad columns 63, 91..127 only ever feed columns of the 64-wide dW
             # blocks that _weight_grads slices away ([:, :63], [:, :27]) -- a contraction's output column depends on its own
             # X column only
-            emb = torch.empty((rows, 128), dtype=torch.float32, device=dev)
-            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code) | _sched_flag(), _lib.ptr(rays), _lib.ptr(z_vals), n, s,
+            # bf16 state on the hand-scheduled kernels: emb holds the bf16 operands themselves (SN_DTYPE_EMB_BF16, K-slot order)
+            emb16 = bf16 and EMB_BF16 and not COMPILER_SCHEDULED and P < 2 ** 31 - 256
+            emb = torch.empty((rows, 128), dtype=torch.bfloat16 if emb16 else torch.float32, device=dev)
+            flags = _sched_flag() | (_lib.SN_DTYPE_EMB_BF16 if emb16 else 0)
+            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code) | flags, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                                      _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
                        "sn_mlp_forward_train")
         ctx.model = model
@@ -147,7 +155,8 @@ class _CompositeFn(torch.autograd.Function):
     def forward(ctx, raw, z_vals, rays, noise, noise_std, white_back):
         n, s = z_vals.shape
         dev = rays.device
-        weights = torch.empty((n, s), dtype=torch.float32, device=dev)
+        ctx.set_materialize_grads(False)           # an output no loss term uses arrives as None (the kernel takes a null
+        weights = torch.empty((n, s), dtype=torch.float32, device=dev)                 # pointer), not as a zero-filled tensor
         rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
         depth = torch.empty((n,), dtype=torch.float32, device=dev)
         _lib.check(_lib.lib.sn_composite_forward(_lib.ptr(raw), 1, _lib.ptr(z_vals), _lib.ptr(rays), _lib.ptr(noise),

@@ -21,8 +21,8 @@ int sn_mlp_backward_chain_bf16_classic_launch(const void* bblob, const float* ac
                                       long n_points, long slot_rows, float* G, float* g_out, int state_bf16,
                                       hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
-long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype);
-int sn_weight_grads_launch(const void* acts, const float* emb, const void* G, long slot_rows, int dtype, void* workspace,
+long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype, int emb16);
+int sn_weight_grads_launch(const void* acts, const float* emb, const void* G, long slot_rows, int dtype, int emb16, void* workspace,
                            float* const* grads, int accumulate, hipStream_t stream);
 int sn_generate_rays_launch(const float* c2w, int H, int W, float focal, float near, float far, int x0, int y0, int sx,
                             int sy, int pw, int ph, float* rays, hipStream_t stream);
@@ -44,9 +44,9 @@ int sn_mlp_forward_bf16_v3_launch(const void* blob, const float* rays, const flo
 int sn_mlp_forward_bf16_v3_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
                                   float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_t_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples, float* out,
-                                 float* acts, float* emb, long slot_rows, hipStream_t stream);
+                                 float* acts, float* emb, long slot_rows, int emb16, hipStream_t stream);
 int sn_mlp_forward_bf16_t_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
-                                         float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
+                                         float* out, float* acts, float* emb, long slot_rows, int emb16, hipStream_t stream);
 int sn_mlp_backward_chain_bf16_t_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw, long n_points,
                                         long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_mlp_backward_chain_bf16_t_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
@@ -188,13 +188,16 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
   if (!blob || !rays || !z_vals || !out || !acts || !emb || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   const bool classic = dtype & SN_DTYPE_CLASSIC_HEADS;
   const bool compiler_scheduled = dtype & SN_DTYPE_COMPILER_SCHEDULED;
-  dtype &= ~(SN_DTYPE_CLASSIC_HEADS | SN_DTYPE_COMPILER_SCHEDULED);
+  const int emb16 = (dtype & SN_DTYPE_EMB_BF16) ? 1 : 0;
+  dtype &= ~(SN_DTYPE_CLASSIC_HEADS | SN_DTYPE_COMPILER_SCHEDULED | SN_DTYPE_EMB_BF16);
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
   const long n_points = n_rays * (long)n_samples;
   const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are stored
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
-  if (dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256)         // the hand-scheduled kernel
-    return SN_HEADS(classic, sn_mlp_forward_bf16_t)(blob, rays, z_vals, n_points, n_samples, out, acts, emb, slot_rows, (hipStream_t)stream);
+  const bool hand = dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256;   // the hand-scheduled kernel
+  if (emb16 && !hand) return SN_E_UNSUPPORTED;                               // (the only one that writes the bf16 form of emb)
+  if (hand)
+    return SN_HEADS(classic, sn_mlp_forward_bf16_t)(blob, rays, z_vals, n_points, n_samples, out, acts, emb, slot_rows, emb16, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32)
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
                                                   dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
@@ -274,16 +277,22 @@ int sn_dw_gemm(const void* tasks, int n_tasks, void* stream) {
 
 long sn_weight_grads_workspace_bytes(long slot_rows, int dtype) {
   if (slot_rows < 16 || slot_rows % 16 != 0) return SN_E_BADSHAPE;
+  const int emb16 = (dtype & SN_DTYPE_EMB_BF16) ? 1 : 0;
+  dtype &= ~SN_DTYPE_EMB_BF16;
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
-  return sn_weight_grads_workspace_bytes_impl(slot_rows, dtype);
+  if (emb16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
+  return sn_weight_grads_workspace_bytes_impl(slot_rows, dtype, emb16);
 }
 
 int sn_weight_grads(const void* acts, const float* emb, const void* g_acts, long slot_rows, int dtype, void* workspace,
                     float* const* grads, int accumulate, void* stream) {
   if (!acts || !emb || !g_acts || !workspace || !grads) return SN_E_BADARG;
   if (slot_rows < 16 || slot_rows % 16 != 0) return SN_E_BADSHAPE;
+  const int emb16 = (dtype & SN_DTYPE_EMB_BF16) ? 1 : 0;
+  dtype &= ~SN_DTYPE_EMB_BF16;
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
-  return sn_weight_grads_launch(acts, emb, g_acts, slot_rows, dtype, workspace, grads, accumulate ? 1 : 0, (hipStream_t)stream);
+  if (emb16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
+  return sn_weight_grads_launch(acts, emb, g_acts, slot_rows, dtype, emb16, workspace, grads, accumulate ? 1 : 0, (hipStream_t)stream);
 }
 
 int sn_composite_backward(const float* raw, const float* z_vals, const float* rays, const float* noise, float noise_std,

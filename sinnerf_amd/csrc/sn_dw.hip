@@ -395,7 +395,21 @@ struct Seg {                                    // dst[r][dst_col0 + c] (+)= sum
   float* dst;
   const float* src;
   int dst_ld, dst_col0, rows, cols, src_ld, src_row0, src_col0, ns, stride, first;   // first = prefix sum of rows*cols
+  int perm, pad;                                  // 1 / 2: source column of c = K-slot position of xyz / dir embedding column c
 };
+// SN_DTYPE_EMB_BF16: the training forward stores the embedded inputs as the bf16 MFMA operands it built (K-slot order: lane half h
+// owns positions 32 h + e of the xyz embedding, 16 h + e of the direction embedding -- sn_mlp_common.h store_emb_xyz / _dir give the
+// column each slot e holds), so the 64-wide gradient blocks come out in that order and are permuted back here
+SN_DEV int emb_xyz_pos(int c) {                   // column c of Embedding(3, 10) (63 columns) -> position in the stored row
+  if (c < 3) return c == 0 ? 30 : c == 1 ? 31 : 62;
+  const int k = (c - 3) % 30, h = (c - 3) / 30;
+  return 32 * h + 2 * (3 * (k / 6) + k % 3) + (k % 6) / 3;
+}
+SN_DEV int emb_dir_pos(int c) {                   // column c of Embedding(3, 4) (27 columns)
+  if (c < 3) return c == 0 ? 12 : c == 1 ? 13 : 28;
+  const int k = (c - 3) % 12, h = (c - 3) / 12;
+  return 16 * h + 2 * (3 * (k / 6) + k % 3) + (k % 6) / 3;
+}
 constexpr int MAX_SEGS = 32;
 struct Segs {
   Seg s[MAX_SEGS];
@@ -411,7 +425,8 @@ __global__ void __launch_bounds__(256) dw_finish_kernel(const Segs segs) {
   const Seg& g = segs.s[q];
   const int l = e - g.first;
   const int r = l / g.cols, c = l - r * g.cols;
-  const float* src = g.src + (long)(g.src_row0 + r) * g.src_ld + g.src_col0 + c;
+  const int sc = g.perm == 0 ? c : g.perm == 1 ? emb_xyz_pos(c) : emb_dir_pos(c);
+  const float* src = g.src + (long)(g.src_row0 + r) * g.src_ld + g.src_col0 + sc;
   // fixed summation order (run-to-run deterministic), but the loads of eight partials are issued together: as a dependent chain
   // of ns ~ 32 strided loads per thread the kernel ran at 1.5 TB/s (50 us per network, 2.5 % of a bf16 training step)
   float acc = 0.0f;
@@ -431,18 +446,18 @@ __global__ void __launch_bounds__(256) dw_finish_kernel(const Segs segs) {
 
 // ---- host: the plan of one network (the K-split cost model that used to live in sinnerf_amd/autograd.py) -------------------
 struct VariantInfo { int m, n; };
-static const VariantInfo VARIANTS[6] = {{256, 256}, {256, 64}, {128, 256}, {128, 64}, {32, 256}, {32, 128}};
+static const VariantInfo VARIANTS[8] = {{256, 256}, {256, 64}, {128, 256}, {128, 64}, {32, 256}, {32, 128}, {256, 64}, {128, 64}};
 // cost of one point of a K-range on one CU (cycles, variant 0 = 512): max(MFMA issue time of the wave block, tile bytes over
 // the per-CU streaming rate) -- measured per mode (tools/dw_time.py): the narrow problems are DMA-bound, and splitting by
 // FLOPs alone left the 32x128 problem streaming 168 MB through a single CU
-static const int COST_F32[6] = {512, 161, 260, 95, 101, 59};
-static const int COST_BF16[6] = {512, 189, 226, 126, 138, 125};          // bf16 operands, fp32 state
+static const int COST_F32[8] = {512, 161, 260, 95, 101, 59, 0, 0};
+static const int COST_BF16[8] = {512, 189, 226, 126, 138, 125, 0, 0};          // bf16 operands, fp32 state
 // bf16 operands, bf16 state (transpose-read fragments, a sync point every 2nd / 4th chunk): the 256x256 problems run at their
 // share of the HBM rate (52 ns per point per CU = 1 KB / 19.7 GB/s), the narrower ones at 19..35 ns per point
 #ifndef SN_DW_COST_STATE
-#define SN_DW_COST_STATE 512, 343, 348, 226, 296, 190
+#define SN_DW_COST_STATE 512, 343, 348, 226, 296, 190, 286, 170     // (6 / 7: variants 1 / 3 at 640 / 384 instead of 768 / 512 B per point)
 #endif
-static const int COST_BF16_STATE[6] = {SN_DW_COST_STATE};
+static const int COST_BF16_STATE[8] = {SN_DW_COST_STATE};
 constexpr int TARGET_WGS = 256;                 // one workgroup per CU
 
 struct HostPlan {
@@ -471,8 +486,10 @@ static Plan group_plan(const HostPlan& hp, int g) {
 enum { W0 = 0, W1 = 1, W2 = 2, W3 = 3, W4 = 4, W4E = 5, W5 = 6, W6 = 7, W7 = 8, WF = 9, WD = 10, WDE = 11, SIG = 12, RGB = 13 };
 
 // dtype: 0 fp32, 1 bf16 operands / fp32 state, 2 bf16 operands / bf16 state.  Pointers may be null (size query).
-static void build_plan(HostPlan& hp, const char* acts, const char* emb, const char* G, long rows, int dtype) {
-  const long es = dtype == 2 ? 2 : 4;           // element size of acts / G (emb is always fp32)
+static void build_plan(HostPlan& hp, const char* acts, const char* emb, const char* G, long rows, int dtype, bool emb16 = false) {
+  const long es = dtype == 2 ? 2 : 4;           // element size of acts / G (emb: fp32, or bf16 in K-slot order with emb16)
+  const int v_e1 = emb16 ? 6 : 1, v_e3 = emb16 ? 7 : 3;
+  const long ees = emb16 ? 2 : 4;
   const long slot = rows * 256 * es;
   const int flags = (dtype >= 1 ? 0x100 : 0) | (dtype == 2 ? 0x200 : 0);
   const int* cost = dtype == 0 ? COST_F32 : dtype == 1 ? COST_BF16 : COST_BF16_STATE;
@@ -482,15 +499,15 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
   auto Gs = [&](int i, int col) { return G + i * slot + col * es; };
   auto As = [&](int i) { return acts + i * slot; };
   for (int i = 0; i < 8; ++i) {                                   // xyz_encoding_{i+1}
-    if (i == 0) pr[n++] = {Gs(0, 0), emb, 256, 128, 1, true};
+    if (i == 0) pr[n++] = {Gs(0, 0), emb, 256, 128, v_e1, true};
     else {
       pr[n++] = {Gs(i, 0), As(i - 1), 256, 256, 0, true};
-      if (i == 4) pr[n++] = {Gs(4, 0), emb, 256, 128, 1, false};  // skip: cat([input_xyz, h4])  nerf.py:133
+      if (i == 4) pr[n++] = {Gs(4, 0), emb, 256, 128, v_e1, false};  // skip: cat([input_xyz, h4])  nerf.py:133
     }
   }
   pr[n++] = {Gs(8, 0), As(7), 256, 256, 0, true};                 // xyz_encoding_final
   pr[n++] = {Gs(9, 0), As(8), 256, 256, 2, true};                 // dir_encoding[:, :256]
-  pr[n++] = {Gs(9, 0), emb + 64 * 4, 256, 128, 3, false};         // dir_encoding[:, 256:]
+  pr[n++] = {Gs(9, 0), emb + 64 * ees, 256, 128, v_e3, false};         // dir_encoding[:, 256:]
   pr[n++] = {Gs(9, 128), As(7), 256, 256, 4, false};              // sigma (nerf.py:136): row 3 of the 32-wide head block
   pr[n++] = {Gs(9, 128), As(9), 256, 256, 5, true};               // rgb (nerf.py:144): rows 0..2; bias = [g_rgb(3), g_sigma(1)]
   // fp32: the 256x256 problems run in their own launch (sn_dw_f32.hip, hand-scheduled inner loop), the narrow ones in a second
@@ -568,17 +585,18 @@ static bool narrow_compiler_scheduled() {
   return v;
 }
 
-extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype) {
+extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype, int emb16) {
   snd::HostPlan hp;
-  snd::build_plan(hp, nullptr, nullptr, nullptr, slot_rows, dtype);
+  snd::build_plan(hp, nullptr, nullptr, nullptr, slot_rows, dtype, emb16 != 0);
   return hp.bytes;
 }
 
-extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const void* G, long slot_rows, int dtype,
+extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const void* G, long slot_rows, int dtype, int emb16,
                                       void* workspace, float* const* grads, int accumulate, hipStream_t stream) {
   using namespace snd;
+  if (emb16 && (dtype != 2 || !SN_DW_NARROW_ASM || narrow_compiler_scheduled())) return -3;     // only the generated narrow kernel reads it
   HostPlan hp;
-  build_plan(hp, (const char*)acts, (const char*)emb, (const char*)G, slot_rows, dtype);
+  build_plan(hp, (const char*)acts, (const char*)emb, (const char*)G, slot_rows, dtype, emb16 != 0);
   char* ws = (char*)workspace;
   for (int i = 0; i < hp.plan.n_probs; ++i) {
     hp.plan.p[i].c = (float*)(ws + hp.c_off[i]);
@@ -609,7 +627,7 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
   if (rc) return rc;
   Segs sg;
   int n = 0, total = 0;
-  auto seg = [&](float* dst, int dst_ld, int dst_col0, int rows, int cols, int prob, bool from_bias, int src_row0, int src_col0) {
+  auto seg = [&](float* dst, int dst_ld, int dst_col0, int rows, int cols, int prob, bool from_bias, int src_row0, int src_col0, int perm = 0) {
     if (dst == nullptr) return;
     const Prob& q = hp.plan.p[prob];
     Seg& g = sg.s[n++];
@@ -617,13 +635,14 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
     g.src = from_bias ? q.bias : q.c;
     g.src_ld = from_bias ? 1 : q.ldc; g.src_row0 = src_row0; g.src_col0 = src_col0;
     g.ns = q.ns; g.stride = from_bias ? q.m : q.m * q.ldc;
+    g.perm = emb16 ? perm : 0; g.pad = 0;
     g.first = total; total += rows * cols;
   };
   const int wl[8] = {W0, W1, W2, W3, W4, W5, W6, W7};
   for (int i = 0; i < 8; ++i) {
-    if (i == 0) seg(grads[0], 63, 0, 256, 63, W0, false, 0, 0);
+    if (i == 0) seg(grads[0], 63, 0, 256, 63, W0, false, 0, 0, 1);
     else if (i == 4) {
-      seg(grads[8], 319, 0, 256, 63, W4E, false, 0, 0);            // cat([input_xyz, h4]): embedded columns first
+      seg(grads[8], 319, 0, 256, 63, W4E, false, 0, 0, 1);         // cat([input_xyz, h4]): embedded columns first
       seg(grads[8], 319, 63, 256, 256, W4, false, 0, 0);
     } else seg(grads[2 * i], 256, 0, 256, 256, wl[i], false, 0, 0);
     seg(grads[2 * i + 1], 1, 0, 256, 1, wl[i], true, 0, 0);
@@ -631,7 +650,7 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
   seg(grads[16], 256, 0, 256, 256, WF, false, 0, 0);
   seg(grads[17], 1, 0, 256, 1, WF, true, 0, 0);
   seg(grads[18], 283, 0, 128, 256, WD, false, 0, 0);
-  seg(grads[18], 283, 256, 128, 27, WDE, false, 0, 0);
+  seg(grads[18], 283, 256, 128, 27, WDE, false, 0, 0, 2);
   seg(grads[19], 1, 0, 128, 1, WD, true, 0, 0);
   seg(grads[20], 256, 0, 1, 256, SIG, false, 3, 0);                // sigma.weight (1, 256) = row 3 of the head block
   seg(grads[21], 1, 0, 1, 1, RGB, true, 3, 0);                     // sigma.bias = column sum of g_sigma

@@ -17,6 +17,7 @@ struct Task {                                   // 64 bytes, built on the host (
   long k0, k1;                                  // point range: (k1-k0) % 16 == 0, rows [k0,k1) readable (callers zero-pad G)
   int lda, ldb;
   int ldc, variant;                             // M x N: 0 = 256x256, 1 = 256x64, 2 = 128x256, 3 = 128x64, 4 = 32x256, 5 = 32x128;
+                                                // 6 / 7 = 1 / 3 with the embedded inputs stored as bf16 (sn_dw_narrow_bf16.hip only);
                                                 // | 0x100: bf16 operands (mixed-precision training), fp32 accumulate;
                                                 // | 0x200: G and the 256-wide activations are stored as bf16 (the embedded
                                                 //   inputs of variants 1 / 3 stay fp32); lda / ldb stay in ELEMENTS

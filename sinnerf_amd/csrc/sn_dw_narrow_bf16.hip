@@ -1,6 +1,6 @@
 // sn_dw_narrow_bf16.hip -- the NARROW weight-gradient contractions  dW[m, n] = sum_p G[p, m] X[p, n]  (+ db[m]) of the bf16-state
 // training step with HAND-SCHEDULED inner loops: everything of models/nerf.py:66-103 that is not 256 x 256 (xyz_encoding_1, the skip
-// layer's xyz columns, both halves of dir_encoding, sigma, rgb: variants 1..5 of sn_dw_common.h, 3.9 KB per sample point).  Same
+// layer's xyz columns, both halves of dir_encoding, sigma, rgb: variants 1..7 of sn_dw_common.h, 3.9 / 3.5 KB per sample point).  Same
 // tasks, K-split plan, tiles, swizzled DMA image, transpose-read fragments and results as dw_narrow_bf16_kernel (sn_dw.hip run_task)
 // -- two workgroups per CU, one workgroup = one K-range of one problem -- what changes is who lays out the instruction stream:
 // tools/gen_dw_narrow.py, one asm statement per PAIR of 16-point chunks.  The compiler-scheduled loop ran at 5.0 TB/s with its waves
@@ -56,8 +56,12 @@ SN_DEV void dwn_task_##V(const Task& t, int tid) {                              
   constexpr int R = SN_DWN##V##_RING;                                                                                              \
   static_assert(BUF == SN_DWN##V##_BUF && R * BUF <= DWN_LDS_BYTES && (R & 1) == 0 && R >= 6, "ring of the generated statement");  \
   constexpr int CH_A = A_BYTES / 16, CH_B = B_BYTES / 16;                                                                          \
-  constexpr int IT_A = (CH_A + 255) / 256, IT_B = CH_B / 256;                                                                      \
-  constexpr bool A_W0 = CH_A < 256;               /* a 32-wide A tile: 64 pieces, staged by wave 0 */                              \
+  constexpr int IT_A = (CH_A + 255) / 256, IT_B = (CH_B + 255) / 256;                                                              \
+  /* a tile of fewer than 256 pieces is staged by its first waves only: a 32-wide A tile (64 pieces) by wave 0, a 64-wide bf16 B   \
+     tile (128 pieces) by waves 0 and 1 -- the waves that stage BOTH tiles run the W0 form of the statement, the others WX */      \
+  constexpr int A_WAVES = CH_A % 256 == 0 ? 4 : CH_A / 64, B_WAVES = CH_B % 256 == 0 ? 4 : CH_B / 64;                              \
+  constexpr int N_FULL = A_WAVES < B_WAVES ? A_WAVES : B_WAVES;                                                                    \
+  static_assert(A_WAVES == 4 || B_WAVES == 4, "one of the tiles is staged by every wave");                                         \
   constexpr bool SWZ_A = WA * 2 / 16 >= 16, SWZ_B = (EB == 2) && (WB * 2 / 16 >= 16);                                              \
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                      \
   const int i = lane & 31, h = lane >> 5;                                                                                          \
@@ -100,12 +104,14 @@ SN_DEV void dwn_task_##V(const Task& t, int tid) {                              
   _Pragma("unroll") for (int c = 0; c < R - 2; ++c) {                                                                              \
     const char* ba = chunk_a(k0 + (long)c * KB);                                                                                   \
     const char* bb = chunk_b(k0 + (long)c * KB);                                                                                   \
-    if (!A_W0 || wave == 0) {                                                                                                      \
+    if (wave < A_WAVES) {                                                                                                          \
       _Pragma("unroll") for (int it = 0; it < IT_A; ++it)                                                                          \
         __builtin_amdgcn_global_load_lds((gbl_cvoid*)(ba + oa[it]), (lds_void*)(size_t)(c * BUF + it * 4096 + wave * 1024), 16, 0, 2);    \
     }                                                                                                                              \
-    _Pragma("unroll") for (int it = 0; it < IT_B; ++it)                                                                            \
-      __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bb + ob[it]), (lds_void*)(size_t)(c * BUF + A_BYTES + it * 4096 + wave * 1024), 16, 0, 2); \
+    if (wave < B_WAVES) {                                                                                                          \
+      _Pragma("unroll") for (int it = 0; it < IT_B; ++it)                                                                          \
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bb + ob[it]), (lds_void*)(size_t)(c * BUF + A_BYTES + it * 4096 + wave * 1024), 16, 0, 2); \
+    }                                                                                                                              \
   }                                                                                                                                \
   asm volatile(SN_DWN##V##_ZERO_ASM ::: SN_DWN_AGPR_CLOBBERS);                                                                     \
   float bs0 = 0.0f, bs1 = 0.0f, bs2 = 0.0f, bs3 = 0.0f;                                                                            \
@@ -120,7 +126,7 @@ SN_DEV void dwn_task_##V(const Task& t, int tid) {                              
     const char* ga0 = chunk_a(kn0); const char* gb0 = chunk_b(kn0);                                                                \
     const char* ga1 = chunk_a(kn1); const char* gb1 = chunk_b(kn1);                                                                \
     const unsigned md0 = (unsigned)sn0 * BUF + (unsigned)wave * 1024u, md1 = (unsigned)sn1 * BUF + (unsigned)wave * 1024u;         \
-    if (!A_W0 || wave == 0) {                                                                                                      \
+    if (wave < N_FULL) {                                                                                                           \
       asm volatile(SN_DWN##V##_PAIR_W0_ASM                                                                                         \
                    : [bs0] "+v"(bs0), [bs1] "+v"(bs1), [bs2] "+v"(bs2), [bs3] "+v"(bs3)                                            \
                    : [ta0] "v"(ta[0]), [ta1] "v"(ta[1]), [ta2] "v"(ta[2]), [ta3] "v"(ta[3]),                                       \
@@ -171,6 +177,8 @@ SN_DWN_TASK(2, 2, 4, 2, 2, 2)
 SN_DWN_TASK(3, 2, 1, 2, 2, 4)
 SN_DWN_TASK(4, 1, 2, 1, 4, 2)
 SN_DWN_TASK(5, 1, 1, 1, 4, 2)
+SN_DWN_TASK(6, 4, 1, 2, 2, 2)
+SN_DWN_TASK(7, 2, 1, 2, 2, 2)
 
 __global__ void __launch_bounds__(256, 2) dw_narrow_bf16_asm_kernel(const Plan plan) {
   asm volatile("" ::: "a0", "a127");               // the hand-managed accumulator file
@@ -181,7 +189,9 @@ __global__ void __launch_bounds__(256, 2) dw_narrow_bf16_asm_kernel(const Plan p
     case 2: dwn_task_2(t, tid); break;
     case 3: dwn_task_3(t, tid); break;
     case 4: dwn_task_4(t, tid); break;
-    default: dwn_task_5(t, tid); break;
+    case 5: dwn_task_5(t, tid); break;
+    case 6: dwn_task_6(t, tid); break;
+    default: dwn_task_7(t, tid); break;
   }
 }
 

@@ -33,6 +33,7 @@ class _RenderLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb_c, rgb_f, depth_c, depth_f, rgb_gt, depth_gt, mask, mask_mode, w_rgb, w_depth):
+        ctx.set_materialize_grads(False)
         preds = (rgb_c, rgb_f, depth_c, depth_f)
         ref = next(t for t in preds if t is not None)
         n = ref.numel() // 3 if ref is rgb_c or ref is rgb_f else ref.numel()
@@ -70,6 +71,8 @@ class _RenderLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_stats):
         saved = list(ctx.saved_tensors)
+        if g_total is None:
+            return (None,) * 10
         res = []
         for have, shape in zip(ctx.have, ctx.shapes):
             res.append((saved.pop(0) * g_total).reshape(shape) if have else None)

@@ -60,7 +60,8 @@ class SinNeRFSystem(nn.Module):
                                     hp.perturb, hp.noise_std, hp.N_importance, hp.chunk, self.white_back)
             for k, v in chunk_res.items():
                 results[k].append(v)
-        return {k: torch.cat(v, 0) for k, v in results.items()}
+        # one chunk (every training batch): hand the tensors on -- torch.cat of a single tensor is a device copy per key
+        return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in results.items()}
 
     # ---- sinnerf.py:202-210 + utils/__init__.py:11-57 -----------------------------------------------------------
     def configure_optimizers(self):

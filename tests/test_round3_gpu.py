@@ -390,3 +390,107 @@ def test_general_configurations_run_on_the_device_and_match_the_oracle():
     with torch.no_grad():
         big = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays[:4]).to(d), 1100, False, 0, 0, 0, 32768, True)
     assert big["opacity_coarse"].shape == (4, 1100) and torch.isfinite(big["rgb_coarse"]).all()
+
+
+# ---- SN_DTYPE_EMB_BF16: the embedded inputs stored as the bf16 operands, in the kernel's K-slot order ---------------------------------
+def _emb_xyz_pos(c):
+    """column c of Embedding(3, 10) -> position in the stored row (csrc/sn_dw.hip emb_xyz_pos; sn_mlp_common.h xyz_col_slot)"""
+    if c < 3:
+        return (30, 31, 62)[c]
+    k, h = (c - 3) % 30, (c - 3) // 30
+    return 32 * h + 2 * (3 * (k // 6) + k % 3) + (k % 6) // 3
+
+
+def _emb_dir_pos(c):
+    if c < 3:
+        return (12, 13, 28)[c]
+    k, h = (c - 3) % 12, (c - 3) // 12
+    return 16 * h + 2 * (3 * (k // 6) + k % 3) + (k % 6) // 3
+
+
+def test_emb_positions_are_a_permutation():
+    assert sorted(_emb_xyz_pos(c) for c in range(63)) == [q for q in range(64) if q != 63]
+    assert sorted(_emb_dir_pos(c) for c in range(27)) == [q for q in range(32) if q not in (14, 15, 29, 30, 31)]
+
+
+@pytest.mark.parametrize("n_rays,S", [(60, 37), (1024, 128)])
+def test_bf16_emb_is_the_rounded_fp32_emb_and_gives_the_same_weight_gradients(n_rays, S):
+    """sn_mlp_forward_train | SN_DTYPE_EMB_BF16 stores RNE-bf16(emb) at the K-slot positions (everything else it writes is unchanged),
+    and sn_weight_grads | SN_DTYPE_EMB_BF16 returns the gradients of the fp32-emb form (same bits while the K-split is the same),
+    accumulate or not."""
+    import ctypes
+    from sinnerf_amd import _lib
+    model, p = make_model(3, True, dtype="bf16")
+    rays = O.lego_rays(400, 400, seed=0)[:: max(1, 160000 // n_rays)][:n_rays]
+    z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (rays.shape[0], S)).astype(np.float32))
+    rays_t, z_t = torch.from_numpy(rays).to(dev()), torch.from_numpy(z).to(dev())
+    out, acts, emb = _train_forward(model, rays_t, z_t, 0)
+    n, s = z_t.shape
+    P, rows = n * s, acts.shape[1]
+    out16 = torch.zeros_like(out)
+    acts16 = torch.full_like(acts, float("nan"))
+    emb16 = torch.full((rows, 128), float("nan"), dtype=torch.bfloat16, device=dev())
+    code16 = model.kernel_dtype(_lib.SN_DTYPE_BF16_STATE) | _lib.SN_DTYPE_EMB_BF16
+    _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code16, _lib.ptr(rays_t), _lib.ptr(z_t), n, s, _lib.ptr(out16),
+                                             _lib.ptr(acts16), _lib.ptr(emb16), rows, _lib.stream_ptr()), "sn_mlp_forward_train emb16")
+    torch.cuda.synchronize()
+    assert torch.equal(out16, out) and torch.equal(acts16.view(torch.int16), acts.view(torch.int16))
+    xp = torch.tensor([_emb_xyz_pos(c) for c in range(63)], device=dev())
+    dp = torch.tensor([64 + _emb_dir_pos(c) for c in range(27)], device=dev())
+    assert torch.equal(emb16[:, xp].view(torch.int16), emb[:, :63].bfloat16().view(torch.int16))
+    assert torch.equal(emb16[:, dp].view(torch.int16), emb[:, 64:91].bfloat16().view(torch.int16))
+    assert bool(torch.isnan(emb16[:, 96:].float()).all())                     # [96, 128) is never written
+    # the weight gradients from both forms of emb
+    G = (torch.randn((10, rows, 256), device=dev()) * (torch.rand((10, rows, 256), device=dev()) > 0.5)).bfloat16()
+    G[:, P:] = 0
+    shapes = [tuple(t.shape) for t in model.raw_tensors()]
+    res = []
+    for e, code in ((emb, _lib.SN_DTYPE_BF16_STATE), (emb16, _lib.SN_DTYPE_BF16_STATE | _lib.SN_DTYPE_EMB_BF16)):
+        nbytes = _lib.lib.sn_weight_grads_workspace_bytes(rows, code)
+        assert nbytes > 0
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev())
+        outs = [torch.full(sh, 0.25, dtype=torch.float32, device=dev()) for sh in shapes]
+        arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[o.data_ptr() for o in outs])
+        for accumulate in (0, 1):
+            _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(e), _lib.ptr(G), rows, code, _lib.ptr(ws), arr, accumulate, None), "wg")
+        torch.cuda.synchronize()
+        res.append(outs)
+    # same bf16 operands, same chunk order inside a K-range; the K-SPLIT may differ (the two forms have their own cost entries), so
+    # beyond the one-range-per-problem sizes the fp32 partial sums associate differently: 1e-6-class differences
+    for i, (a, b) in enumerate(zip(*res)):
+        assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0
+        if P <= 4096:
+            assert torch.equal(a, b), ("gradient", i, float((a - b).abs().max()))
+        else:
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), ("gradient", i, float((a - b).abs().max()), float(a.abs().max()))
+    # the flag belongs to the hand-scheduled bf16-state kernels only
+    assert _lib.lib.sn_weight_grads_workspace_bytes(rows, _lib.SN_DTYPE_BF16 | _lib.SN_DTYPE_EMB_BF16) == -4
+    rc = _lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), code16 | _lib.SN_DTYPE_COMPILER_SCHEDULED, _lib.ptr(rays_t), _lib.ptr(z_t), n, s,
+                                       _lib.ptr(out16), _lib.ptr(acts16), _lib.ptr(emb16), rows, _lib.stream_ptr())
+    assert rc == -4
+
+
+def test_training_render_gradients_do_not_depend_on_the_emb_form():
+    """a bf16 training render + backward through the Python surface with the bf16 emb (default) and with the fp32 one: same loss bit for
+    bit, same gradients up to the association of the K-split partial sums"""
+    import sinnerf_amd
+    from sinnerf_amd import autograd as A
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=5)[::131][:1000]).to(dev())
+    tgt = torch.rand((rays.shape[0], 3), device=dev())
+    grads = []
+    for emb_bf16 in (True, False):
+        coarse, _ = make_model(1, True, dtype="bf16")
+        fine, _ = make_model(2, True, dtype="bf16")
+        old = A.EMB_BF16
+        A.EMB_BF16 = emb_bf16
+        try:
+            torch.manual_seed(7)
+            res = sinnerf_amd.render_rays([coarse, fine], embeddings(), rays, 64, False, 1.0, 1.0, 64, 32768, True)
+            loss = ((res["rgb_coarse"] - tgt) ** 2).mean() + ((res["rgb_fine"] - tgt) ** 2).mean()
+            loss.backward()
+        finally:
+            A.EMB_BF16 = old
+        grads.append([loss.detach()] + [q.grad.clone() for m_ in (coarse, fine) for q in m_.parameters()])
+    assert torch.equal(grads[0][0], grads[1][0])
+    for i, (a, b) in enumerate(zip(*grads)):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-12, ("tensor", i, float((a - b).abs().max()), float(a.abs().max()))

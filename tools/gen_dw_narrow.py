@@ -8,6 +8,7 @@ contractions of models/nerf.py:66-103 that are not 256 x 256 --
     variant 3  128 x 64   dir_encoding[:, 256:]                             A = G slot 9, B = embedded directions (fp32, 64 wide)
     variant 4   32 x 256  sigma                                             A = the 32-wide head block of G slot 9, B = h8
     variant 5   32 x 128  rgb                                               A = the same block, B = dir_encoding output (128 wide)
+    variants 6, 7         variants 1, 3 with B = the embedded inputs stored as bf16 in K-slot order (64 wide)
 
 Same plan as tools/gen_dw_bf16.py (one asm statement per PAIR of chunks: counted vmcnt + barrier on entry, the reads of chunk c+1
 behind the MFMAs of chunk c, the DMA pieces of the chunks R-2 ahead, bias dot products), parameterised by the wave tiling
@@ -17,8 +18,8 @@ at 5.0 TB/s where the 256 x 256 kernel streams at 7.
 
   bf16 tiles   fragments by ds_read_b64_tr_b16 (two per 32 x 16 block), swizzled DMA image for tiles of >= 128 columns (sn_dw.hip)
   fp32 B tile  eight ds_read_b32 per block (points 8h .. 8h+7 of this lane's feature) + four v_cvt_pk_bf16_f32
-  32-wide A    a chunk's A tile is 64 sixteen-byte pieces: only wave 0 stages it -> the statement exists in two forms (W0 / WX)
-               whose DMA instruction counts, and therefore counted waits, differ
+  small tiles  a 32-wide A tile is 64 sixteen-byte pieces (wave 0 stages it), a 64-wide bf16 B tile 128 (waves 0, 1): the statement
+               then exists in two forms (W0 / WX) whose DMA instruction counts, and therefore counted waits, differ
 
 Registers of a statement: v[48:111] two fragment sets (A blocks at 48 + 32 s + 4 a, B blocks 16 further), v[112:119] address
 temporaries, v[120:127] raw fp32 B words (the compiler keeps v0..v47: two workgroups share a CU, 128 VGPRs + 128 AGPRs per wave); accumulators a[16 (NT a + b) : +15]; bs0.. column sums.
@@ -37,6 +38,8 @@ VARIANTS = {                                         # v: (MT, NT, WM, WN, B ele
     3: (2, 1, 2, 2, 4),
     4: (1, 2, 1, 4, 2),
     5: (1, 1, 1, 4, 2),
+    6: (4, 1, 2, 2, 2),                              # variants 1 / 3 with the embedded inputs stored as bf16 (SN_DTYPE_EMB_BF16):
+    7: (2, 1, 2, 2, 2),                              # a 64-wide bf16 B tile is 128 pieces -- staged by waves 0 and 1
 }
 
 
@@ -51,12 +54,21 @@ class Shape:
         self.R = min(16, r - (r & 1))                # ring depth in chunks (even: chunks are consumed in pairs)
         self.nA_pieces, self.nB_pieces = self.A_BYTES // 16, self.B_BYTES // 16
         self.nA = (self.nA_pieces + 255) // 256       # DMA instructions per thread and chunk (wave 0 when the tile is < 256 pieces)
-        self.nB = self.nB_pieces // 256
-        assert self.nB_pieces % 256 == 0 and (self.nA_pieces % 256 == 0 or self.nA_pieces == 64)
-        self.a_wave0_only = self.nA_pieces == 64
+        self.nB = (self.nB_pieces + 255) // 256
+        # a tile of fewer than 256 pieces is staged by its first waves only (64 pieces per wave): the statement then exists in two
+        # forms -- W0 for the waves that stage both tiles, WX for the others -- whose DMA counts, and counted waits, differ
+        self.a_waves = 4 if self.nA_pieces % 256 == 0 else self.nA_pieces // 64
+        self.b_waves = 4 if self.nB_pieces % 256 == 0 else self.nB_pieces // 64
+        assert self.a_waves in (1, 2, 4) and self.b_waves in (1, 2, 4) and (self.a_waves == 4 or self.b_waves == 4)
+        self.two_forms = min(self.a_waves, self.b_waves) < 4
 
-    def n_dma(self, wave0):
-        return (self.nA if (wave0 or not self.a_wave0_only) else 0) + self.nB
+    def stages(self, full):
+        """(stages A, stages B) of a wave of the full / the other class"""
+        return (full or self.a_waves == 4, full or self.b_waves == 4)
+
+    def n_dma(self, full):
+        sa, sb = self.stages(full)
+        return (self.nA if sa else 0) + (self.nB if sb else 0)
 
 
 def fa(st, a): return F0 + 32 * st + 4 * a
@@ -111,9 +123,11 @@ def half(sh, st, next_reads, g, wave0):
     fill += ["v_dot2c_f32_bf16 %%[bs%d], v%d, %%[one]" % (a, fa(st, a) + w) for a in range(sh.MT) for w in range(4)]
     if g is not None:
         pieces = []
-        if wave0 or not sh.a_wave0_only:
+        sa, sb = sh.stages(wave0)
+        if sa:
             pieces += [("ga%d" % g, "oa%d" % k, k * 4096) for k in range(sh.nA)]
-        pieces += [("gb%d" % g, "ob%d" % k, sh.A_BYTES + k * 4096) for k in range(sh.nB)]
+        if sb:
+            pieces += [("gb%d" % g, "ob%d" % k, sh.A_BYTES + k * 4096) for k in range(sh.nB)]
         for base, off, lds in pieces:                 # m0 one instruction ahead of its use
             fill += ["s_add_u32 m0, %%[md%d], %d" % (g, lds), "s_nop 0", "global_load_lds_dwordx4 %%[%s], %%[%s] nt" % (off, base)]
     # deal the fill instructions evenly behind the MFMAs
@@ -152,7 +166,7 @@ def main():
         f.write("// GENERATED by tools/gen_dw_narrow.py -- do not edit.\n")
         for v in sorted(VARIANTS):
             sh = Shape(v)
-            forms = [("W0", True)] + ([("WX", False)] if sh.a_wave0_only else [])
+            forms = [("W0", True)] + ([("WX", False)] if sh.two_forms else [])
             for tag, w0 in forms:
                 body = gen_pair(sh, w0)
                 f.write("#define SN_DWN%d_PAIR_%s_ASM \\\n" % (v, tag))
