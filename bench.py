@@ -126,10 +126,11 @@ def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
 
 
 # bf16 mixed-precision training keeps its state (activations, pre-activation gradients) in bf16 in HBM and every stage streams
-# it once: forward writes 10 x 512 B activations + 256 B ReLU sign words + 512 B embedded inputs + 16 B output per point, the
-# chain reads the sign words + the 256 B softplus tile (+ 32 B) and writes 10 x 512 B gradients (+ 16 B), the weight-gradient
-# contractions read 11 904 B -- the step is bound by HBM, not by the MFMA rate.
-TRAIN_BF16_BYTES_PER_POINT = (5120 + 256 + 512 + 16) + (256 + 256 + 32 + 5120 + 16) + 11904
+# it once: forward writes 10 x 512 B activations + 256 B ReLU sign words + 192 B embedded inputs (bf16 operands, SN_DTYPE_EMB_BF16;
+# 512 B as fp32 until round 3) + 16 B output per point, the chain reads the sign words + the 256 B softplus tile (+ 32 B) and writes
+# 10 x 512 B gradients (+ 16 B), the weight-gradient contractions read 11 520 B (11 904 with the fp32 emb) -- the step
+# is bound by HBM, not by the MFMA rate.
+TRAIN_BF16_BYTES_PER_POINT = (5120 + 256 + 192 + 16) + (256 + 256 + 32 + 5120 + 16) + 11520
 HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_ACHIEVABLE_TBS = 6.3                            # same guide: ~6.3 TB/s achievable; tools/hbm_calib.py on this pool: 6.2 read / 6.7 write / 5.2 copy
 
@@ -151,7 +152,7 @@ def train_hbm_roofline(ms_per_step, n_points):
         pass
     alg = TRAIN_BF16_BYTES_PER_POINT * n_points
     ach = alg / (ms_per_step * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "bf16 training step: mlp_fwd_bf16_kernel<STORE> + mlp_bwd_chain_bf16_kernel + dw_bf16_asm_kernel + dw_kernel (coarse + fine)",
+    return {"bound": "hbm", "kernel": "bf16 training step: mlp_fwd_bf16_t_kernel + mlp_bwd_chain_bf16_t_kernel + dw_bf16_asm_kernel + dw_narrow_bf16_asm_kernel (coarse + fine)",
             "achieved": ach, "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": ach / HBM_PEAK_TBS,
             "achievable_peak": HBM_ACHIEVABLE_TBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_TBS, "traffic": traffic,
             "traffic_note": note, "algorithmic_bytes_per_step": alg}

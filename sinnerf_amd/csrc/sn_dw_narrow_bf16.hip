@@ -37,14 +37,18 @@ SN_DEV void dwn_store_all(const Task& t, int m0, int n0, int i, int h) {
   }
 }
 
-// byte offset inside a staged W-wide bf16 tile of the 8-byte group (row, columns col .. col+3), col % 4 == 0; tiles of >= 128
-// columns are staged swizzled at 16-byte granularity (sn_dw.hip RowStager: LDS piece (row, p) holds global piece (row, p ^ 4 (row & 3)))
+// A transpose read touches 4 consecutive rows x 64 bytes per half-wave: rows a multiple of 256 B apart would sit on the same banks.
+// The DMA therefore builds a swizzled image (the LDS side of global_load_lds is lane-linear, each lane's GLOBAL address is free):
+// LDS piece (row, p) holds global 16-byte piece (row, swz(row, p)) --
+//   rows of >= 256 B (128+ columns): p ^ 4 (row & 3)        (sn_dw.hip RowStager)
+//   rows of 128 B (64 columns):      p ^ 4 ((row >> 1) & 1)  (rows r and r + 2 would collide)
+//   rows of 64 B (32 columns):       none (four rows fill the 256-byte bank window by themselves)
+template <int PER_ROW>
+SN_DEV int dwn_swz(int row, int p) { return PER_ROW >= 16 ? (p ^ (4 * (row & 3))) : PER_ROW == 8 ? (p ^ (4 * ((row >> 1) & 1))) : p; }
+// byte offset inside a staged W-wide bf16 tile of the 8-byte group (row, columns col .. col+3), col % 4 == 0
 template <int W>
 SN_DEV unsigned dwn_tr_offset(int row, int col) {
-  constexpr bool SWZ = W * 2 / 16 >= 16;
-  const int cp = col / 8;
-  const int lp = SWZ ? (cp ^ (4 * (row & 3))) : cp;
-  return (unsigned)(row * W * 2 + lp * 16 + (col * 2) % 16);
+  return (unsigned)(row * W * 2 + dwn_swz<W * 2 / 16>(row, col / 8) * 16 + (col * 2) % 16);
 }
 
 // One task of variant V.  MT x NT blocks per wave, WM x WN waves, EB = element size of the B tile (4: the embedded inputs stay fp32).
@@ -62,7 +66,6 @@ SN_DEV void dwn_task_##V(const Task& t, int tid) {                              
   constexpr int A_WAVES = CH_A % 256 == 0 ? 4 : CH_A / 64, B_WAVES = CH_B % 256 == 0 ? 4 : CH_B / 64;                              \
   constexpr int N_FULL = A_WAVES < B_WAVES ? A_WAVES : B_WAVES;                                                                    \
   static_assert(A_WAVES == 4 || B_WAVES == 4, "one of the tiles is staged by every wave");                                         \
-  constexpr bool SWZ_A = WA * 2 / 16 >= 16, SWZ_B = (EB == 2) && (WB * 2 / 16 >= 16);                                              \
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                      \
   const int i = lane & 31, h = lane >> 5;                                                                                          \
   const int wr = wave / WN, wc = wave % WN;                                                                                        \
@@ -76,12 +79,12 @@ SN_DEV void dwn_task_##V(const Task& t, int tid) {                              
   _Pragma("unroll") for (int it = 0; it < IT_A; ++it) {                                                                            \
     const int c = it * 256 + tid, per_row = WA * 2 / 16;                                                                           \
     const int row = c / per_row, lp = c % per_row;                                                                                 \
-    oa[it] = (unsigned)(row * t.lda * 2 + (SWZ_A ? (lp ^ (4 * (row & 3))) : lp) * 16);                                             \
+    oa[it] = (unsigned)(row * t.lda * 2 + dwn_swz<WA * 2 / 16>(row, lp) * 16);                                                     \
   }                                                                                                                                \
   _Pragma("unroll") for (int it = 0; it < IT_B; ++it) {                                                                            \
     const int c = it * 256 + tid, per_row = WB * EB / 16;                                                                          \
     const int row = c / per_row, lp = c % per_row;                                                                                 \
-    ob[it] = (unsigned)(row * t.ldb * EB + (SWZ_B ? (lp ^ (4 * (row & 3))) : lp) * 16);                                           \
+    ob[it] = (unsigned)(row * t.ldb * EB + (EB == 2 ? dwn_swz<WB * EB / 16>(row, lp) : lp) * 16);                                  \
   }                                                                                                                                \
   /* fragment addresses of this lane inside a slot: transpose reads (lane (q, G): feature block G & 1, point rows 8 (G >> 1) +     \
      (q >> 2)); fp32 B tile: point row 8 h of feature n0 + i */                                                                    \

@@ -16,8 +16,10 @@ P = N * S
 rows = -(-P // 256) * 256
 out = torch.empty((N, S, 4), device=dev)
 acts = torch.empty((10, rows, 256), dtype=torch.bfloat16, device=dev)
-emb = torch.empty((rows, 128), device=dev)
 flag = _lib.SN_DTYPE_COMPILER_SCHEDULED if int(os.environ.get("SINNERF_COMPILER_SCHEDULED", "0")) else 0
+emb16 = not flag and not int(os.environ.get("SINNERF_EMB_FP32", "0"))
+emb = torch.empty((rows, 128), dtype=torch.bfloat16 if emb16 else torch.float32, device=dev)
+flag |= _lib.SN_DTYPE_EMB_BF16 if emb16 else 0
 def run():
     _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m.packed()), _lib.SN_DTYPE_BF16_STATE | flag, _lib.ptr(rays), _lib.ptr(z), N, S,
                                              _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()), "fwd")
@@ -30,4 +32,5 @@ for rep in range(3):
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 20)
-print("fwd_train kernel %.4f ms  (%.2f TB/s of 5.8 KB/point)" % (best, 5800 * P / best / 1e9))
+bpp = 5120 + 256 + (192 if emb16 else 512) + 16
+print("fwd_train kernel %.4f ms  (%.2f TB/s of %d B/point)" % (best, bpp * P / best / 1e9, bpp))

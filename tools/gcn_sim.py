@@ -255,7 +255,7 @@ class Wave:
         if op == "s_barrier":
             return "barrier"
         # ---- SALU
-        if op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_subb_u32", "s_mov_b32", "s_and_b32", "s_lshl_b32", "s_mul_i32"):
+        if op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_subb_u32", "s_mov_b32", "s_and_b32", "s_lshl_b32", "s_mul_i32"):   # (destination: an SGPR or m0)
             d = _parse_reg(args[0])
             srcs = [self.rds(_parse_reg(a)) for a in args[1:]]
             if op == "s_add_u32":
@@ -356,6 +356,10 @@ class Wave:
                 r = u32(f32(S[0]) + f32(S[1]))
             elif op == "v_fmac_f32":
                 r = u32((f32(S[0]).astype(np.float64) * f32(S[1]).astype(np.float64) + f32(self.rd(d)).astype(np.float64)).astype(np.float32))
+            elif op == "v_dot2c_f32_bf16":                       # d += a.lo * b.lo + a.hi * b.hi (fp32)
+                lo = bf16_to_f32(S[0] & 0xFFFF).astype(np.float64) * bf16_to_f32(S[1] & 0xFFFF).astype(np.float64)
+                hi = bf16_to_f32(S[0] >> 16).astype(np.float64) * bf16_to_f32(S[1] >> 16).astype(np.float64)
+                r = u32((f32(self.rd(d)).astype(np.float64) + lo + hi).astype(np.float32))
             elif op == "v_fma_f32":
                 r = u32((f32(S[0]).astype(np.float64) * f32(S[1]).astype(np.float64) + f32(S[2]).astype(np.float64)).astype(np.float32))
             else:
@@ -376,6 +380,31 @@ class Wave:
             data = np.stack([lds.b[a:a + nb].view(np.uint32) for a in addr], 1)          # (nb/4, 64)
             regs = [("v", d[1] + i) for i in range(nb // 4)]
             self.wr(d, data if nb > 4 else data[0])
+            for r in regs:
+                self.vpoison[r] = True
+            self.lgkm.append(regs)
+            return None
+        if op == "ds_read_b64_tr_b16":
+            # transpose read (tools/ubench/tr_probe.hip): within a 16-lane group lane p supplies the address of 4 contiguous b16 = row
+            # (p >> 2), columns 4 (p & 3) .. +3 of a 4 x 16 block; lane q receives column q, rows 0..3:
+            #   out[16 G + q][e] = LDS16[addr(lane 16 G + 4 e + (q >> 2)) + 2 (q & 3)]
+            d = _parse_reg(args[0])
+            addr = self.rd(_parse_reg(args[1])).astype(np.int64) + mods.get("offset", 0)
+            if (addr % 8).any():
+                raise SimError("unaligned %s: %s" % (op, text))
+            if addr.min() < 0 or addr.max() + 8 > lds.b.size:
+                raise SimError("LDS address out of range: %s" % text)
+            self._lds_check(addr, 8, write=False)
+            lds.conflict(op, addr, 8)
+            el = np.zeros((4, 64), np.uint32)
+            for l in range(64):
+                Gq, q = l >> 4, l & 15
+                for e in range(4):
+                    a = int(addr[16 * Gq + 4 * e + (q >> 2)]) + 2 * (q & 3)
+                    el[e, l] = int(lds.b[a]) | (int(lds.b[a + 1]) << 8)
+            data = np.stack([el[0] | (el[1] << 16), el[2] | (el[3] << 16)], 0)
+            regs = [("v", d[1]), ("v", d[1] + 1)]
+            self.wr(d, data)
             for r in regs:
                 self.vpoison[r] = True
             self.lgkm.append(regs)

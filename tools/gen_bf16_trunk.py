@@ -53,6 +53,7 @@ KNOBS = dict(prefetch=4,        # A-fragment prefetch distance in k-steps (ring 
              nt=1,              # store mode: non-temporal hint on the row stores
              dma_early=0,       # 1: a slab's DMA pieces in consecutive gaps right behind the sync point (in FRONT of the slab's row stores)
              spread=1,          # store mode: row stores dealt into the next tile's epilogue (0: burst behind the odd tile)
+             abl_sign4=0,       # timing experiment (WRONG results): one dwordx4 sign store per FOUR tiles instead of a dword per tile
              abl_vstore=1, abl_stage=1, abl_sign=1)   # store mode timing ablations (0 = leave out: WRONG results): the global stores, the
                                 # staging round trip (swaps + LDS writes / reads + stores), the sign-word arithmetic
 
@@ -428,7 +429,11 @@ def gen(knobs):
                 for i in range(4):
                     block(pt, i)
         finish_pt(0); finish_pt(1)
-        if not copy:                                         # the tile's ReLU sign word: 256 contiguous bytes per wave
+        if not copy and K["abl_sign4"]:
+            if t % 4 == 3:
+                items.append(("vstore", "global_store_dwordx4 v%d, v[%d:%d], s[%d:%d] nt" % (ST_VSG, ST_SB, ST_SB + 3, ST_SGPR_SIGN, ST_SGPR_SIGN + 1), (), None, "post",
+                              (ST_SGPR_SIGN, ST_SGPR_SIGN + 1)))
+        elif not copy:                                       # the tile's ReLU sign word: 256 contiguous bytes per wave
             items.append(("vstore", "global_store_dword v%d, v%d, s[%d:%d] nt" % (ST_VSG, ST_SB, ST_SGPR_SIGN, ST_SGPR_SIGN + 1), (), None, "post",
                           (ST_SGPR_SIGN, ST_SGPR_SIGN + 1)))
             items.append(("valu", "v_add_u32 v%d, 512, v%d" % (ST_VSG, ST_VSG), (ST_VSG,), None, "post"))

@@ -1,0 +1,6 @@
+#!/bin/bash
+R=$PWD; mkdir -p gpurun_out
+for rep in 1 2 3; do
+for v in base pf3 sign4; do
+  printf "%-8s" $v; SINNERF_HIP_LIB=$R/build/variants/lib_$v.so timeout 100 python tools/fwd_t_time.py 2>&1 | grep kernel
+done; done 2>&1 | tee gpurun_out/fwd_sign4_ab.log
