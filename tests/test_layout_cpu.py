@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/sinnerf_hip.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert L.lib.sn_abi_version() == L.ABI_VERSION == 2
+    assert L.lib.sn_abi_version() == L.ABI_VERSION == 3
     assert L.lib.sn_packed_weights_bytes(0) == 4 * (32 * (8 * 64 + 24 * 256 + 8 * 320 + 32 * 256 + 4 * 288) + 76 * 32 + 648)
     assert L.lib.sn_error_string(-3).decode().startswith("perturb")
 
