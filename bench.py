@@ -96,7 +96,7 @@ def pmc_traffic(n_points, dtype):
     return None, None
 
 
-def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
+def train_step_record(O, dev, dtype, rays, NS, NI, reps=10):
     """fwd+bwd of render_rays on a 4096-ray batch (perturb=1, noise_std=1, MSE coarse+fine), gradients only."""
     import sinnerf_amd
     from sinnerf_amd import rendering
@@ -111,7 +111,9 @@ def train_step_record(O, dev, dtype, rays, NS, NI, reps=3):
             m.zero_grad(set_to_none=True)
         r = rendering.render_rays(models, emb, tr, NS, False, 1.0, 1.0, NI, 32768, True)
         (((r["rgb_fine"] - tgt) ** 2).mean() + ((r["rgb_coarse"] - tgt) ** 2).mean()).backward()
-    tstep(); torch.cuda.synchronize()
+    for _ in range(3):
+        tstep()
+    torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(reps):
         tstep()
@@ -433,8 +435,10 @@ def main():
     # ---- the data-parallel training leg (every rank takes part; it is the only place a collective runs) ----------------
     if not args.no_extra:
         try:
-            leg = train_dp_leg(O, dev, "bf16", rank, world, steps=max(3, min(args.steps, 10)))
-            leg_graph = train_dp_leg(O, dev, "bf16", rank, world, steps=max(3, min(args.steps, 10)), graph=True) if world == 1 else None
+            # (a 3.5 ms step: 5 warm-up + >= 20 timed steps -- a 2 + 5 run measures 7 % of ramp-up, tools/dp_leg_time.py)
+            dp_steps = max(20, min(args.steps, 100))
+            leg = train_dp_leg(O, dev, "bf16", rank, world, steps=dp_steps, warmup=5)
+            leg_graph = train_dp_leg(O, dev, "bf16", rank, world, steps=dp_steps, warmup=5, graph=True) if world == 1 else None
             leg32 = train_dp_leg(O, dev, "fp32", rank, world, steps=3) if world == 1 else None
         except AssertionError:
             raise
@@ -481,7 +485,7 @@ def main():
         for cfg in TRAIN_CFGS:
             for dt_name in ("bf16", "fp32"):
                 try:
-                    records[cfg + "_" + dt_name] = train_cfg_record(O, dev, dt_name, cfg)
+                    records[cfg + "_" + dt_name] = train_cfg_record(O, dev, dt_name, cfg, steps=8 if dt_name == "bf16" else 3, warmup=3 if dt_name == "bf16" else 2)
                 except Exception as e:              # noqa: BLE001
                     records[cfg + "_" + dt_name] = {"error": repr(e)}
                 torch.cuda.empty_cache()

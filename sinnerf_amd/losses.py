@@ -73,9 +73,10 @@ class _RenderLossFn(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         if g_total is None:
             return (None,) * 10
+        scaled = list(torch._foreach_mul(saved, g_total)) if saved else []      # one launch for all four gradients
         res = []
         for have, shape in zip(ctx.have, ctx.shapes):
-            res.append((saved.pop(0) * g_total).reshape(shape) if have else None)
+            res.append(scaled.pop(0).reshape(shape) if have else None)
         return (*res, None, None, None, None, None, None)
 
 

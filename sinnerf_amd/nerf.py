@@ -68,6 +68,21 @@ def _pack_table(device, code):
     return _PACK_TABLES[key]
 
 
+def _pack_table_bwd(device, code):
+    """(table, blob bytes) of the transposed-weight blob of ``sn_mlp_backward_chain``"""
+    bf16 = code == _lib.SN_DTYPE_BF16
+    n_entries, build, n_bytes = ((_lib.lib.sn_pack_table_entries_bwd_bf16, _lib.lib.sn_build_pack_table_bwd_bf16,
+                                  _lib.lib.sn_packed_weights_bytes_bwd_bf16) if bf16 else
+                                 (_lib.lib.sn_pack_table_entries_bwd, _lib.lib.sn_build_pack_table_bwd,
+                                  _lib.lib.sn_packed_weights_bytes_bwd))
+    key = (str(device), "bwd", code)
+    if key not in _PACK_TABLES:
+        host = torch.empty((n_entries(), 2), dtype=torch.int32)
+        _lib.check(build(ctypes.c_void_p(host.data_ptr())), "sn_build_pack_table_bwd")
+        _PACK_TABLES[key] = host.to(device)
+    return _PACK_TABLES[key], int(n_bytes())
+
+
 class NeRF(nn.Module):
     """``NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False)``.
 
@@ -157,6 +172,8 @@ class NeRF(nn.Module):
         for t in raws:
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("sinnerf_amd.NeRF: parameters must be contiguous float32 master weights")
+        if self._training_pack(raws):
+            return self._pack_both(code, raws, dev, sig)[0]
         blob = hit[0] if (hit is not None and hit[0].device == dev) else \
             torch.empty(_lib.lib.sn_packed_weights_bytes(code), dtype=torch.uint8, device=dev)
         arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[t.data_ptr() for t in raws])
@@ -166,6 +183,35 @@ class NeRF(nn.Module):
                                                 _lib.stream_ptr()), "sn_pack_weights")
         self._packed[code] = (blob, sig)
         return blob
+
+    @staticmethod
+    def _training_pack(raws):
+        return torch.is_grad_enabled() and any(t.requires_grad for t in raws)
+
+    def _pack_both(self, code, raws, dev, sig):
+        """Training: the forward blob and the transposed blob of the backward chain are re-packed after every optimizer step --
+        ONE gather launch for both (the two tables concatenated, the second one's destinations shifted behind the first blob)
+        instead of two launch-latency-bound ones per network."""
+        fwd_t = _pack_table(dev, code)
+        bwd_t, nb = _pack_table_bwd(dev, code)
+        nf = int(_lib.lib.sn_packed_weights_bytes(code))
+        off = (nf + 255) // 256 * 256
+        key = (str(dev), "both", code)
+        if key not in _PACK_TABLES:
+            shifted = bwd_t.clone()
+            shifted[:, 0] += off
+            _PACK_TABLES[key] = torch.cat([fwd_t, shifted], 0).contiguous()
+        table = _PACK_TABLES[key]
+        hit = self._packed.get(("both", code))
+        blob = hit if (hit is not None and hit.device == dev) else torch.empty(off + nb, dtype=torch.uint8, device=dev)
+        arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[t.data_ptr() for t in raws])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.sn_pack_weights(arr, _lib.ptr(table), table.shape[0], _lib.ptr(blob), code, _lib.stream_ptr()),
+                       "sn_pack_weights")
+        self._packed[("both", code)] = blob
+        self._packed[code] = (blob[:nf], sig)
+        self._packed[("bwd", code)] = (blob[off:off + nb], sig)
+        return self._packed[code][0], self._packed[("bwd", code)][0]
 
     def packed_bwd(self, dtype="fp32"):
         """Transposed-weight blob for ``sn_mlp_backward_chain`` (fp32, or bf16 operands for the mixed-precision chain),
@@ -180,19 +226,11 @@ class NeRF(nn.Module):
         hit = self._packed.get(slot)
         if hit is not None and hit[1] == sig and hit[0].device == dev:
             return hit[0]
-        bf16 = code == _lib.SN_DTYPE_BF16
-        n_entries, build, n_bytes = ((_lib.lib.sn_pack_table_entries_bwd_bf16, _lib.lib.sn_build_pack_table_bwd_bf16,
-                                      _lib.lib.sn_packed_weights_bytes_bwd_bf16) if bf16 else
-                                     (_lib.lib.sn_pack_table_entries_bwd, _lib.lib.sn_build_pack_table_bwd,
-                                      _lib.lib.sn_packed_weights_bytes_bwd))
-        key = (str(dev), "bwd", code)
-        if key not in _PACK_TABLES:
-            host = torch.empty((n_entries(), 2), dtype=torch.int32)
-            _lib.check(build(ctypes.c_void_p(host.data_ptr())), "sn_build_pack_table_bwd")
-            _PACK_TABLES[key] = host.to(dev)
-        table = _PACK_TABLES[key]
+        if self._training_pack(raws):
+            return self._pack_both(code, raws, dev, sig)[1]
+        table, n_bytes = _pack_table_bwd(dev, code)
         blob = hit[0] if (hit is not None and hit[0].device == dev) else \
-            torch.empty(n_bytes(), dtype=torch.uint8, device=dev)
+            torch.empty(n_bytes, dtype=torch.uint8, device=dev)
         arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[t.data_ptr() for t in raws])
         with torch.cuda.device(dev):
             _lib.check(_lib.lib.sn_pack_weights(arr, _lib.ptr(table), table.shape[0], _lib.ptr(blob), code,

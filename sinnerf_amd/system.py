@@ -203,7 +203,11 @@ class SinNeRFSystem(nn.Module):
     def _zero_forward_backward(self, batch):
         self.optimizer.zero_grad()
         out = self.training_step(batch)
-        out["loss"].backward()
+        loss = out["loss"]
+        unit = self.__dict__.get("_unit_grad")      # the root gradient, kept: backward() would fill a fresh ones_like every step
+        if unit is None or unit.device != loss.device or unit.dtype != loss.dtype or unit.shape != loss.shape:
+            unit = self.__dict__["_unit_grad"] = torch.ones_like(loss)
+        loss.backward(unit)
         return out
 
     def train_step(self, batch, graph=False):

@@ -41,7 +41,7 @@ out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separ
 import statistics
 for name, disp in per.items():
     mx = max(d["ms"] for d in disp.values())
-    if mx < 0.3:
+    if mx < 0.2:
         continue
     groups = {"": [d for d in disp.values() if d["ms"] > 0.6 * mx]}
     if "dw_kernel" in name and not any("dw_narrow_bf16" in n for n in per):    # (before the bf16-state narrow problems had a kernel

@@ -23,7 +23,7 @@ for tag in ("p1", "p2"):
         dur[k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     for name in sorted({k[0] for k in dur}):
         ks = [k for k in dur if k[0] == name]; mx = max(dur[k] for k in ks)
-        if mx < 0.4: continue
+        if mx < 0.25: continue
         ks = [k for k in ks if dur[k] > 0.6 * mx]
         med = lambda f: statistics.median(f(k) for k in ks)
         cyc = med(lambda k: per[k]["GRBM_GUI_ACTIVE"] / 8)
