@@ -217,3 +217,32 @@ def test_training_streams_are_deterministic_and_complete():
             for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", l):
                 regs |= set(range(int(a), int(b) + 1))
         assert min(regs) >= lo, min(regs)
+
+
+def test_bf16_emb_positions_invert_the_layout_slot_maps():
+    """SN_DTYPE_EMB_BF16 stores the embedded inputs at their K-slot positions (32 h + e / 16 h + e); sn_dw.hip's emb_xyz_pos / emb_dir_pos
+    (restated here, and in tests/test_round3_gpu.py where the device code is checked) must be the inverse of csrc/sn_layout.h's
+    slot -> column maps the packed weights are built from."""
+    from sinnerf_amd import _lib as L
+
+    def xyz_pos(c):
+        if c < 3:
+            return (30, 31, 62)[c]
+        k, h = (c - 3) % 30, (c - 3) // 30
+        return 32 * h + 2 * (3 * (k // 6) + k % 3) + (k % 6) // 3
+
+    def dir_pos(c):
+        if c < 3:
+            return (12, 13, 28)[c]
+        k, h = (c - 3) % 12, (c - 3) // 12
+        return 16 * h + 2 * (3 * (k // 6) + k % 3) + (k % 6) // 3
+
+    for c in range(63):
+        p = xyz_pos(c)
+        assert L.lib.sn_layout_xyz_slot_col(p // 32, p % 32) == c
+    for c in range(27):
+        p = dir_pos(c)
+        assert L.lib.sn_layout_dir_slot_col(p // 16, p % 16) == c
+    # the positions no column maps to are exactly the pad slots of the layout
+    assert {32 * h + e for h in (0, 1) for e in range(32) if L.lib.sn_layout_xyz_slot_col(h, e) < 0} == set(range(64)) - {xyz_pos(c) for c in range(63)}
+    assert {16 * h + e for h in (0, 1) for e in range(16) if L.lib.sn_layout_dir_slot_col(h, e) < 0} == set(range(32)) - {dir_pos(c) for c in range(27)}

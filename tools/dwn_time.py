@@ -10,7 +10,7 @@ m = sinnerf_amd.NeRF(use_new_activation=True, compute_dtype="bf16")
 m.load_state_dict({k: torch.from_numpy(v) for k, v in O.init_params(1, True).items()})
 m = m.to(dev)
 P = 4096 * 128
-acts = torch.randn((10, P, 256), device=dev).bfloat16(); G = torch.randn((10, P, 256), device=dev).bfloat16(); emb = torch.randn((P, 128), device=dev)
+acts = torch.randn((10, P, 256), device=dev).bfloat16(); G = torch.randn((10, P, 256), device=dev).bfloat16(); emb = torch.randn((P, 128), device=dev).bfloat16()
 def run(): return A._weight_grads(m, acts, emb, G, [True] * 24)
 for _ in range(3): run()
 torch.cuda.synchronize()
