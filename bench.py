@@ -128,11 +128,13 @@ def train_step_record(O, dev, dtype, rays, NS, NI, reps=10):
 
 
 # bf16 mixed-precision training keeps its state (activations, pre-activation gradients) in bf16 in HBM and every stage streams
-# it once: forward writes 10 x 512 B activations + 256 B ReLU sign words + 192 B embedded inputs (bf16 operands, SN_DTYPE_EMB_BF16;
-# 512 B as fp32 until round 3) + 16 B output per point, the chain reads the sign words + the 256 B softplus tile (+ 32 B) and writes
-# 10 x 512 B gradients (+ 16 B), the weight-gradient contractions read 11 520 B (11 904 with the fp32 emb) -- the step
-# is bound by HBM, not by the MFMA rate.
-TRAIN_BF16_BYTES_PER_POINT = (5120 + 256 + 192 + 16) + (256 + 256 + 32 + 5120 + 16) + 11520
+# it once.  Per sample point: the forward writes 9 x 512 B activations + slot 9 (256 B softplus outputs + 256 B ReLU sign words)
+# + 192 B embedded inputs (bf16 operands, SN_DTYPE_EMB_BF16; 512 B as fp32 until round 3) + 16 B output = 5 328 B; the chain reads
+# the sign words, the 256 B softplus tile and 2 x 16 B and writes 9 x 512 B + 256 B + the 64 B head block of gradients + 16 B =
+# 5 488 B; the weight-gradient contractions read 8 x 1 024 B (256 x 256 problems) + 3 328 B (the six narrow ones) = 11 520 B
+# (DESIGN.md §3).  (Through round 3's first profiles this constant double-counted slot 9's sign-word half and the unwritten part
+# of G[9]: 23 488 B; the PMC counters of the same launches see 22 860 B.)  The step is bound by HBM, not by the MFMA rate.
+TRAIN_BF16_BYTES_PER_POINT = (9 * 512 + 256 + 256 + 192 + 16) + (256 + 256 + 32 + 9 * 512 + 256 + 64 + 16) + (8 * 1024 + 3328)
 HBM_PEAK_TBS = 8.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_ACHIEVABLE_TBS = 6.3                            # same guide: ~6.3 TB/s achievable; tools/hbm_calib.py on this pool: 6.2 read / 6.7 write / 5.2 copy
 
