@@ -594,7 +594,7 @@ extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype, 
 extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const void* G, long slot_rows, int dtype, int emb16,
                                       void* workspace, float* const* grads, int accumulate, hipStream_t stream) {
   using namespace snd;
-  if (emb16 && (dtype != 2 || !SN_DW_NARROW_ASM || narrow_compiler_scheduled())) return -3;     // only the generated narrow kernel reads it
+  if (emb16 && (dtype != 2 || !SN_DW_NARROW_ASM || narrow_compiler_scheduled())) return -4;     // SN_E_UNSUPPORTED: only the generated narrow kernel reads it
   HostPlan hp;
   build_plan(hp, (const char*)acts, (const char*)emb, (const char*)G, slot_rows, dtype, emb16 != 0);
   char* ws = (char*)workspace;

@@ -1,6 +1,7 @@
-"""The GENERATED chunk-pair statements of the narrow bf16-state weight-gradient kernel (tools/gen_dw_narrow.py ->
-csrc/sn_dw_narrow_bf16.hip), executed on the CPU by tools/gcn_sim.py: one workgroup = one K-range of one problem, every one of
-the seven shapes, even and odd chunk counts, against the fp64 contraction of the same bf16 operands.  The simulator also checks what
+"""The GENERATED chunk-pair statements of the bf16-state weight-gradient kernels (tools/gen_dw_narrow.py -> csrc/sn_dw_narrow_bf16.hip;
+tools/gen_dw_bf16.py -> csrc/sn_dw_bf16.hip, shape 0 below), executed on the CPU by tools/gcn_sim.py: one workgroup = one K-range of
+one problem, the 256 x 256 shape and every one of the seven narrow ones, even and odd chunk counts, against the fp64 contraction of
+the same bf16 operands.  The simulator also checks what
 the statements promise the hardware: every counted s_waitcnt covers the LDS reads / LDS-DMA pieces it is meant to cover, a chunk is
 only read behind the barrier that follows its landing, a ring slot is only restaged after every wave has left it -- for BOTH forms of
 the statement (waves that stage both tiles / the others).  The C++ glue of the kernel (offsets, ring bookkeeping, prologue) is
@@ -30,10 +31,25 @@ def swz(per_row, row, p):
     return p ^ (4 * (row & 3)) if per_row >= 16 else p ^ (4 * ((row >> 1) & 1)) if per_row == 8 else p
 
 
+class BigShape:
+    """the 256 x 256 kernel of tools/gen_dw_bf16.py (csrc/sn_dw_bf16.hip) in the terms of gen_dw_narrow.Shape"""
+    WA = WB = 256
+    R, BUF, A_BYTES = 8, 16384, 8192
+    nA = nB = 2
+    a_waves = b_waves = 4
+
+
 def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0):
-    gen = H.load_tool("gen_dw_narrow")
-    sh = gen.Shape(v)
-    MT, NT, WM, WN, EB = gen.VARIANTS[v]
+    if v == 0:
+        gen = H.load_tool("gen_dw_bf16")
+        sh = BigShape
+        MT, NT, WM, WN, EB = 4, 4, 2, 2, 2
+        gen_pair, gen_tail = (lambda sh_, full: gen.gen()), (lambda sh_: gen.gen_tail())
+    else:
+        gen = H.load_tool("gen_dw_narrow")
+        sh = gen.Shape(v)
+        MT, NT, WM, WN, EB = gen.VARIANTS[v]
+        gen_pair, gen_tail = gen.gen_pair, gen.gen_tail
     WA, WB, R, BUF, A_BYTES = sh.WA, sh.WB, sh.R, sh.BUF, sh.A_BYTES
     ldb = 256 if WB > 128 else 128
     rs = np.random.RandomState(seed)
@@ -46,13 +62,13 @@ def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0):
         gb = rs.standard_normal((K, ldb)).astype(np.float32)
         b_val = G.bf16_to_f32(G.bf16_rne(gb))
     a_val = G.bf16_to_f32(ga.astype(np.uint32))
-    wg = G.Workgroup(4, lds_bytes=81920)
+    wg = G.Workgroup(4, lds_bytes=81920 if v else 131072)
     wg.mem.add("a", GA_BASE, data=ga.tobytes(), writable=False)
     wg.mem.add("b", GB_BASE, data=gb.tobytes(), writable=False)
     a_base, b_base = GA_BASE + a_col0 * 2, GB_BASE + b_col0 * EB
     chunk_a = lambda c: a_base + min(c, n_chunks - 1) * KB * lda * 2
     chunk_b = lambda c: b_base + min(c, n_chunks - 1) * KB * ldb * EB
-    pair_full, pair_other, tail = gen.gen_pair(sh, True), gen.gen_pair(sh, False), gen.gen_tail(sh)
+    pair_full, pair_other, tail = gen_pair(sh, True), gen_pair(sh, False), gen_tail(sh)
     zero = ["v_accvgpr_write_b32 a%d, 0" % i for i in range(16 * MT * NT)]
     n_full = min(sh.a_waves, sh.b_waves)
     programs = []
@@ -125,7 +141,7 @@ def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0):
     return wg, C, want, bias, want_bias
 
 
-@pytest.mark.parametrize("v,n_chunks", [(1, 9), (2, 8), (3, 13), (4, 11), (5, 21), (6, 10), (7, 15)])
+@pytest.mark.parametrize("v,n_chunks", [(0, 11), (0, 16), (1, 9), (2, 8), (3, 13), (4, 11), (5, 21), (6, 10), (7, 15)])
 def test_narrow_dw_statements_match_the_contraction(v, n_chunks):
     # A: the columns a 32-wide head block / a full G row starts at; B: the direction half of emb for the 128 x 64 shapes
     a_col0 = 128 if v in (4, 5) else 0
