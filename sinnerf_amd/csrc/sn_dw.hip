@@ -455,7 +455,8 @@ static const int COST_BF16[8] = {512, 189, 226, 126, 138, 125, 0, 0};          /
 // bf16 operands, bf16 state (transpose-read fragments, a sync point every 2nd / 4th chunk): the 256x256 problems run at their
 // share of the HBM rate (52 ns per point per CU = 1 KB / 19.7 GB/s), the narrower ones at 19..35 ns per point
 #ifndef SN_DW_COST_STATE
-#define SN_DW_COST_STATE 512, 343, 348, 226, 296, 190, 286, 170     // (6 / 7: variants 1 / 3 at 640 / 384 instead of 768 / 512 B per point)
+#define SN_DW_COST_STATE 512, 343, 348, 226, 261, 145, 290, 174     // (narrow shapes of the bf16-emb step, 2 / 4 / 5 / 6 / 7: their bytes per
+                                                                    //  point x 0.453 -- tools/r3_run32.sh: 0.4 % on the step against the round-2 table)
 #endif
 static const int COST_BF16_STATE[8] = {SN_DW_COST_STATE};
 constexpr int TARGET_WGS = 256;                 // one workgroup per CU

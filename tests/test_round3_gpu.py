@@ -494,3 +494,30 @@ def test_training_render_gradients_do_not_depend_on_the_emb_form():
     assert torch.equal(grads[0][0], grads[1][0])
     for i, (a, b) in enumerate(zip(*grads)):
         assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-12, ("tensor", i, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_training_pack_is_the_two_separate_packs_in_one_launch(dtype):
+    """NeRF.packed() / packed_bwd() under autograd re-pack both blobs with ONE gather launch (concatenated tables, one allocation):
+    the bytes are those of the two separate launches the no-grad path uses."""
+    model, _ = make_model(4, True, dtype=dtype)
+    with torch.no_grad():
+        fwd = model.packed().clone()
+        bwd = model.packed_bwd(dtype).clone()
+    model.invalidate_packed()
+    fwd2 = model.packed()                      # grad enabled, parameters require grad: the combined launch
+    bwd2 = model.packed_bwd(dtype)
+    torch.cuda.synchronize()
+    assert fwd2.data_ptr() % 256 == 0 and bwd2.data_ptr() % 256 == 0
+    assert bwd2.data_ptr() - fwd2.data_ptr() >= fwd2.numel()          # one allocation, the second blob behind the first
+    assert torch.equal(fwd, fwd2) and torch.equal(bwd, bwd2)
+    # an optimizer-style in-place update is noticed by both views
+    with torch.no_grad():
+        model.sigma.weight.mul_(1.5)
+    fwd3, bwd3 = model.packed(), model.packed_bwd(dtype)
+    with torch.no_grad():
+        model.invalidate_packed()
+        ref_f, ref_b = model.packed().clone(), model.packed_bwd(dtype).clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(fwd, fwd3)
+    assert torch.equal(fwd3, ref_f) and torch.equal(bwd3, ref_b)
