@@ -32,5 +32,5 @@ for rep in range(3):
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 20)
-bpp = 5120 + 256 + (192 if emb16 else 512) + 16
+bpp = 9 * 512 + 256 + 256 + (192 if emb16 else 512) + 16
 print("fwd_train kernel %.4f ms  (%.2f TB/s of %d B/point)" % (best, bpp * P / best / 1e9, bpp))
