@@ -177,3 +177,82 @@ def test_narrow_dw_checker_is_not_vacuous():
                 run_task(2, 8, seed=1)
         finally:
             H.load_tool = saved
+
+
+# ---- the fp32 256 x 256 kernel (tools/gen_dw_f32.py -> csrc/sn_dw_f32.hip): one statement per chunk, 4-slot ring -----------------
+def run_task_f32(n_chunks, seed=0, drop=None):
+    gen = H.load_tool("gen_dw_f32")
+    body = gen.gen()
+    if drop is not None:
+        idx = [k for k, l in enumerate(body) if drop(l)][0]
+        body = body[:idx] + body[idx + 1:]
+    A_BYTES, BUF, NBUF = 16384, 32768, 4
+    lda = ldb = 256
+    rs = np.random.RandomState(seed)
+    K = n_chunks * KB
+    ga = rs.standard_normal((K, lda)).astype(np.float32)
+    gb = rs.standard_normal((K, ldb)).astype(np.float32)
+    wg = G.Workgroup(4, lds_bytes=131072)
+    wg.mem.add("a", GA_BASE, data=ga.tobytes(), writable=False)
+    wg.mem.add("b", GB_BASE, data=gb.tobytes(), writable=False)
+    chunk = lambda base, c: base + min(c, n_chunks - 1) * KB * 1024
+    bind = dict(bs0="v14", bs1="v15", bs2="v16", bs3="v17", la0="v20", la1="v21", lb0="v22", lb1="v23",
+                **{"oa%d" % k: "v%d" % k for k in range(4)}, **{"ob%d" % k: "v%d" % (4 + k) for k in range(4)},
+                ga="s[22:23]", gb="s[24:25]", md="s30")
+    stmt = G.bind(body, bind)
+    programs = []
+    for w, wave in enumerate(wg.waves):
+        tid = 64 * w + LANE
+        i, h = LANE & 31, LANE >> 5
+        m0, n0 = (w >> 1) * 128, (w & 1) * 128
+        for it in range(4):
+            c = it * 256 + tid
+            wave.v[it] = (c >> 6) * lda * 4 + (c & 63) * 16
+            wave.v[4 + it] = (c >> 6) * ldb * 4 + (c & 63) * 16
+        wave.v[24] = h * 1024 + (m0 + i) * 4                    # la
+        wave.v[25] = A_BYTES + h * 1024 + (n0 + i) * 4          # lb
+        prog = []
+        def set64(reg, val):
+            prog.append("s_mov_b32 s%d, %d" % (reg, val & 0xFFFFFFFF)); prog.append("s_mov_b32 s%d, %d" % (reg + 1, val >> 32))
+        for c in range(NBUF - 1):
+            set64(40, chunk(GA_BASE, c)); set64(42, chunk(GB_BASE, c))
+            for it in range(4):
+                prog += ["s_mov_b32 m0, %d" % (c * BUF + it * 4096 + w * 1024), "global_load_lds_dwordx4 v%d, s[40:41]" % it,
+                         "s_mov_b32 m0, %d" % (c * BUF + A_BYTES + it * 4096 + w * 1024), "global_load_lds_dwordx4 v%d, s[42:43]" % (4 + it)]
+        prog += ["v_accvgpr_write_b32 a%d, 0" % r for r in range(256)]
+        for c in range(n_chunks):
+            slot = (c % NBUF) * BUF
+            prog += ["v_add_u32 v20, %d, v24" % slot, "v_add_u32 v21, %d, v24" % (slot + 128),
+                     "v_add_u32 v22, %d, v25" % slot, "v_add_u32 v23, %d, v25" % (slot + 128),
+                     "s_mov_b32 s30, %d" % (((c + NBUF - 1) % NBUF) * BUF + w * 1024)]
+            set64(22, chunk(GA_BASE, c + NBUF - 1)); set64(24, chunk(GB_BASE, c + NBUF - 1))
+            prog += stmt
+        prog += ["s_waitcnt vmcnt(0)"]
+        programs.append(prog)
+    wg.run(programs)
+    C = np.zeros((256, 256), np.float32)
+    bias = np.zeros(256, np.float32)
+    for w, wave in enumerate(wg.waves):
+        i, h = LANE & 31, LANE >> 5
+        m0, n0 = (w >> 1) * 128, (w & 1) * 128
+        for a in range(4):
+            for b in range(4):
+                for r in range(16):
+                    C[m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + 32 * b + i] = wave.a[16 * (4 * a + b) + r].view(np.float32)
+            if (w & 1) == 0:
+                bs = wave.v[14 + a].view(np.float32)
+                bias[m0 + 32 * a + np.arange(32)] = bs[:32] + bs[32:]
+    return C, ga.astype(np.float64).T @ gb.astype(np.float64), bias, ga.astype(np.float64).sum(0)
+
+
+@pytest.mark.parametrize("n_chunks", [3, 6])
+def test_fp32_dw_chunk_statement_matches_the_contraction(n_chunks):
+    C, want, bias, want_bias = run_task_f32(n_chunks, seed=n_chunks)
+    assert np.abs(C - want).max() <= 2e-6 * np.abs(want).max() * np.sqrt(n_chunks * KB)
+    assert np.abs(bias - want_bias).max() <= 1e-5 * max(1.0, np.abs(want_bias).max())
+
+
+def test_fp32_dw_checker_is_not_vacuous():
+    for drop in (lambda l: l.startswith("s_waitcnt vmcnt"), lambda l: l.startswith("s_barrier"), lambda l: l.startswith("s_waitcnt lgkmcnt")):
+        with pytest.raises(G.SimError):
+            run_task_f32(6, seed=1, drop=drop)

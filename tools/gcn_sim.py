@@ -294,6 +294,20 @@ class Wave:
                 out[r] = (C[r].astype(np.float64) + D[(r & 3) + 8 * (r >> 2) + 4 * LH, LJ]).astype(np.float32)
             self.wr(d, u32(out))
             return None
+        if op == "v_mfma_f32_32x32x2_f32":                   # fp32 operands, K = 2: lane (i, h) holds A[i][h] and B[h][i]
+            d, a_, b_, c_ = (_parse_reg(x) for x in args)
+            assert d[2] == 16 and a_[2] == 1 and b_[2] == 1 and c_[2] == 16, text
+            A, B = f32(self.rd(a_)).astype(np.float64), f32(self.rd(b_)).astype(np.float64)
+            C = f32(self.rd(c_)).astype(np.float64)
+            Am = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+            Am[LJ, LH] = A
+            Bm[LH, LJ] = B
+            D = Am @ Bm
+            out = np.empty((16, 64), np.float32)
+            for r in range(16):
+                out[r] = (C[r] + D[(r & 3) + 8 * (r >> 2) + 4 * LH, LJ]).astype(np.float32)
+            self.wr(d, u32(out))
+            return None
         # ---- VALU
         if op == "v_permlane32_swap_b32":                    # vdst lanes 32..63 <-> src0 lanes 0..31 (both registers are written)
             d, s0 = _parse_reg(args[0]), _parse_reg(args[1])
@@ -380,6 +394,23 @@ class Wave:
             data = np.stack([lds.b[a:a + nb].view(np.uint32) for a in addr], 1)          # (nb/4, 64)
             regs = [("v", d[1] + i) for i in range(nb // 4)]
             self.wr(d, data if nb > 4 else data[0])
+            for r in regs:
+                self.vpoison[r] = True
+            self.lgkm.append(regs)
+            return None
+        if op == "ds_read2st64_b32":                         # two dwords, offsets in units of 64 dwords
+            d = _parse_reg(args[0])
+            base = self.rd(_parse_reg(args[1])).astype(np.int64)
+            regs, rows = [], []
+            for k, key in enumerate(("offset0", "offset1")):
+                addr = base + 256 * mods.get(key, 0)
+                if (addr % 4).any() or addr.min() < 0 or addr.max() + 4 > lds.b.size:
+                    raise SimError("bad LDS address: %s" % text)
+                self._lds_check(addr, 4, write=False)
+                lds.conflict(op, addr, 4)
+                rows.append(np.array([lds.b[a:a + 4].view(np.uint32)[0] for a in addr], np.uint32))
+                regs.append(("v", d[1] + k))
+            self.wr(d, np.stack(rows, 0))
             for r in regs:
                 self.vpoison[r] = True
             self.lgkm.append(regs)
