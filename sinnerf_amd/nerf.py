@@ -186,7 +186,8 @@ class NeRF(nn.Module):
 
     @staticmethod
     def _training_pack(raws):
-        return torch.is_grad_enabled() and any(t.requires_grad for t in raws)
+        # (not torch.is_grad_enabled(): the blobs are requested inside autograd.Function.forward, where grad mode is off)
+        return any(t.requires_grad for t in raws)
 
     def _pack_both(self, code, raws, dev, sig):
         """Training: the forward blob and the transposed blob of the backward chain are re-packed after every optimizer step --

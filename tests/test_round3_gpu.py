@@ -501,11 +501,16 @@ def test_training_pack_is_the_two_separate_packs_in_one_launch(dtype):
     """NeRF.packed() / packed_bwd() under autograd re-pack both blobs with ONE gather launch (concatenated tables, one allocation):
     the bytes are those of the two separate launches the no-grad path uses."""
     model, _ = make_model(4, True, dtype=dtype)
-    with torch.no_grad():
-        fwd = model.packed().clone()
-        bwd = model.packed_bwd(dtype).clone()
+    for q in model.parameters():               # frozen parameters: the two blobs are packed by separate launches
+        q.requires_grad_(False)
+    fwd = model.packed().clone()
+    bwd = model.packed_bwd(dtype).clone()
+    assert not any(isinstance(k, tuple) and k[0] == "both" for k in model._packed)
+    for q in model.parameters():
+        q.requires_grad_(True)
     model.invalidate_packed()
-    fwd2 = model.packed()                      # grad enabled, parameters require grad: the combined launch
+    with torch.no_grad():                      # (autograd.Function.forward runs with grad mode off: must not matter)
+        fwd2 = model.packed()                  # trainable parameters: the combined launch
     bwd2 = model.packed_bwd(dtype)
     torch.cuda.synchronize()
     assert fwd2.data_ptr() % 256 == 0 and bwd2.data_ptr() % 256 == 0
@@ -514,10 +519,11 @@ def test_training_pack_is_the_two_separate_packs_in_one_launch(dtype):
     # an optimizer-style in-place update is noticed by both views
     with torch.no_grad():
         model.sigma.weight.mul_(1.5)
-    fwd3, bwd3 = model.packed(), model.packed_bwd(dtype)
-    with torch.no_grad():
-        model.invalidate_packed()
-        ref_f, ref_b = model.packed().clone(), model.packed_bwd(dtype).clone()
+    fwd3, bwd3 = model.packed().clone(), model.packed_bwd(dtype).clone()      # (combined launch again)
+    for q in model.parameters():
+        q.requires_grad_(False)
+    model.invalidate_packed()
+    ref_f, ref_b = model.packed().clone(), model.packed_bwd(dtype).clone()
     torch.cuda.synchronize()
     assert not torch.equal(fwd, fwd3)
     assert torch.equal(fwd3, ref_f) and torch.equal(bwd3, ref_b)
