@@ -156,6 +156,15 @@ def test_narrow_dw_statements_match_the_contraction(v, n_chunks):
     assert st is not None and st[1] == 2 * st[0], st
 
 
+@pytest.mark.parametrize("v,n_chunks", [(0, 1), (0, 2), (2, 1), (5, 2), (5, 3), (6, 1), (7, 3)])
+def test_dw_statements_on_k_ranges_shorter_than_the_ring(v, n_chunks):
+    """one to three chunks per K-range (tiny batches: every ring slot but the first is a clamped re-read of the last chunk): the tail
+    statement alone, one pair, pair + tail"""
+    wg, C, want, bias, want_bias = run_task(v, n_chunks, seed=10 * v + n_chunks, a_col0=128 if v in (4, 5) else 0, b_col0=64 if v in (3, 7) else 0)
+    assert np.abs(C - want).max() <= 2e-6 * max(1.0, np.abs(want).max()) * np.sqrt(n_chunks * KB)
+    assert np.abs(bias - want_bias).max() <= 1e-5 * max(1.0, np.abs(want_bias).max())
+
+
 def test_narrow_dw_checker_is_not_vacuous():
     """dropping the counted vmcnt wait of a pair / its barrier / the lgkmcnt wait in front of the second half is caught"""
     gen = H.load_tool("gen_dw_narrow")
