@@ -170,6 +170,103 @@ SN_DEV void dwn_task_##V(const Task& t, int tid) {                              
   }                                                                                                                                \
 }
 
+// The same task with NCH = 4 chunks per sync point (tools/gen_dw_narrow.py QUAD: the shapes whose chunks are 5 - 6 KB; a workgroup's
+// streaming rate follows the bytes it consumes per barrier).  One A and one B DMA piece per thread and chunk (bf16 tiles only).
+#define SN_DWN_TASK_Q(V, MT_, NT_, WM_, WN_)                                                                                      \
+SN_DEV void dwn_task_##V(const Task& t, int tid) {                                                                                 \
+  constexpr int MT = MT_, NT = NT_, WM = WM_, WN = WN_, EB = 2, NCH = SN_DWN##V##_NCH;                                             \
+  constexpr int WA = WM * MT * 32, WB = WN * NT * 32;                                                                              \
+  constexpr int A_BYTES = KB * WA * 2, B_BYTES = KB * WB * EB, BUF = A_BYTES + B_BYTES;                                            \
+  constexpr int R = SN_DWN##V##_RING;                                                                                              \
+  static_assert(BUF == SN_DWN##V##_BUF && R * BUF <= DWN_LDS_BYTES && R % NCH == 0 && R >= 3 * NCH && NCH == 4 && MT <= 2 && NT == 1, "generated statement"); \
+  constexpr int CH_A = A_BYTES / 16, CH_B = B_BYTES / 16;                                                                          \
+  static_assert(CH_A <= 256 && CH_B <= 256, "one DMA piece per thread, tile and chunk");                                           \
+  constexpr int A_WAVES = CH_A / 64, B_WAVES = CH_B / 64;                                                                          \
+  constexpr int N_FULL = A_WAVES < B_WAVES ? A_WAVES : B_WAVES;                                                                    \
+  static_assert(A_WAVES == 4 || B_WAVES == 4, "one of the tiles is staged by every wave");                                         \
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                      \
+  const int i = lane & 31, h = lane >> 5;                                                                                          \
+  const int wr = wave / WN, wc = wave % WN;                                                                                        \
+  const int m0 = wr * MT * 32, n0 = wc * NT * 32;                                                                                  \
+  const long k0 = t.k0, k1 = t.k1;                                                                                                 \
+  if (k0 >= k1) return;                                                                                                            \
+  const int n_chunks = (int)((k1 - k0) / KB);                                                                                      \
+  const int n_groups = n_chunks / NCH;                                                                                             \
+  unsigned oa, ob;                                                                                                                 \
+  {                                                                                                                                \
+    int per_row = WA * 2 / 16, row = tid / per_row, lp = tid % per_row;                                                            \
+    oa = (unsigned)(row * t.lda * 2 + dwn_swz<WA * 2 / 16>(row, lp) * 16);                                                         \
+    per_row = WB * 2 / 16; row = tid / per_row; lp = tid % per_row;                                                                \
+    ob = (unsigned)(row * t.ldb * 2 + dwn_swz<WB * 2 / 16>(row, lp) * 16);                                                         \
+  }                                                                                                                                \
+  unsigned ta[2] = {0u, 0u}, tb;                                                                                                   \
+  {                                                                                                                                \
+    const int q = lane & 15, G = lane >> 4;                                                                                        \
+    _Pragma("unroll") for (int a = 0; a < MT; ++a) ta[a] = dwn_tr_offset<WA>(8 * (G >> 1) + (q >> 2), m0 + 32 * a + 16 * (G & 1) + 4 * (q & 3)); \
+    tb = dwn_tr_offset<WB>(8 * (G >> 1) + (q >> 2), n0 + 16 * (G & 1) + 4 * (q & 3)) + A_BYTES;                                    \
+  }                                                                                                                                \
+  const char* ga_base = reinterpret_cast<const char*>(t.a);                                                                        \
+  const char* gb_base = reinterpret_cast<const char*>(t.b);                                                                        \
+  auto chunk_a = [&](long k) __attribute__((always_inline)) { const long kc = k < k1 ? k : k1 - KB; return ga_base + kc * t.lda * 2; };   \
+  auto chunk_b = [&](long k) __attribute__((always_inline)) { const long kc = k < k1 ? k : k1 - KB; return gb_base + kc * t.ldb * 2; };   \
+  _Pragma("unroll") for (int c = 0; c < R - NCH; ++c) {                                                                            \
+    if (wave < A_WAVES)                                                                                                            \
+      __builtin_amdgcn_global_load_lds((gbl_cvoid*)(chunk_a(k0 + (long)c * KB) + oa), (lds_void*)(size_t)(c * BUF + wave * 1024), 16, 0, 2);            \
+    if (wave < B_WAVES)                                                                                                            \
+      __builtin_amdgcn_global_load_lds((gbl_cvoid*)(chunk_b(k0 + (long)c * KB) + ob), (lds_void*)(size_t)(c * BUF + A_BYTES + wave * 1024), 16, 0, 2);  \
+  }                                                                                                                                \
+  asm volatile(SN_DWN##V##_ZERO_ASM ::: SN_DWN_AGPR_CLOBBERS);                                                                     \
+  float bs0 = 0.0f, bs1 = 0.0f;                                                                                                    \
+  unsigned one = 0x3f803f80u;                                                                                                      \
+  asm volatile("" : "+v"(one));                                                                                                    \
+  int s0 = 0;                                      /* ring slot of the group's first chunk (R % NCH == 0: no wrap inside a group) */ \
+  _Pragma("unroll 1") for (int g = 0; g < n_groups; ++g) {                                                                         \
+    const int sn = s0 >= NCH ? s0 - NCH : s0 + R - NCH;          /* slots of the group R - NCH chunks ahead = those of the previous group */ \
+    const unsigned sl0 = (unsigned)s0 * BUF, sl1 = sl0 + BUF, sl2 = sl0 + 2 * BUF, sl3 = sl0 + 3 * BUF;                            \
+    const unsigned md0 = (unsigned)sn * BUF + (unsigned)wave * 1024u, md1 = md0 + BUF, md2 = md0 + 2 * BUF, md3 = md0 + 3 * BUF;   \
+    const long kn = k0 + (long)(NCH * g + R - NCH) * KB;                                                                           \
+    const char* ga0 = chunk_a(kn); const char* gb0 = chunk_b(kn);                                                                  \
+    const char* ga1 = chunk_a(kn + KB); const char* gb1 = chunk_b(kn + KB);                                                        \
+    const char* ga2 = chunk_a(kn + 2 * KB); const char* gb2 = chunk_b(kn + 2 * KB);                                                \
+    const char* ga3 = chunk_a(kn + 3 * KB); const char* gb3 = chunk_b(kn + 3 * KB);                                                \
+    if (wave < N_FULL) {                                                                                                           \
+      asm volatile(SN_DWN##V##_GROUP_W0_ASM                                                                                        \
+                   : [bs0] "+v"(bs0), [bs1] "+v"(bs1)                                                                              \
+                   : [ta0] "v"(ta[0]), [ta1] "v"(ta[1]), [tb0] "v"(tb), [one] "v"(one), [oa0] "v"(oa), [ob0] "v"(ob),              \
+                     [sl0] "s"(sl0), [sl1] "s"(sl1), [sl2] "s"(sl2), [sl3] "s"(sl3),                                               \
+                     [ga0] "s"(ga0), [gb0] "s"(gb0), [ga1] "s"(ga1), [gb1] "s"(gb1), [ga2] "s"(ga2), [gb2] "s"(gb2), [ga3] "s"(ga3), [gb3] "s"(gb3), \
+                     [md0] "s"(md0), [md1] "s"(md1), [md2] "s"(md2), [md3] "s"(md3)                                                \
+                   : SN_DWN_VGPR_CLOBBERS, SN_DWN_AGPR_CLOBBERS, "memory", "scc");                                                 \
+    } else {                                                                                                                       \
+      asm volatile(SN_DWN##V##_GROUP_WX_ASM                                                                                        \
+                   : [bs0] "+v"(bs0), [bs1] "+v"(bs1)                                                                              \
+                   : [ta0] "v"(ta[0]), [ta1] "v"(ta[1]), [tb0] "v"(tb), [one] "v"(one), [oa0] "v"(oa), [ob0] "v"(ob),              \
+                     [sl0] "s"(sl0), [sl1] "s"(sl1), [sl2] "s"(sl2), [sl3] "s"(sl3),                                               \
+                     [ga0] "s"(ga0), [gb0] "s"(gb0), [ga1] "s"(ga1), [gb1] "s"(gb1), [ga2] "s"(ga2), [gb2] "s"(gb2), [ga3] "s"(ga3), [gb3] "s"(gb3), \
+                     [md0] "s"(md0), [md1] "s"(md1), [md2] "s"(md2), [md3] "s"(md3)                                                \
+                   : SN_DWN_VGPR_CLOBBERS, SN_DWN_AGPR_CLOBBERS, "memory", "scc");                                                 \
+    }                                                                                                                              \
+    s0 = (s0 + NCH == R) ? 0 : s0 + NCH;                                                                                           \
+  }                                                                                                                                \
+  _Pragma("unroll 1") for (int c = n_groups * NCH; c < n_chunks; ++c) {     /* up to three left-over chunks (staged long ago), one at a time */ \
+    const unsigned sl0 = (unsigned)s0 * BUF;                                                                                       \
+    asm volatile(SN_DWN##V##_TAIL_ASM                                                                                              \
+                 : [bs0] "+v"(bs0), [bs1] "+v"(bs1)                                                                                \
+                 : [ta0] "v"(ta[0]), [ta1] "v"(ta[1]), [tb0] "v"(tb), [one] "v"(one), [sl0] "s"(sl0)                               \
+                 : SN_DWN_VGPR_CLOBBERS, SN_DWN_AGPR_CLOBBERS, "memory", "scc");                                                   \
+    s0 = (s0 + 1 == R) ? 0 : s0 + 1;                                                                                              \
+  }                                                                                                                                \
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");                                                         \
+  dwn_store_all<MT, NT, 0>(t, m0, n0, i, h);                                                                                       \
+  if (t.bias != nullptr && wc == 0) {                                                                                              \
+    const float b[2] = {bs0, bs1};                                                                                                 \
+    _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                                                               \
+      const float v = b[a] + __shfl_xor(b[a], 32, 64);                                                                             \
+      if (h == 0) t.bias[m0 + 32 * a + i] = v;                                                                                     \
+    }                                                                                                                              \
+  }                                                                                                                                \
+}
+
 // the PAIR_WX form only exists for the variants whose A tile is staged by wave 0 alone
 #define SN_DWN1_PAIR_WX_ASM SN_DWN1_PAIR_W0_ASM
 #define SN_DWN2_PAIR_WX_ASM SN_DWN2_PAIR_W0_ASM
@@ -179,9 +276,17 @@ SN_DWN_TASK(1, 4, 1, 2, 2, 4)
 SN_DWN_TASK(2, 2, 4, 2, 2, 2)
 SN_DWN_TASK(3, 2, 1, 2, 2, 4)
 SN_DWN_TASK(4, 1, 2, 1, 4, 2)
+#ifdef SN_DWN_NO_QUAD                            // (A/B build: two chunks per sync point for every shape)
 SN_DWN_TASK(5, 1, 1, 1, 4, 2)
+#else
+SN_DWN_TASK_Q(5, 1, 1, 1, 4)
+#endif
 SN_DWN_TASK(6, 4, 1, 2, 2, 2)
+#ifdef SN_DWN_NO_QUAD
 SN_DWN_TASK(7, 2, 1, 2, 2, 2)
+#else
+SN_DWN_TASK_Q(7, 2, 1, 2, 2)
+#endif
 
 __global__ void __launch_bounds__(256, 2) dw_narrow_bf16_asm_kernel(const Plan plan) {
   asm volatile("" ::: "a0", "a127");               // the hand-managed accumulator file

@@ -39,7 +39,7 @@ class BigShape:
     a_waves = b_waves = 4
 
 
-def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0):
+def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0, pairs_only=False):
     if v == 0:
         gen = H.load_tool("gen_dw_bf16")
         sh = BigShape
@@ -71,6 +71,9 @@ def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0):
     pair_full, pair_other, tail = gen_pair(sh, True), gen_pair(sh, False), gen_tail(sh)
     zero = ["v_accvgpr_write_b32 a%d, 0" % i for i in range(16 * MT * NT)]
     n_full = min(sh.a_waves, sh.b_waves)
+    nch = getattr(gen, "QUAD", {}).get(v, 2) if (v and not pairs_only) else 2      # chunks per sync point (csrc: SN_DWN_TASK_Q)
+    if nch != 2:
+        pair_full, pair_other = gen.gen_group(sh, True, nch), gen.gen_group(sh, False, nch)
     programs = []
     for w, wave in enumerate(wg.waves):
         tid = 64 * w + LANE
@@ -98,7 +101,7 @@ def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0):
         def set64(reg, val):
             prog.append("s_mov_b32 s%d, %d" % (reg, val & 0xFFFFFFFF)); prog.append("s_mov_b32 s%d, %d" % (reg + 1, val >> 32))
         # prologue: R - 2 chunks in flight
-        for c in range(R - 2):
+        for c in range(R - nch):
             set64(40, chunk_a(c)); set64(42, chunk_b(c))
             if w < sh.a_waves:
                 for it in range(sh.nA):
@@ -108,16 +111,31 @@ def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0):
                     prog += ["s_mov_b32 m0, %d" % (c * BUF + A_BYTES + it * 4096 + w * 1024), "global_load_lds_dwordx4 v%d, s[42:43]" % (2 + it)]
         prog += zero
         s0 = 0
-        for p in range(n_chunks // 2):
-            c = 2 * p
-            sn0 = s0 - 2 if s0 + R - 2 >= R else s0 + R - 2
-            prog += ["s_mov_b32 s20, %d" % (s0 * BUF), "s_mov_b32 s21, %d" % ((s0 + 1) * BUF),
-                     "s_mov_b32 s30, %d" % (sn0 * BUF + w * 1024), "s_mov_b32 s31, %d" % ((sn0 + 1) * BUF + w * 1024)]
-            set64(22, chunk_a(c + R - 2)); set64(24, chunk_b(c + R - 2)); set64(26, chunk_a(c + R - 1)); set64(28, chunk_b(c + R - 1))
-            prog += G.bind(pair_full if w < n_full else pair_other, BIND)
-            s0 = 0 if s0 + 2 == R else s0 + 2
-        if n_chunks & 1:
-            prog += ["s_mov_b32 s20, %d" % (s0 * BUF)] + G.bind(tail, BIND)
+        if nch == 2:
+            for p in range(n_chunks // 2):
+                c = 2 * p
+                sn0 = s0 - 2 if s0 + R - 2 >= R else s0 + R - 2
+                prog += ["s_mov_b32 s20, %d" % (s0 * BUF), "s_mov_b32 s21, %d" % ((s0 + 1) * BUF),
+                         "s_mov_b32 s30, %d" % (sn0 * BUF + w * 1024), "s_mov_b32 s31, %d" % ((sn0 + 1) * BUF + w * 1024)]
+                set64(22, chunk_a(c + R - 2)); set64(24, chunk_b(c + R - 2)); set64(26, chunk_a(c + R - 1)); set64(28, chunk_b(c + R - 1))
+                prog += G.bind(pair_full if w < n_full else pair_other, BIND)
+                s0 = 0 if s0 + 2 == R else s0 + 2
+            if n_chunks & 1:
+                prog += ["s_mov_b32 s20, %d" % (s0 * BUF)] + G.bind(tail, BIND)
+        else:
+            # SN_DWN_TASK_Q: groups of nch chunks, then the left-over chunks one tail statement at a time
+            qbind = dict(BIND, sl2="s32", sl3="s33", md2="s34", md3="s35", ga2="s[44:45]", gb2="s[46:47]", ga3="s[48:49]", gb3="s[50:51]")
+            stmt = G.bind(pair_full if w < n_full else pair_other, qbind)
+            for g_ in range(n_chunks // nch):
+                sn = s0 - nch if s0 >= nch else s0 + R - nch
+                for k, (sl, md, ga_, gb_) in enumerate(((20, 30, 22, 24), (21, 31, 26, 28), (32, 34, 44, 46), (33, 35, 48, 50))):
+                    prog += ["s_mov_b32 s%d, %d" % (sl, (s0 + k) * BUF), "s_mov_b32 s%d, %d" % (md, (sn + k) * BUF + w * 1024)]
+                    set64(ga_, chunk_a(nch * g_ + R - nch + k)); set64(gb_, chunk_b(nch * g_ + R - nch + k))
+                prog += stmt
+                s0 = 0 if s0 + nch == R else s0 + nch
+            for c in range(n_chunks // nch * nch, n_chunks):
+                prog += ["s_mov_b32 s20, %d" % (s0 * BUF)] + G.bind(tail, BIND)
+                s0 = 0 if s0 + 1 == R else s0 + 1
         prog += ["s_waitcnt vmcnt(0)"]
         programs.append(prog)
     wg.run(programs)
@@ -141,7 +159,7 @@ def run_task(v, n_chunks, seed=0, lda=256, a_col0=0, b_col0=0):
     return wg, C, want, bias, want_bias
 
 
-@pytest.mark.parametrize("v,n_chunks", [(0, 11), (0, 16), (1, 9), (2, 8), (3, 13), (4, 11), (5, 21), (6, 10), (7, 15)])
+@pytest.mark.parametrize("v,n_chunks", [(0, 11), (0, 16), (1, 9), (2, 8), (3, 13), (4, 11), (5, 21), (5, 32), (6, 10), (7, 15), (7, 26)])
 def test_narrow_dw_statements_match_the_contraction(v, n_chunks):
     # A: the columns a 32-wide head block / a full G row starts at; B: the direction half of emb for the 128 x 64 shapes
     a_col0 = 128 if v in (4, 5) else 0
@@ -156,7 +174,7 @@ def test_narrow_dw_statements_match_the_contraction(v, n_chunks):
     assert st is not None and st[1] == 2 * st[0], st
 
 
-@pytest.mark.parametrize("v,n_chunks", [(0, 1), (0, 2), (2, 1), (5, 2), (5, 3), (6, 1), (7, 3)])
+@pytest.mark.parametrize("v,n_chunks", [(0, 1), (0, 2), (2, 1), (5, 2), (5, 3), (5, 4), (5, 7), (6, 1), (7, 3), (7, 5)])
 def test_dw_statements_on_k_ranges_shorter_than_the_ring(v, n_chunks):
     """one to three chunks per K-range (tiny batches: every ring slot but the first is a clamped re-read of the last chunk): the tail
     statement alone, one pair, pair + tail"""

@@ -26,7 +26,7 @@ for P in (256 * 3, 4096 * 16 + 256, 4096 * 128):      # a task of 3 chunks / odd
     g = torch.Generator(device=dev).manual_seed(P)
     acts = torch.randn((10, P, 256), device=dev, generator=g).bfloat16()
     G = torch.randn((10, P, 256), device=dev, generator=g).bfloat16()
-    emb = torch.randn((P, 128), device=dev, generator=g)
+    emb = torch.randn((P, 128), device=dev, generator=g).bfloat16()      # SN_DTYPE_EMB_BF16 form: the 64-wide bf16 shapes
     out += [x.float().cpu() for x in A._weight_grads(m, acts, emb, G, [True] * 24)]
 torch.cuda.synchronize()
 torch.save(out, sys.argv[1])

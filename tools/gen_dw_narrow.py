@@ -154,6 +154,31 @@ def gen_pair(sh, wave0):
     return out
 
 
+def gen_group(sh, wave0, nch):
+    """nch chunks per sync point (the shapes whose chunks are small: a workgroup's streaming rate follows the bytes it consumes per
+    barrier).  Entry: the nch chunks of this group have landed -- R - 2 nch younger ones may be in flight; chunk k+1's fragments are
+    read behind the MFMAs of chunk k; the DMA pieces of chunk k of the group R - nch ahead go out in half k."""
+    assert sh.R % nch == 0 and sh.R >= 3 * nch
+    n = sh.n_dma(wave0)
+    assert (sh.R - 2 * nch) * n <= 63
+    out = ["s_waitcnt vmcnt(%d)" % ((sh.R - 2 * nch) * n), "s_barrier"]
+    out += addr_adds(sh, "sl0") + reads(sh, 0) + ["s_waitcnt lgkmcnt(0)"] + cvts(sh, 0)
+    for k in range(nch):
+        st = k & 1
+        last = k + 1 == nch
+        if not last:
+            out += addr_adds(sh, "sl%d" % (k + 1))
+        if sh.EB == 4:
+            out += ["s_nop 1"]
+        out += half(sh, st, not last, k, wave0)
+        if not last:
+            out += ["s_waitcnt lgkmcnt(0)"] + cvts(sh, st ^ 1)
+    return out
+
+
+QUAD = {5: 4, 7: 4}                                  # variant -> chunks per sync point (default 2: gen_pair)
+
+
 def gen_tail(sh):
     out = ["s_waitcnt vmcnt(0)", "s_barrier"] + addr_adds(sh, "sl0") + reads(sh, 0) + ["s_waitcnt lgkmcnt(0)"] + cvts(sh, 0)
     if sh.EB == 4:
@@ -173,6 +198,13 @@ def main():
                 for l in body:
                     f.write('  "%s\\n\\t" \\\n' % l)
                 f.write('  ""\n')
+            if v in QUAD:
+                for tag, w0 in forms:
+                    f.write("#define SN_DWN%d_GROUP_%s_ASM \\\n" % (v, tag))
+                    for l in gen_group(sh, w0, QUAD[v]):
+                        f.write('  "%s\\n\\t" \\\n' % l)
+                    f.write('  ""\n')
+                f.write("#define SN_DWN%d_NCH %d\n" % (v, QUAD[v]))
             f.write("#define SN_DWN%d_TAIL_ASM \\\n" % v)
             for l in gen_tail(sh):
                 f.write('  "%s\\n\\t" \\\n' % l)
