@@ -22,6 +22,18 @@ COMPILER_SCHEDULED = bool(int(__import__("os").environ.get("SINNERF_COMPILER_SCH
 EMB_BF16 = not bool(int(__import__("os").environ.get("SINNERF_EMB_FP32", "0")))    # A/B: keep the fp32 column-order emb
 
 
+_EMB16_OK = None
+
+
+def _emb16_supported():
+    """the library is asked, once: with SINNERF_DW_NARROW_COMPILER=1 (or a build without the generated narrow kernel) no
+    weight-gradient kernel reads a bf16 `emb`, and the forward must not store one"""
+    global _EMB16_OK
+    if _EMB16_OK is None:
+        _EMB16_OK = _lib.lib.sn_weight_grads_workspace_bytes(256, _lib.SN_DTYPE_BF16_STATE | _lib.SN_DTYPE_EMB_BF16) >= 0
+    return _EMB16_OK
+
+
 def _sched_flag():
     return _lib.SN_DTYPE_COMPILER_SCHEDULED if COMPILER_SCHEDULED else 0
 
@@ -116,7 +128,7 @@ class _MLPFn(torch.autograd.Function):
             # blocks that _weight_grads slices away ([:, :63], [:, :27]) -- a contraction's output column depends on its own
             # X column only
             # bf16 state on the hand-scheduled kernels: emb holds the bf16 operands themselves (SN_DTYPE_EMB_BF16, K-slot order)
-            emb16 = bf16 and EMB_BF16 and not COMPILER_SCHEDULED and P < 2 ** 31 - 256
+            emb16 = bf16 and EMB_BF16 and not COMPILER_SCHEDULED and P < 2 ** 31 - 256 and _emb16_supported()
             emb = torch.empty((rows, 128), dtype=torch.bfloat16 if emb16 else torch.float32, device=dev)
             flags = _sched_flag() | (_lib.SN_DTYPE_EMB_BF16 if emb16 else 0)
             _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code) | flags, _lib.ptr(rays), _lib.ptr(z_vals), n, s,

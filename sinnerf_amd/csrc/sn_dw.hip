@@ -520,11 +520,6 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
   for (int i = 0; i < n; ++i) group[i] = (split_launch && pr[i].var != 0) ? 1 : 0;
   hp.two_launches = split_launch;
   int splits[MAX_PROBS];
-#ifdef SN_DW_ONLY_VARIANT                        // timing experiment (WRONG gradients): the narrow launch streams ONE shape only -- the other
-  int cost_only[8];                              // narrow problems shrink to a single chunk (tools/build_variant_dw.sh)
-  for (int v = 0; v < 8; ++v) cost_only[v] = (v == 0 || v == SN_DW_ONLY_VARIANT) ? cost[v] : 0;
-  cost = cost_only;
-#endif
   for (int gsel = 0; gsel < 2; ++gsel) {
     double tot = 0;
     for (int i = 0; i < n; ++i) if (group[i] == gsel) tot += cost[pr[i].var];
@@ -560,9 +555,6 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
     const long gran = (dtype == 2 && pr[i].var == 0) ? 2 * KB : KB;      // sn_dw_bf16.hip consumes chunk PAIRS (an odd tail
     per = (per + gran - 1) / gran * gran;                                // chunk of the last K-range costs a statement of its own)
     ns = (rows + per - 1) / per;
-#ifdef SN_DW_ONLY_VARIANT
-    if (group[i] == 1 && pr[i].var != SN_DW_ONLY_VARIANT) { ns = 1; per = KB; }
-#endif
     const VariantInfo v = VARIANTS[pr[i].var];
     Prob& q = hp.plan.p[i];
     q.a = pr[i].a; q.b = pr[i].b; q.c = nullptr; q.bias = nullptr;
@@ -595,6 +587,9 @@ static bool narrow_compiler_scheduled() {
 }
 
 extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype, int emb16) {
+  // the same refusal as the launch below: a caller that asks here first (sinnerf_amd/autograd.py does) never stores a bf16 emb
+  // that the backward cannot read
+  if (emb16 && (dtype != 2 || !SN_DW_NARROW_ASM || narrow_compiler_scheduled())) return -4;
   snd::HostPlan hp;
   snd::build_plan(hp, nullptr, nullptr, nullptr, slot_rows, dtype, emb16 != 0);
   return hp.bytes;

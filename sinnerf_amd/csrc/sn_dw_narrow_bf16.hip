@@ -276,17 +276,9 @@ SN_DWN_TASK(1, 4, 1, 2, 2, 4)
 SN_DWN_TASK(2, 2, 4, 2, 2, 2)
 SN_DWN_TASK(3, 2, 1, 2, 2, 4)
 SN_DWN_TASK(4, 1, 2, 1, 4, 2)
-#ifdef SN_DWN_NO_QUAD                            // (A/B build: two chunks per sync point for every shape)
-SN_DWN_TASK(5, 1, 1, 1, 4, 2)
-#else
 SN_DWN_TASK_Q(5, 1, 1, 1, 4)
-#endif
 SN_DWN_TASK(6, 4, 1, 2, 2, 2)
-#ifdef SN_DWN_NO_QUAD
-SN_DWN_TASK(7, 2, 1, 2, 2, 2)
-#else
 SN_DWN_TASK_Q(7, 2, 1, 2, 2)
-#endif
 
 __global__ void __launch_bounds__(256, 2) dw_narrow_bf16_asm_kernel(const Plan plan) {
   asm volatile("" ::: "a0", "a127");               // the hand-managed accumulator file

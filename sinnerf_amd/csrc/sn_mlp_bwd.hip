@@ -143,24 +143,16 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
     // data otherwise evict the L2-resident weight blob every workgroup streams.  Rows are allocated for whole 128-point
     // tiles (slot_rows), rows >= P receive the exact zeros their lanes computed: no predicate.
     auto stage = [&](int q, const float (&v)[4]) __attribute__((always_inline)) {
-#ifndef SN_ABL_NO_STAGE                          // (ablation builds for timing only: tools/build_variant_src.sh)
       f32x4 o;
       o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
       *reinterpret_cast<f32x4*>(xp + xp_w + 32 * q) = o;
-#endif
     };
     auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) {
-#ifndef SN_ABL_NO_STAGE
       const f32x4 o = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
       const char* base = reinterpret_cast<const char*>(G) + (((long)slot * slot_rows + p_wave + 8 * i) * 256 + 32 * t) * 4;
       unsigned go = g_off;
       asm volatile("" : "+v"(go));               // opaque per store: no hoisted per-slot address registers
-#ifndef SN_ABL_NO_G_STORE
       __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
-#else
-      asm volatile("" :: "v"(o), "s"(base), "v"(go));
-#endif
-#endif
     };
     // forward activation tile for the derivative mask of output tile t, accumulator layout (quad i of 4), requested one
     // slab ahead of the epilogue that consumes it
@@ -169,11 +161,7 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
       const char* base = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + p_wave) * 256 + 32 * t + 8 * i) * 4;
       unsigned ao = (unsigned)(j * 256 + 4 * h) * 4u;
       asm volatile("" : "+v"(ao));
-#ifndef SN_ABL_NO_MASK_LOAD
       av[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + ao));
-#else
-      asm volatile("" : "+v"(av[i]) : "s"(base), "v"(ao));
-#endif
     };
 
     // ---- rgb.0^T on the VALU: g_h2 = W_r^T g_y3 ; g_y2 = g_h2 (1 - exp(-h2)); written to set 0 (K-slots 16t + 4q + i)

@@ -262,11 +262,7 @@ mlp_bwd_chain_bf16_kernel(const char* __restrict__ bblob, const float* __restric
           char* base = reinterpret_cast<char*>(G) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * (t - 1)) * 2;
           unsigned go = g16_off;
           asm volatile("" : "+v"(go));
-#ifndef SN_ABL_NO_STATE_STORE                       // (timing experiments only: tools/build_variant_src.sh)
           __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
-#else
-          asm volatile("" :: "v"(o), "s"(base), "v"(go));
-#endif
         }
       } else {
         const f32x4 o = *reinterpret_cast<const f32x4*>(xp + pt * XPOSE_WAVE_BYTES + xp_r + 8 * i * XPOSE_PITCH * 4);

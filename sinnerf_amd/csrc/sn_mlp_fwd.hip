@@ -100,14 +100,12 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       xe[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
     }
   }
-#ifndef SN_ABL_NO_EMB_STORE
   if (STORE && INPUT_MODE == 0) {                // rows are allocated for whole 128-point tiles: no predicate.  (Pre-embedded
                                                  // rows, INPUT_MODE 1: the caller builds emb itself, it is a column re-layout of x)
     int hh = h;
     asm volatile("" : "+v"(hh));                 // the half-dependent offsets stay inside the tile loop
     store_emb_xyz(emb + p_raw * 128, xe, hh);    // columns [0, 63); the pad columns 63, 91..127 are never read back
   }
-#endif
 
   int s = 0;                                     // slab id being consumed
   float sg = 0.0f;                               // sigma head partial of this lane half (nerf.py:136), K-slot order
@@ -132,11 +130,7 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       const char* base = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + p_wave + 8 * i) * 256 + 32 * t) * 4;
       unsigned go = g_off;
       asm volatile("" : "+v"(go));               // opaque per store: no hoisted per-slot address registers
-#ifndef SN_ABL_NO_ACTS_STORE                  // (ablation builds for timing only: tools/build_variant_src.sh)
       __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
-#else
-      asm volatile("" :: "v"(o), "s"(base), "v"(go));
-#endif
     }
   };
   auto relu_slice = [&](auto wset, int slot, int t, int q, const f32x16& r) __attribute__((always_inline)) {
@@ -249,13 +243,11 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       de[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
     }
   }
-#ifndef SN_ABL_NO_EMB_STORE
   if (STORE && INPUT_MODE == 0) {
     int hh = h;
     asm volatile("" : "+v"(hh));
     store_emb_dir(emb + p_raw * 128 + 64, de, hh);                 // columns [64, 91)
   }
-#endif
   // rgb head (nerf.py:144) accumulated from the softplus outputs while they are produced: 3 rows x this half's 64 K-slots
   float c3[3] = {0.0f, 0.0f, 0.0f};
   auto ssp_slice = [&](auto, int, int t, int q, const f32x16& r) __attribute__((always_inline)) {

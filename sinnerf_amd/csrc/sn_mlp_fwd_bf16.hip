@@ -190,11 +190,7 @@ mlp_fwd_bf16_kernel(const char* __restrict__ blob, const float* __restrict__ in0
           char* base = reinterpret_cast<char*>(acts) + (((long)slot * slot_rows + p_wave + pt * 32 + 8 * i) * 256 + 32 * (t - 1)) * 2;
           unsigned go = g16_off;
           asm volatile("" : "+v"(go));
-#ifndef SN_ABL_NO_STATE_STORE                       // (timing experiments only: tools/build_variant_src.sh)
           __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + go));
-#else
-          asm volatile("" :: "v"(o), "s"(base), "v"(go));
-#endif
         }
       } else if (STORE == 2 && k == 8) {
         if (slot < 8) {                          // ReLU layers: the tile's sign word, 256 contiguous bytes per wave

@@ -103,6 +103,10 @@ class NeRF(nn.Module):
         self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
         self.skips = skips
         self.compute_dtype = compute_dtype
+        if not self.fused and dtype_code(compute_dtype) != _lib.SN_DTYPE_F32:
+            import warnings
+            warnings.warn("sinnerf_amd.NeRF: compute_dtype=%r only exists for the fused configuration (D=8, W=256, 63/27, skips=[4]); "
+                          "this network runs the reference's fp32 op sequence (sinnerf_amd.generic)" % (compute_dtype,), stacklevel=2)
         for i in range(D):                                           # nerf.py:66-75
             if i == 0:
                 layer = nn.Linear(in_channels_xyz, W)
@@ -148,13 +152,13 @@ class NeRF(nn.Module):
         return (self._pack_generation,) + tuple((t.data_ptr(), t._version) for t in raws)
 
     def invalidate_packed(self):
-        if not getattr(self, "fused", True):
-            return
         """Mark the MFMA-packed weight blobs stale.  ``packed()`` notices in-place updates of the parameters through
         ``Parameter._version`` (optimizer steps, ``load_state_dict``, ``p.mul_()`` under ``no_grad``) and replaced storage
         through ``data_ptr``; a write THROUGH ``p.data`` (``dist.broadcast(p.data)``, ``p.data.copy_()``, EMA / clipping code,
         a fused optimiser writing a flat buffer the parameters are views of) bumps neither -- call this after such a write.
         ``parallel.broadcast_parameters`` and ``optim.FlatAdam`` do.  The blob tensors are kept and re-filled in place."""
+        if not getattr(self, "fused", True):           # nothing is packed for the general configurations (generic.py)
+            return
         self._pack_generation += 1
 
     def packed(self, dtype=None):

@@ -29,12 +29,21 @@ PROFILE = None
 MAX_FUSED_SAMPLES = 1024       # samples per ray the per-ray kernels (compositor, sampler) hold in one wave
 
 
+def _is_pow2_bands(e, n_freqs):
+    """the reference's Embedding keeps no `logscale` attribute (nerf.py:8-22): the frequency bands themselves decide"""
+    fb = getattr(e, "freq_bands", None)
+    if fb is None or len(fb) != n_freqs:
+        return False
+    return [float(f) for f in fb] == [float(2 ** k) for k in range(n_freqs)]
+
+
 def _fused_embeddings(embeddings):
-    """the kernels fuse Embedding(3, 10) / Embedding(3, 4) (logscale) into the MLP (sinnerf.py:133-134, eval.py:134-135)"""
+    """the kernels fuse Embedding(3, 10) / Embedding(3, 4) with the logscale bands 2^k into the MLP (sinnerf.py:133-134,
+    eval.py:134-135); anything else -- including a reference-style Embedding(..., logscale=False) -- goes to generic.py"""
     ex, ed = embeddings[0], embeddings[1]
     return (getattr(ex, "in_channels", None) == 3 and getattr(ex, "N_freqs", None) == 10 and
             getattr(ed, "in_channels", None) == 3 and getattr(ed, "N_freqs", None) == 4 and
-            getattr(ex, "logscale", True) and getattr(ed, "logscale", True))
+            _is_pow2_bands(ex, 10) and _is_pow2_bands(ed, 4))
 
 
 def _check_embeddings(embeddings):
@@ -151,9 +160,9 @@ def render_rays(models,
                 ):
     """Render rays -- drop-in for reference ``models/rendering.py:126-335`` (same arguments, same dict).
 
-    ``chunk`` only bounds temporary memory in the reference (its results are chunk-invariant); the fused kernel
-    needs no point chunking, so the argument is accepted and ignored.  ``noisy_coarse`` is unused in the
-    reference as well.
+    ``chunk`` only bounds temporary memory in the reference (its results are chunk-invariant); the fused kernels
+    need no point chunking and ignore it, the general path (``sinnerf_amd/generic.py``: other layer shapes / embeddings /
+    more than 1024 samples per ray) honours it as the reference does.  ``noisy_coarse`` is unused in the reference as well.
     """
     if not isinstance(rays, torch.Tensor) or not rays.is_cuda:
         raise RuntimeError("sinnerf_amd.render_rays: rays must be a CUDA/ROCm tensor (there is no CPU fallback)")

@@ -185,8 +185,22 @@ class SinNeRFSystem(nn.Module):
         new = FlatAdam(self.models, lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"])
         if "initial_lr" in g:
             new.param_groups[0]["initial_lr"] = g["initial_lr"]
-        for sch in getattr(self, "_schedulers", []):          # MultiStepLR keeps a reference to the optimiser it drives
-            sch.optimizer = new
+        # the scheduler is REBUILT on the new optimiser (patching `.optimizer` would leave its step-order bookkeeping --
+        # the wrapper around optimizer.step, `_opt_called` -- bound to the discarded torch.optim.Adam): same milestones / gamma,
+        # resumed at the epoch the old one had reached.  Lists configure_optimizers() returned earlier still hold the old pair:
+        # re-read `self.optimizer` / `self._schedulers` (or call configure_optimizers() again) after .to(device)
+        rebuilt = []
+        for sch in getattr(self, "_schedulers", []):
+            if isinstance(sch, torch.optim.lr_scheduler.MultiStepLR):
+                ns = torch.optim.lr_scheduler.MultiStepLR(new, milestones=sorted(sch.milestones.elements()), gamma=sch.gamma,
+                                                          last_epoch=sch.last_epoch)
+                sch.optimizer = new       # a caller still holding the old object at least drives the live optimiser's lr
+            else:
+                sch.optimizer = new
+                ns = sch
+            rebuilt.append(ns)
+        if rebuilt:
+            self._schedulers = rebuilt
         self.optimizer, self._flat = new, new.grads
         self.__dict__.pop("_step_graphs", None)
         return new
@@ -204,10 +218,19 @@ class SinNeRFSystem(nn.Module):
         self.optimizer.zero_grad()
         out = self.training_step(batch)
         loss = out["loss"]
-        unit = self.__dict__.get("_unit_grad")      # the root gradient, kept: backward() would fill a fresh ones_like every step
-        if unit is None or unit.device != loss.device or unit.dtype != loss.dtype or unit.shape != loss.shape:
-            unit = self.__dict__["_unit_grad"] = torch.ones_like(loss)
+        # the root gradient, kept: backward() would fill a fresh ones_like every step.  READ-ONLY contract: autograd hands this
+        # very tensor to the first backward nodes and to any hook / side_loss Function; an in-place op on it there (g.mul_(),
+        # unscale / clip code) would corrupt every later step, so its version counter is checked and the tensor replaced if it
+        # moved (eager steps; a captured graph replays the kernels recorded while it was still 1)
+        unit, ver = self.__dict__.get("_unit_grad", (None, None))
+        if (unit is None or unit.device != loss.device or unit.dtype != loss.dtype or unit.shape != loss.shape
+                or unit._version != ver):
+            unit = torch.ones_like(loss)
+            self.__dict__["_unit_grad"] = (unit, unit._version)
         loss.backward(unit)
+        if unit._version != self.__dict__["_unit_grad"][1]:
+            raise RuntimeError("SinNeRFSystem: a backward hook / side_loss modified the root gradient in place; it is shared "
+                               "between steps -- use out-of-place ops on incoming gradients")
         return out
 
     def train_step(self, batch, graph=False):

@@ -1,0 +1,45 @@
+"""Convergence-length PSNR parity of mixed precision (VERDICT r3 "Next round" #4; SURVEY §8d "PSNR parity protocol"; the
+north_star bar "PSNR within 0.05 dB" is for renders -- over a 2 000-step optimisation with the training defaults perturb=1,
+noise_std=1 (opt.py:25-28) the trajectories are chaotic, so the statement is about the MEAN over seeds with a 0.1 dB allowance).
+
+tools/convergence.py trains a student on a teacher scene for SN_CONV_STEPS (default 2000) Adam steps on three seeds, once with the
+bf16-state kernels and once with the fp32 kernels, plus one run of the UNMODIFIED reference modules (oracle/_ref, PyTorch-ROCm
+eager) from the same initial weights, batches and RNG seed; held-out PSNR curves go to gpurun_out/convergence.json (copied to
+profiles/ by hand when a round's numbers are recorded)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def test_mixed_precision_reaches_the_fp32_psnr_at_convergence_length():
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import convergence
+    steps = int(os.environ.get("SN_CONV_STEPS", "2000"))
+    res = convergence.run_all(steps=steps, seeds=(0, 1, 2), ref_seeds=(0,))
+    try:
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        json.dump(res, open(os.path.join(REPO, "gpurun_out", "convergence.json"), "w"), indent=1)
+    except OSError:
+        pass
+    s = res["summary"]
+    print(json.dumps(s))
+    for r in res["runs"]:
+        first, last = r["psnr_curve"][0][1], r["psnr_curve"][-1][1]
+        assert np.isfinite(last) and last > first + 3.0, (r["path"], r["seed"], first, last)      # every run really optimises
+    # mixed precision loses nothing measurable at convergence length (mean over three seeds)
+    assert s["mean_final_psnr"]["bf16"] >= s["mean_final_psnr"]["fp32"] - 0.1, s
+    # and the fp32 HIP path lands where the reference's own modules land from the same start (same batches, same RNG draws;
+    # the allowance is the seed-to-seed spread of the fp32 runs themselves, at least 0.25 dB)
+    if "ref" in s["mean_final_psnr"]:
+        spread = float(np.ptp(s["final_psnr"]["fp32"]))
+        f0 = [r["final_psnr"] for r in res["runs"] if r["path"] == "fp32" and r["seed"] == 0][0]
+        assert abs(f0 - s["final_psnr"]["ref"][0]) <= max(0.25, spread), (f0, s["final_psnr"]["ref"], spread)

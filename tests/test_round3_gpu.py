@@ -128,6 +128,9 @@ def test_optimizer_configured_on_host_is_upgraded_on_device():
     flat = sysm.setup_distributed()
     assert isinstance(sysm.optimizer, FlatAdam) and flat is sysm.optimizer.grads
     assert abs(sysm.optimizer.param_groups[0]["lr"] - 3e-4) < 1e-12 and scheds[0].optimizer is sysm.optimizer
+    # the scheduler is rebuilt on the new optimiser (its step-order bookkeeping wraps FlatAdam.step, not the discarded Adam's)
+    assert sysm._schedulers[0] is not scheds[0] and sysm._schedulers[0].optimizer is sysm.optimizer
+    assert list(sysm._schedulers[0].milestones.elements()) == list(scheds[0].milestones.elements())
     rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::313][:512]).to(dev())
     batch = {"rays": rays, "rgbs": torch.rand((512, 3), device=dev())}
     before = sysm.replica_checksum().clone()
@@ -211,7 +214,16 @@ def test_bench_self_launch_two_gloo_ranks_one_gpu():
     assert rec["n_gpus"] == 2 and rec["value"] > 0
     leg = rec["train_dp"]
     assert leg["n_ranks_seen"] == 2 and leg["all_reduce_backend"] == "gloo" and leg["all_reduce_us"] > 0
-    assert leg["replicas_identical_after"] >= 3
+    # the full (un-shortened) record is written beside the one JSON line; the line itself stays under the driver's 8 KB tail
+    assert len(lines[0]) < 8000
+    full = json.load(open(os.path.join(REPO, "gpurun_out", "bench_full_fp32_n2.json")))
+    assert full["train_dp"]["replicas_identical_after"] >= 3
+    # BASELINE configs[4] / configs[3] as the sharded workloads they name: one frame split over the ranks with the
+    # rgb tiles gathered on rank 0, and the dtu four-render step per rank with the flat all-reduce
+    c5, c4 = rec["records"]["config5_sharded"], rec["records"]["train_cfg4_dp"]
+    assert c5["n_ranks"] == 2 and c5["value"] > 0 and c5["gathered_rows_on_rank0"] == 2 * c5["rays_per_rank"] == 240 * 240
+    assert c4["n_ranks"] == 2 and c4["all_reduce_backend"] == "gloo" and c4["all_reduce_us"] > 0 and c4["ms_per_step"] > 0
+    assert full["records"]["train_cfg4_dp"]["replicas_identical_after"] >= 3
 
 
 def _train_forward(model, rays_t, z_t, flag):

@@ -59,6 +59,9 @@ for name, disp in per.items():
                                          "hbm_TB_per_s": (fetch + write) / ms / 1e9, "bytes_per_point": (fetch + write) / POINTS}
 out["git_head"] = subprocess.run(["git", "describe", "--always", "--dirty"], capture_output=True, text=True).stdout.strip() or "unknown"
 json.dump(out, open(f"{P}/{tag}_train_pmc.json", "w"), indent=1)
+if out["kernels"]:                      # the pointer bench.py follows (a lexicographic sort of the file names picked r03_run7 over r03_run33)
+    json.dump({"file": f"{tag}_train_pmc.json", "note": "written by tools/save_round.py: the profile bench.py's train_hbm_roofline reads (never picked by sorting file names)"},
+              open(f"{P}/train_pmc_latest.json", "w"), indent=1)
 print("saved", sorted(os.path.basename(p) for p in glob.glob(f"{P}/{tag}_*")))
 for k, v in out["kernels"].items():
     print("  %-84s %.3f ms  %.2f TB/s  %.0f B/point" % (k, v["ms"], v["hbm_TB_per_s"], v["bytes_per_point"]))
