@@ -17,14 +17,19 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 3   /* 2: sn_sample_pdf_bins gained eps, dtype carries SN_DTYPE_CLASSIC_HEADS, sn_mlp_forward flag bits
-                            * 3: dtype carries SN_DTYPE_COMPILER_SCHEDULED and SN_DTYPE_EMB_BF16 */
+#define SN_ABI_VERSION 4   /* 2: sn_sample_pdf_bins gained eps, dtype carries SN_DTYPE_CLASSIC_HEADS, sn_mlp_forward flag bits
+                            * 3: dtype carries SN_DTYPE_COMPILER_SCHEDULED and SN_DTYPE_EMB_BF16
+                            * 4: SN_DTYPE_BF16X3 (inference entries + packer), sn_pack_table_entries_dtype */
 
 #define SN_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32                                          */
 #define SN_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate                    */
 #define SN_DTYPE_BF16_STATE 2 /* training entries only: SN_DTYPE_BF16 arithmetic AND acts / g_acts stored as bf16
                                * (same shapes; the float* parameters then point at bf16 arrays; emb stays fp32
                                * unless SN_DTYPE_EMB_BF16 is OR-ed in)                                             */
+#define SN_DTYPE_BF16X3 3 /* inference entries (sn_mlp_forward, sn_mlp_forward_embedded) and the packer: fp32-LEVEL accuracy on the bf16
+                           * MFMA -- every weight and activation as a (hi, lo) bf16 pair, W.x ~= Wh.xh + Wl.xh + Wh.xl with fp32
+                           * accumulation (3 bf16 MFMAs instead of 8 fp32 ones per 16 k; SURVEY §7 "3-term bf16 split"); exact
+                           * embeddings and fp32 heads as SN_DTYPE_F32.  Measured against the fp32 bars of the parity tests.  */
 /* OR-ed into `dtype` of the sn_mlp_* entry points: the network was built as NeRF(use_new_activation=False), the
  * constructor's default (models/nerf.py:47-50, :91-100) -- ReLU after dir_encoding, Sigmoid after rgb -- instead of the
  * ShiftedSoftplus / WidenedSigmoid heads both reference call sites ask for (models/nerf.py:81-90, models/activations.py).
@@ -70,7 +75,8 @@ int sn_layout_n_slabs(void);
  *   sigma.weight/.bias, rgb.0.weight/.bias                                                              */
 #define SN_N_RAW_TENSORS 24
 long sn_packed_weights_bytes(int dtype);
-long sn_pack_table_entries(void);
+long sn_pack_table_entries(void);           /* SN_DTYPE_F32 / SN_DTYPE_BF16 */
+long sn_pack_table_entries_dtype(int dtype); /* any packable dtype (SN_DTYPE_BF16X3 has two entries per weight) */
 /* fills table_host[2*entries] int32 (dst byte offset, src tensor<<20|offset or -1); upload it once */
 int sn_build_pack_table(int dtype, int32_t* table_host);
 int sn_pack_weights(const float* const* raw_host_array_of_device_ptrs, const int32_t* table, long n_entries,

@@ -89,11 +89,38 @@ class bf16_operands:
 
 
 _HEADS_FP32 = True
+_SPLIT3 = False
+
+
+def bf16_split(a):
+    """(hi, lo) with hi = RNE_bf16(a), lo = RNE_bf16(a - hi): the operand pair of the 3-term split (16 mantissa bits)."""
+    hi = bf16_round(a)
+    return hi, bf16_round((np.asarray(a, F) - hi).astype(F))
+
+
+class bf16x3_operands(bf16_operands):
+    """Context manager: every non-head ``_linear`` inside computes  Wh.xh + Wl.xh + Wh.xl  (fp32 accumulate) with the (hi, lo)
+    bf16 pairs of both operands -- the arithmetic of csrc/sn_mlp_fwd_bf16x3.hip (SN_DTYPE_BF16X3: fp32-level accuracy on the bf16
+    MFMA; the dropped Wl.xl term is 2^-16 relative).  Heads stay fp32 as in the kernel."""
+
+    def __enter__(self):
+        global _SPLIT3
+        super().__enter__()
+        self._saved3, _SPLIT3 = _SPLIT3, True
+        return self
+
+    def __exit__(self, *exc):
+        global _SPLIT3
+        _SPLIT3 = self._saved3
+        super().__exit__(*exc)
 
 
 def _linear(x, w, b, head=False):
     """nn.Linear: x @ W^T + b (``nerf.py:68-76``)."""
     if _OPERAND_ROUND is not None and not (head and _HEADS_FP32):
+        if _SPLIT3:
+            (xh, xl), (wh, wl) = bf16_split(x), bf16_split(w)
+            return ((xh @ wh.T + b) + (xh @ wl.T) + (xl @ wh.T)).astype(F)
         return (_OPERAND_ROUND(x) @ _OPERAND_ROUND(w).T + b).astype(F)
     return (x @ w.T + b).astype(F)
 

@@ -13,11 +13,12 @@ LIB_PATH = os.environ.get("SINNERF_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 SN_DTYPE_F32 = 0
 SN_DTYPE_BF16 = 1
 SN_DTYPE_BF16_STATE = 2
+SN_DTYPE_BF16X3 = 3                 # inference + packer: fp32-level accuracy on the bf16 MFMA (3-term hi/lo split)
 SN_DTYPE_CLASSIC_HEADS = 0x100      # OR-ed into dtype: NeRF(use_new_activation=False) heads (include/sinnerf_hip.h)
 SN_DTYPE_COMPILER_SCHEDULED = 0x200 # OR-ed into dtype of the bf16-state training entries: the compiler-scheduled kernels (A/B, tests)
 N_RAW_TENSORS = 24
 SN_DTYPE_EMB_BF16 = 0x400           # ... emb stored as bf16 in K-slot order (hand-scheduled bf16-state kernels only)
-ABI_VERSION = 3                     # == SN_ABI_VERSION of include/sinnerf_hip.h this binding was written against
+ABI_VERSION = 4                     # == SN_ABI_VERSION of include/sinnerf_hip.h this binding was written against
 
 c_fp = ctypes.c_void_p      # device float*
 c_vp = ctypes.c_void_p
@@ -33,6 +34,7 @@ SIGNATURES = {
     "sn_layout_n_slabs": (_int, []),
     "sn_packed_weights_bytes": (_long, [_int]),
     "sn_pack_table_entries": (_long, []),
+    "sn_pack_table_entries_dtype": (_long, [_int]),
     "sn_build_pack_table": (_int, [_int, c_vp]),
     "sn_pack_weights": (_int, [ctypes.POINTER(c_vp), c_vp, _long, c_vp, _int, c_vp]),
     "sn_packed_weights_bytes_bwd": (_long, []),

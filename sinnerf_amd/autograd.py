@@ -34,6 +34,12 @@ def _emb16_supported():
     return _EMB16_OK
 
 
+def _train_dtype(model):
+    """the arithmetic a network TRAINS in: 'bf16x3' is an inference arithmetic (fp32-level accuracy on the bf16 MFMA); under
+    autograd such a network runs the fp32 kernels, forward and backward"""
+    return "fp32" if dtype_code(model.compute_dtype) == _lib.SN_DTYPE_BF16X3 else model.compute_dtype
+
+
 def _sched_flag():
     return _lib.SN_DTYPE_COMPILER_SCHEDULED if COMPILER_SCHEDULED else 0
 
@@ -104,7 +110,7 @@ class _MLPFn(torch.autograd.Function):
         n, s = (rays.shape[0], 1) if embedded else z_vals.shape
         P = n * s
         dev = rays.device
-        code = dtype_code(model.compute_dtype)
+        code = dtype_code(_train_dtype(model))
         # mixed precision keeps the training state (activations, pre-activation gradients) in bf16 as well: every stage of
         # that mode is HBM-bound on exactly this traffic, and the stored values are the ones the kernels consume anyway
         bf16 = code == _lib.SN_DTYPE_BF16
@@ -119,7 +125,7 @@ class _MLPFn(torch.autograd.Function):
             emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
             emb[:n, :63] = rays[:, :63]
             emb[:n, 64:91] = rays[:, 63:90]
-            _lib.check(_lib.lib.sn_mlp_forward_train_embedded(_lib.ptr(model.packed()), model.kernel_dtype(code), _lib.ptr(rays), n, rays.shape[1],
+            _lib.check(_lib.lib.sn_mlp_forward_train_embedded(_lib.ptr(model.packed(_train_dtype(model))), model.kernel_dtype(code), _lib.ptr(rays), n, rays.shape[1],
                                                               _lib.ptr(out), _lib.ptr(acts), rows, _lib.stream_ptr()),
                        "sn_mlp_forward_train_embedded")
         else:
@@ -131,7 +137,7 @@ class _MLPFn(torch.autograd.Function):
             emb16 = bf16 and EMB_BF16 and not COMPILER_SCHEDULED and P < 2 ** 31 - 256 and _emb16_supported()
             emb = torch.empty((rows, 128), dtype=torch.bfloat16 if emb16 else torch.float32, device=dev)
             flags = _sched_flag() | (_lib.SN_DTYPE_EMB_BF16 if emb16 else 0)
-            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code) | flags, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
+            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed(_train_dtype(model))), model.kernel_dtype(code) | flags, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                                      _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
                        "sn_mlp_forward_train")
         ctx.model = model
@@ -151,10 +157,10 @@ class _MLPFn(torch.autograd.Function):
             G[:, P:].zero_()
         g_o = torch.empty((P, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
+            code = dtype_code(_train_dtype(model))   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
             if acts.dtype == torch.bfloat16:
                 code = _lib.SN_DTYPE_BF16_STATE
-            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(model.compute_dtype)), model.kernel_dtype(code) | _sched_flag(),
+            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(_train_dtype(model))), model.kernel_dtype(code) | _sched_flag(),
                                                       _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")
             needs = ctx.needs_input_grad[3:]

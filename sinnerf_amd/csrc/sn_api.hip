@@ -39,6 +39,10 @@ int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* 
 int sn_mlp_forward_bf16_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
                                int state_bf16, hipStream_t stream);
+int sn_mlp_forward_bf16x3_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld, int sigma_only,
+                                 int input_mode, float* out, hipStream_t stream);
+int sn_mlp_forward_bf16x3_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                                         int sigma_only, int input_mode, float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_v3_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
                                   float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_v3_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
@@ -82,13 +86,15 @@ pack_kernel(RawPtrs raw, const snl::PackEntry* __restrict__ table, long n, char*
     float v = 0.0f;
     const bool as_f32 = (e.src == -2) || (e.src >= 0 && (e.src & snl::SRC_F32_FLAG));
     if (e.src >= 0) {
-      const int t = (e.src >> 20) & 0x3ff, off = e.src & 0xfffff;
+      const int t = (e.src >> 20) & 0x1ff, off = e.src & 0xfffff;
       const float* src = raw.p[0];
 #pragma unroll
       for (int k = 1; k < snl::N_RAW; ++k) src = (t == k) ? raw.p[k] : src;
       v = src[off];
     }
     if (dtype == snl::DT_F32 || as_f32) *reinterpret_cast<float*>(blob + e.dst) = v;
+    else if (e.src >= 0 && (e.src & snl::SRC_LO_FLAG))             // bf16x3: the remainder of the RNE high part, itself RNE
+      *reinterpret_cast<unsigned short*>(blob + e.dst) = f32_to_bf16_rne(__fsub_rn(v, __uint_as_float((unsigned)f32_to_bf16_rne(v) << 16)));
     else *reinterpret_cast<unsigned short*>(blob + e.dst) = f32_to_bf16_rne(v);
   }
 }
@@ -117,13 +123,17 @@ const char* sn_error_string(int code) {
 }
 
 long sn_packed_weights_bytes(int dtype) {
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
   return snl::blob_bytes(dtype);
 }
 long sn_pack_table_entries(void) { return snl::table_entries(); }
+long sn_pack_table_entries_dtype(int dtype) {
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
+  return snl::table_entries_dt(dtype);
+}
 
 int sn_build_pack_table(int dtype, int32_t* table_host) {
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
   if (!table_host) return SN_E_BADARG;
   snl::build_pack_table(dtype, reinterpret_cast<snl::PackEntry*>(table_host));
   return 0;
@@ -146,7 +156,7 @@ int sn_build_pack_table_bwd_bf16(int32_t* table_host) {
 }
 
 int sn_pack_weights(const float* const* raw, const int32_t* table, long n_entries, void* blob, int dtype, void* stream) {
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
   if (!raw || !table || !blob || n_entries <= 0) return SN_E_BADARG;
   RawPtrs rp;
   for (int i = 0; i < snl::N_RAW; ++i) {
@@ -173,6 +183,9 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
   if (!blob || !rays || !z_vals || !out || n_rays < 0 || n_samples < 1) return SN_E_BADARG;
   const bool classic = (dtype & SN_DTYPE_CLASSIC_HEADS) && !sigma_only;
   dtype &= ~SN_DTYPE_CLASSIC_HEADS;
+  if (dtype == SN_DTYPE_BF16X3)                  // fp32-level accuracy on the bf16 MFMA: 3-term split (csrc/sn_mlp_fwd_bf16x3.hip)
+    return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out,
+                                                    (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16 && !sigma_only && !(flags & SN_FLAG_BF16_COMPILER_SCHEDULED))     // the hand-scheduled kernel
     return SN_HEADS(classic, sn_mlp_forward_bf16_v3)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, out, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16)
@@ -309,6 +322,8 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   if (ld < (sigma_only ? 63 : 90)) return SN_E_BADSHAPE;
   const bool classic = (dtype & SN_DTYPE_CLASSIC_HEADS) && !sigma_only;
   dtype &= ~SN_DTYPE_CLASSIC_HEADS;
+  if (dtype == SN_DTYPE_BF16X3)
+    return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16)
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;

@@ -28,7 +28,10 @@
 
 namespace snl {
 
-enum { DT_F32 = 0, DT_BF16 = 1 };
+// DT_BF16X3 (sn_mlp_fwd_bf16x3.hip): every weight as a (hi, lo) pair of bf16 -- hi = RNE(w), lo = RNE(w - hi) -- for the 3-term split
+// product  W.x ~= Wh.xh + Wl.xh + Wh.xl  on the bf16 MFMA at fp32-level accuracy.  Slabs are K x 128 B like the fp32 ones:
+//   bf16x3: [K/16 k-steps][hi, lo][64 lanes][8] bf16    (two ds_read_b128 feed three MFMAs)
+enum { DT_F32 = 0, DT_BF16 = 1, DT_BF16X3 = 3 };
 
 // ---- network constants (padded K per layer kind)
 constexpr int W_HID = 256;
@@ -63,8 +66,8 @@ constexpr long slab_elem_offset(int s) {
   for (int i = 0; i < s; ++i) o += slab_elems(i);
   return o;
 }
-constexpr long TOTAL_W_ELEMS = slab_elem_offset(N_SLABS);           // 606208
-constexpr int esize(int dt) { return dt == DT_F32 ? 4 : 2; }
+constexpr long TOTAL_W_ELEMS = slab_elem_offset(N_SLABS);           // 593920
+constexpr int esize(int dt) { return dt == DT_BF16 ? 2 : 4; }        // bytes per weight in the blob (bf16x3: a 2 + 2 byte pair)
 constexpr long bias_byte_offset(int dt) { return TOTAL_W_ELEMS * esize(dt); }
 constexpr int BIAS_FLOATS = N_SLABS * 32;
 // aux table (fp32) behind the biases:  sigma_w[2][128] | rgb_w[3][2][64] | sigma_b, rgb_b[3] | pad  -> 648 floats
@@ -132,7 +135,9 @@ constexpr int raw_cols(int raw_w) {
 //  Entries carrying SRC_F32_FLAG (biases) are stored as fp32 whatever the weight dtype.
 struct PackEntry { int32_t dst; int32_t src; };
 constexpr int32_t SRC_F32_FLAG = 1 << 30;
+constexpr int32_t SRC_LO_FLAG = 1 << 29;         // DT_BF16X3: store RNE(w - RNE(w)) instead of RNE(w)
 constexpr long table_entries() { return TOTAL_W_ELEMS + TAIL_FLOATS; }
+constexpr long table_entries_dt(int dt) { return (dt == DT_BF16X3 ? 2 : 1) * TOTAL_W_ELEMS + TAIL_FLOATS; }
 
 inline void build_pack_table(int dt, PackEntry* out) {
   long n = 0;
@@ -151,6 +156,18 @@ inline void build_pack_table(int dt, PackEntry* out) {
             e.src = (i < rows && col >= 0) ? ((rw << 20) | ((row0 + i) * ncol + col)) : -1;
             out[n++] = e;
           }
+    } else if (dt == DT_BF16X3) {
+      for (int ks = 0; ks < K / 16; ++ks)
+        for (int part = 0; part < 2; ++part)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int i = lane & 31, h = lane >> 5, q = 8 * ks + j;
+              const int col = slab_raw_col(s, q, h);
+              PackEntry e;
+              e.dst = (int32_t)(base * 4 + ((((long)ks * 2 + part) * 64 + lane) * 8 + j) * 2);
+              e.src = (i < rows && col >= 0) ? ((part ? SRC_LO_FLAG : 0) | (rw << 20) | ((row0 + i) * ncol + col)) : -1;
+              out[n++] = e;
+            }
     } else {
       for (int ks = 0; ks < K / 16; ++ks)
         for (int lane = 0; lane < 64; ++lane)

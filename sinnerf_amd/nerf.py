@@ -17,14 +17,17 @@ from torch import nn
 from . import _lib
 
 _DTYPES = {"fp32": _lib.SN_DTYPE_F32, "float32": _lib.SN_DTYPE_F32, torch.float32: _lib.SN_DTYPE_F32,
-           "bf16": _lib.SN_DTYPE_BF16, "bfloat16": _lib.SN_DTYPE_BF16, torch.bfloat16: _lib.SN_DTYPE_BF16}
+           "bf16": _lib.SN_DTYPE_BF16, "bfloat16": _lib.SN_DTYPE_BF16, torch.bfloat16: _lib.SN_DTYPE_BF16,
+           # fp32-level accuracy on the bf16 matrix cores (3-term hi/lo split, csrc/sn_mlp_fwd_bf16x3.hip): an INFERENCE
+           # arithmetic -- under autograd a network with this compute_dtype trains on the fp32 kernels
+           "bf16x3": _lib.SN_DTYPE_BF16X3}
 
 
 def dtype_code(dtype):
     try:
         return _DTYPES[dtype]
     except KeyError:
-        raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32' or 'bf16')")
+        raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32', 'bf16' or 'bf16x3')")
 
 
 class Embedding(nn.Module):
@@ -61,7 +64,7 @@ _PACK_TABLES = {}        # (device, dtype_code) -> int32 device tensor
 def _pack_table(device, code):
     key = (str(device), code)
     if key not in _PACK_TABLES:
-        n = _lib.lib.sn_pack_table_entries()
+        n = _lib.lib.sn_pack_table_entries_dtype(code)
         host = torch.empty((n, 2), dtype=torch.int32)
         _lib.check(_lib.lib.sn_build_pack_table(code, ctypes.c_void_p(host.data_ptr())), "sn_build_pack_table")
         _PACK_TABLES[key] = host.to(device)

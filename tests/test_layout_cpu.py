@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/sinnerf_hip.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert L.lib.sn_abi_version() == L.ABI_VERSION == 3
+    assert L.lib.sn_abi_version() == L.ABI_VERSION == 4
     assert L.lib.sn_packed_weights_bytes(0) == 4 * (32 * (8 * 64 + 24 * 256 + 8 * 320 + 32 * 256 + 4 * 288) + 76 * 32 + 648)
     assert L.lib.sn_error_string(-3).decode().startswith("perturb")
 
@@ -115,6 +115,39 @@ def test_bf16_backward_blob_table_covers_the_transposed_weights_once():
     assert ((aux >> 30) & 1 == 1).all()
     at, ao = (aux >> 20) & 0x3ff, aux & 0xfffff
     assert sorted(ao[at == 22].tolist()) == list(range(384)) and sorted(ao[at == 20].tolist()) == list(range(256))
+
+
+def test_bf16x3_pack_table_pairs_every_weight_with_its_remainder():
+    """SN_DTYPE_BF16X3 blob (csrc/sn_layout.h DT_BF16X3): per slab and k-step the hi fragment (64 lanes x 8 bf16) then the lo
+    fragment of the SAME weights (SRC_LO_FLAG), dense over [0, 4 x weights); the fp32 tail (biases, head table) is the fp32 blob's"""
+    from sinnerf_amd import _lib
+    n3, n32 = _lib.lib.sn_pack_table_entries_dtype(3), _lib.lib.sn_pack_table_entries_dtype(0)
+    t3, t32 = np.zeros((n3, 2), np.int32), np.zeros((n32, 2), np.int32)
+    assert _lib.lib.sn_build_pack_table(3, ctypes.c_void_p(t3.ctypes.data)) == 0
+    assert _lib.lib.sn_build_pack_table(0, ctypes.c_void_p(t32.ctypes.data)) == 0
+    n_w = 593920
+    assert n32 == n_w + 3080 == _lib.lib.sn_pack_table_entries() and n3 == 2 * n_w + 3080
+    assert _lib.lib.sn_packed_weights_bytes(3) == _lib.lib.sn_packed_weights_bytes(0) == 4 * n_w + 4 * 3080
+    assert np.array_equal(t3[2 * n_w:], t32[n_w:])                                     # same tail, same place
+    dst, src = t3[:2 * n_w, 0].astype(np.int64), t3[:2 * n_w, 1].astype(np.int64)
+    assert np.array_equal(np.sort(dst), 2 * np.arange(2 * n_w))                        # dense, no overlap
+    LO = 1 << 29
+    frag = (dst // 1024) % 2                                                            # 1 KB fragments alternate hi, lo
+    live = src >= 0
+    assert ((src[live] & LO != 0) == (frag[live] == 1)).all()
+    hi, lo = (frag == 0), (frag == 1)
+    order_hi, order_lo = np.argsort(dst[hi]), np.argsort(dst[lo])
+    assert np.array_equal(dst[hi][order_hi] + 1024, dst[lo][order_lo])                # lo fragment right behind its hi fragment
+    sh, sl = src[hi][order_hi], src[lo][order_lo]
+    assert np.array_equal(np.where(sh >= 0, sh | LO, sh), sl)                          # ... of the same raw element
+    used = sh[sh >= 0]
+    # the hi halves alone reproduce the bf16 blob's table (same K-slot order, element size 2 -> 4)
+    tb = np.zeros((n32, 2), np.int32)
+    assert _lib.lib.sn_build_pack_table(1, ctypes.c_void_p(tb.ctypes.data)) == 0
+    bdst, bsrc = tb[:n_w, 0].astype(np.int64), tb[:n_w, 1].astype(np.int64)
+    ob = np.argsort(bdst)
+    assert np.array_equal(bsrc[ob], sh)
+    assert np.array_equal((bdst[ob] // 1024) * 2048 + bdst[ob] % 1024, dst[hi][order_hi])
 
 
 def test_generated_instruction_streams_are_well_formed(tmp_path):

@@ -36,6 +36,28 @@ def test_bf16_emulated_forward_and_backward_close_to_fp32():
         assert 0 < e < 2e-2, (k, e)
 
 
+def test_bf16x3_split_emulation_is_fp32_level():
+    """the 3-term split (hi.hi + lo.hi + hi.lo, fp32 accumulate) of csrc/sn_mlp_fwd_bf16x3.hip restated in the oracle: norm-wise
+    error of the whole MLP ~1e-5 against the fp32 arithmetic -- three orders below one bf16 product, inside the 2e-4 MLP bar"""
+    p = O.init_params(0, True)
+    r = np.random.RandomState(2)
+    pts = r.uniform(-3, 3, (1024, 3)).astype(np.float32)
+    x = np.concatenate([O.embedding(pts, 10), O.embedding(r.standard_normal((1024, 3)).astype(np.float32), 4)], 1)
+    o32 = O.nerf_forward(p, x)
+    with O.bf16x3_operands():
+        o3 = O.nerf_forward(p, x)
+    with O.bf16_operands():
+        o1 = O.nerf_forward(p, x)
+    assert np.array_equal(O.nerf_forward(p, x), o32)                      # hooks restored
+    n3 = np.linalg.norm(o3.astype(np.float64) - o32) / np.linalg.norm(o32)
+    n1 = np.linalg.norm(o1.astype(np.float64) - o32) / np.linalg.norm(o32)
+    assert 0 < n3 < 3e-5 and n1 > 100 * n3, (n3, n1)
+    assert (np.abs(o3 - o32) / (np.abs(o32) + 1e-3)).max() <= 2e-4
+    hi, lo = O.bf16_split(np.array([1.2345678, -3.3e-5, 0.0], np.float32))
+    assert np.array_equal(O.bf16_round(hi), hi) and np.array_equal(O.bf16_round(lo), lo)
+    assert np.abs((hi + lo) - np.array([1.2345678, -3.3e-5, 0.0], np.float32)).max() <= 2.0 ** -16 * 1.3
+
+
 def test_patch_ray_generators_match_config_sizes():
     ll, dt = O.llff_patch_rays(0), O.dtu_patch_rays(0)
     assert ll.shape == (5292, 8) and dt.shape == (3920, 8)                # BASELINE configs 3, 4 (SURVEY §8a sizes)
