@@ -6,6 +6,8 @@
 //   mode 1: random bf16 operands         (8 A and 8 B fragments in rotation)
 //   mode 2: mode 1 + one ds_read_b128 of a random LDS tile per MFMA pair (the A-fragment stream of the fused MLP kernel)
 //   mode 3: mode 2 + 3 VALU instructions (v_cvt_pk_bf16_f32 / v_pk_max / v_accvgpr_write-like moves) per MFMA
+//   mode 4: mode 1 with HALF of the B operands zero (a ReLU layer's activations: the fused MLP's actual B operand statistics)
+//   mode 5: mode 4 + the ds_read_b128 per MFMA pair of mode 2
 // prints TFLOP/s (dense, 32*32*16*2 FLOP per MFMA) and the clock an MFMA-bound stream implies (32 cycles per MFMA per SIMD).
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_bf16_peak tools/ubench/mfma_bf16_peak.hip
 #include <hip/hip_runtime.h>
@@ -16,8 +18,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
+template <int MODE_>
 __global__ void __launch_bounds__(256) k(const u32x4* __restrict__ src, float* out, int iters) {
+  constexpr int MODE = MODE_ == 4 ? 1 : MODE_ == 5 ? 2 : MODE_;      // 4, 5: the loops of 1, 2 over ReLU-like B operands
+
   __shared__ __attribute__((aligned(16))) u32x4 lds[2048];           // 32 KB of operand tiles
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = (MODE == 0) ? u32x4{0, 0, 0, 0} : src[i];
@@ -27,6 +31,14 @@ __global__ void __launch_bounds__(256) k(const u32x4* __restrict__ src, float* o
   for (int i = 0; i < 8; ++i) {
     a[i] = lds[i * 64 + lane];
     b[i] = lds[(8 + i) * 64 + lane];
+    if (MODE_ >= 4) {                                                 // zero half of the bf16 values (pseudo-random pattern per lane / slot)
+      unsigned m = (unsigned)(lane * 2654435761u + i * 40503u);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (m & (1u << (2 * w))) b[i][w] &= 0xffff0000u;
+        if (m & (1u << (2 * w + 1))) b[i][w] &= 0x0000ffffu;
+      }
+    }
   }
   f32x16 c0, c1;
   for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; }
@@ -89,6 +101,8 @@ int main(int argc, char** argv) {
     run<1>("mode 1: random bf16 operands", src, d, n_cu, target_ms);
     run<2>("mode 2: random + ds_read_b128 / 2 MFMA", src, d, n_cu, target_ms);
     run<3>("mode 3: mode 2 + 3 VALU / MFMA", src, d, n_cu, target_ms);
+    run<4>("mode 4: random A, half-zero B (ReLU-like)", src, d, n_cu, target_ms);
+    run<5>("mode 5: mode 4 + ds_read_b128 / 2 MFMA", src, d, n_cu, target_ms);
   }
   return 0;
 }
