@@ -35,8 +35,9 @@ def _emb16_supported():
 
 
 def _train_dtype(model):
-    """the arithmetic a network TRAINS in: 'bf16x3' is an inference arithmetic (fp32-level accuracy on the bf16 MFMA); under
-    autograd such a network runs the fp32 kernels, forward and backward"""
+    """the arithmetic of a network's BACKWARD (and of its training state): 'bf16x3' (fp32-level accuracy on the bf16 MFMA) has a
+    training forward that writes the fp32 state (csrc/sn_mlp_fwd_bf16x3.hip STORE) and no backward kernels of its own -- the chain
+    and the weight gradients of such a network are the fp32 ones"""
     return "fp32" if dtype_code(model.compute_dtype) == _lib.SN_DTYPE_BF16X3 else model.compute_dtype
 
 
@@ -110,7 +111,7 @@ class _MLPFn(torch.autograd.Function):
         n, s = (rays.shape[0], 1) if embedded else z_vals.shape
         P = n * s
         dev = rays.device
-        code = dtype_code(_train_dtype(model))
+        code = dtype_code(model.compute_dtype)      # (bf16x3: its own forward, fp32 state -- then the fp32 backward)
         # mixed precision keeps the training state (activations, pre-activation gradients) in bf16 as well: every stage of
         # that mode is HBM-bound on exactly this traffic, and the stored values are the ones the kernels consume anyway
         bf16 = code == _lib.SN_DTYPE_BF16
@@ -125,7 +126,7 @@ class _MLPFn(torch.autograd.Function):
             emb = torch.zeros((rows, 128), dtype=torch.float32, device=dev)
             emb[:n, :63] = rays[:, :63]
             emb[:n, 64:91] = rays[:, 63:90]
-            _lib.check(_lib.lib.sn_mlp_forward_train_embedded(_lib.ptr(model.packed(_train_dtype(model))), model.kernel_dtype(code), _lib.ptr(rays), n, rays.shape[1],
+            _lib.check(_lib.lib.sn_mlp_forward_train_embedded(_lib.ptr(model.packed()), model.kernel_dtype(code), _lib.ptr(rays), n, rays.shape[1],
                                                               _lib.ptr(out), _lib.ptr(acts), rows, _lib.stream_ptr()),
                        "sn_mlp_forward_train_embedded")
         else:
@@ -137,7 +138,7 @@ class _MLPFn(torch.autograd.Function):
             emb16 = bf16 and EMB_BF16 and not COMPILER_SCHEDULED and P < 2 ** 31 - 256 and _emb16_supported()
             emb = torch.empty((rows, 128), dtype=torch.bfloat16 if emb16 else torch.float32, device=dev)
             flags = _sched_flag() | (_lib.SN_DTYPE_EMB_BF16 if emb16 else 0)
-            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed(_train_dtype(model))), model.kernel_dtype(code) | flags, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
+            _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code) | flags, _lib.ptr(rays), _lib.ptr(z_vals), n, s,
                                                      _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
                        "sn_mlp_forward_train")
         ctx.model = model

@@ -40,9 +40,10 @@ int sn_mlp_forward_bf16_classic_launch(const void* blob, const float* in0, const
                                int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
                                int state_bf16, hipStream_t stream);
 int sn_mlp_forward_bf16x3_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld, int sigma_only,
-                                 int input_mode, float* out, hipStream_t stream);
+                                 int input_mode, float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
 int sn_mlp_forward_bf16x3_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                                         int sigma_only, int input_mode, float* out, hipStream_t stream);
+                                         int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
+                                         hipStream_t stream);
 int sn_mlp_forward_bf16_v3_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
                                   float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_v3_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
@@ -185,7 +186,7 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
   dtype &= ~SN_DTYPE_CLASSIC_HEADS;
   if (dtype == SN_DTYPE_BF16X3)                  // fp32-level accuracy on the bf16 MFMA: 3-term split (csrc/sn_mlp_fwd_bf16x3.hip)
     return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out,
-                                                    (hipStream_t)stream);
+                                                    nullptr, nullptr, 0, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16 && !sigma_only && !(flags & SN_FLAG_BF16_COMPILER_SCHEDULED))     // the hand-scheduled kernel
     return SN_HEADS(classic, sn_mlp_forward_bf16_v3)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, out, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16)
@@ -203,12 +204,14 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
   const bool compiler_scheduled = dtype & SN_DTYPE_COMPILER_SCHEDULED;
   const int emb16 = (dtype & SN_DTYPE_EMB_BF16) ? 1 : 0;
   dtype &= ~(SN_DTYPE_CLASSIC_HEADS | SN_DTYPE_COMPILER_SCHEDULED | SN_DTYPE_EMB_BF16);
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
   const long n_points = n_rays * (long)n_samples;
-  const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are stored
+  const long tile = (dtype == SN_DTYPE_F32 || dtype == SN_DTYPE_BF16X3) ? 128 : 256;      // whole point tiles are stored
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
   const bool hand = dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256;   // the hand-scheduled kernel
   if (emb16 && !hand) return SN_E_UNSUPPORTED;                               // (the only one that writes the bf16 form of emb)
+  if (dtype == SN_DTYPE_BF16X3)                  // fp32-level forward on the bf16 MFMA, fp32 training state (as SN_DTYPE_F32 writes it)
+    return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows, (hipStream_t)stream);
   if (hand)
     return SN_HEADS(classic, sn_mlp_forward_bf16_t)(blob, rays, z_vals, n_points, n_samples, out, acts, emb, slot_rows, emb16, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32)
@@ -225,9 +228,11 @@ int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, l
   if (ld < 90) return SN_E_BADSHAPE;
   const bool classic = dtype & SN_DTYPE_CLASSIC_HEADS;
   dtype &= ~SN_DTYPE_CLASSIC_HEADS;
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;   // mixed precision keeps bf16 state
-  const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16_STATE && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;   // mixed precision keeps bf16 state
+  const long tile = (dtype == SN_DTYPE_F32 || dtype == SN_DTYPE_BF16X3) ? 128 : 256;
   if (slot_rows < (n_rows + tile - 1) / tile * tile) return SN_E_BADSHAPE;
+  if (dtype == SN_DTYPE_BF16X3)
+    return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32)
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows,
                                                   dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
@@ -323,7 +328,7 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   const bool classic = (dtype & SN_DTYPE_CLASSIC_HEADS) && !sigma_only;
   dtype &= ~SN_DTYPE_CLASSIC_HEADS;
   if (dtype == SN_DTYPE_BF16X3)
-    return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, (hipStream_t)stream);
+    return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16)
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;

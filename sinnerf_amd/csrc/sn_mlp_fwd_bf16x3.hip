@@ -17,6 +17,13 @@
 //   depend on each other; chain A starts from the bias, chain B from the inline constant 0, the epilogue adds them;
 // * the epilogue splits each fp32 result into its (hi, lo) bf16 pair for the next layer's B operands; the embeddings are the
 //   EXACT ones of the fp32 kernel (no angle doubling) split the same way; heads in fp32 on the VALU as everywhere.
+// STORE (training forward, SN_DTYPE_BF16X3 of sn_mlp_forward_train): additionally writes the fp32 activations of every layer
+// (acts[10][slot_rows][256], the values the next layer consumed BEFORE their hi/lo split) and the fp32 embedded inputs (emb) --
+// the fp32 training state of sn_mlp_fwd.hip, value for value at fp32 rounding level -- for the fp32 backward chain and weight
+// gradients.  Row-coalesced stores through per-wave staging tiles, four 1 KB row-group stores per finished tile dealt one per
+// k-step behind the slab's DMA pieces; the sync points wait with a COUNTED vmcnt (the four youngest operations of a wave are those
+// stores) at a fence-less barrier, and the staging writes are inline asm -- the three measures sn_mlp_bf16.h documents for the
+// bf16-state kernels; at this kernel's slab time (48 MFMAs x 32 cycles) a store drain per slab would cost more than the slab.
 // Compiler-scheduled C++ around inline-asm MFMAs / epilogue blocks (the register-file discipline of sn_mlp_fwd_bf16.hip:
 // hand-managed AGPRs, VGPR accumulators, tools/check_agpr.py on the build).
 #include "sn_mlp_bf16.h"
@@ -101,18 +108,24 @@ SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], flo
 //   af         ring of A-fragment PAIRS (hi, lo), prefetch distance 3 k-steps: fragments of k-steps 0, 1, 2 of this slab sit in
 //              af[(PHASE + 0..2) & 3] at entry; PHASE' = (PHASE + NK) & 3 at exit
 //   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead), a multiple of 4 KB for every K
-template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, class Pending>
+//   VMW        counted wait at the sync point (training forward): the youngest VMW vector-memory operations of the wave are row
+//              stores issued BEHIND the previous slab's DMA pieces and may stay in flight; the barrier is then a raw s_barrier
+//   post(i)    i = 0..3: row-group store i of the previous tile, in the LAST four k-steps of the slab (behind its DMA pieces)
+template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, int VMW = 0, class Pending, class Post>
 SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], const char* lw, const u32x4* bh, const u32x4* bl,
-                    const char* lw_next, const float* lds_bias, int s_next, int h, Ring& ring, Pending&& pending) {
+                    const char* lw_next, const float* lds_bias, int s_next, int h, Ring& ring, Pending&& pending, Post&& post) {
   constexpr int NK = NK0 + NK1;
   constexpr int NP = NBYTES / 4096;
   constexpr int PPK = (NP + (NK - GB) - 1) / (NK - GB);
+  constexpr int NPS = (NP + PPK - 1) / PPK;                  // k-steps that carry DMA pieces: GB .. GB + NPS - 1
   static_assert(NBYTES % 4096 == 0 && GB >= 1 && GB + 3 <= NK && NK >= 4, "whole pieces; sync point inside the slab");
+  static_assert(NK >= 8 ? GB + NPS <= NK - 4 : true, "the four store steps follow the DMA pieces");
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
     if (ks == GB) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
+      if (VMW == 0) __syncthreads();
+      else __builtin_amdgcn_s_barrier();
       ring.begin_static();
       nA = load_bias(lds_bias, s_next, h);
     }
@@ -126,6 +139,12 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
 #pragma unroll
       for (int i = 0; i < PPK; ++i)
         if ((ks - GB) * PPK + i < NP) ring.piece_static();
+    }
+    if (NK >= 8) {
+      if (ks >= NK - 4) post(ks - (NK - 4));
+    } else if (ks >= GB) {                                   // layer 0 (4 k-steps, sync after the first): 1 + 1 + 2 behind the pieces
+      if (ks - GB < 2) post(ks - GB);
+      else { post(2); post(3); }
     }
     __builtin_amdgcn_sched_barrier(0);
     const u32x4 a_hi = af[(PHASE + ks) & 3][0], a_lo = af[(PHASE + ks) & 3][1];
@@ -164,10 +183,18 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
   ring.template end_static<NP>();
 }
 
-template <bool SIGMA_ONLY, int INPUT_MODE>
+// 16-byte write into a wave's staging tile as inline asm (hipcc guards every LDS write it sees with s_waitcnt vmcnt(0) while
+// LDS-DMA pieces may be in flight, sn_mlp_bf16.h): lds = byte address in LDS (dynamic LDS starts at 0), off = compile-time part
+SN_DEV void x3_lds_write_b128(unsigned lds, int off, const float (&v)[4]) {
+  f32x4 o;
+  o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(lds), "v"(o), "n"(off) : "memory");
+}
+
+template <bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1,
-                      long P, int S, float* __restrict__ out) {
+                      long P, int S, float* __restrict__ out, float* __restrict__ acts, float* __restrict__ emb, long slot_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_bias = reinterpret_cast<float*>(smem);
   const float* lds_aux = lds_bias + snl::BIAS_FLOATS;
@@ -213,11 +240,17 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
   f32x16 a0, b0, a1, b1;                                     // chains (A, B) of the two accumulator sets
   a0 = load_bias(lds_bias, 0, h);
   const int n_used = ring.n_used;
+  // training forward: per-wave staging tile of the activation stores (sn_mlp_pipe.h XPOSE_*)
+  const char* const xp = smem + X3_LDS_BYTES + wave * XPOSE_WAVE_BYTES;
+  const unsigned xp_w_lds = (unsigned)(X3_LDS_BYTES + wave * XPOSE_WAVE_BYTES) + (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
+  const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;    // row lane>>3, 16-byte chunk lane&7
+  const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     int ht = h;
     asm volatile("" : "+v"(ht));               // per-tile opaque copy of the lane half (keeps the embedding's selects in the loop)
-    const long p_raw = (tile * 4 + wave) * 32 + j;
+    const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * 32;          // wave-uniform
+    const long p_raw = p_wave + j;
     const bool valid = p_raw < P;
     const long p = valid ? p_raw : P - 1;
     u32x4 xh[4], xl[4];                                      // embedded xyz, (hi, lo) operands of the 4 k-steps
@@ -241,6 +274,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
           f[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
         }
       }
+      if (STORE && INPUT_MODE == 0) store_emb_xyz(emb + p_raw * 128, f, ht);   // whole 128-point tiles are allocated: no predicate
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         x3_split8(f + 8 * ks, xh[ks], xl[ks]);
@@ -251,6 +285,21 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
 
     int s = 0;
     float sg = 0.0f;                                         // sigma head partial (fp32, this lane half)
+    int cur_slot = 0;
+    // training forward: the four fp32 values of accumulator registers 4qq..4qq+3 go to the wave's staging tile; store_rows(i) writes
+    // row group i (8 points x 128 B) of the staged 32-point x 32-feature tile to acts[slot][point][32t..32t+31], non-temporal
+    auto stage = [&](int qq, const float (&v)[4]) __attribute__((always_inline)) {
+      if (STORE) x3_lds_write_b128(xp_w_lds, 32 * qq, v);
+    };
+    auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) {
+      if (STORE) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
+        const char* base = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + p_wave + 8 * i) * 256 + 32 * t) * 4;
+        unsigned go = g_off;
+        asm volatile("" : "+v"(go));             // opaque per store: no hoisted per-slot address registers
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
+      }
+    };
     // Epilogues of output tile t (chains ra + rb) writing activation set W: dword q of the tile = results 2q, 2q+1 -> k-steps
     // 2t (q < 4), 2t+1 of the next layer, hi part and lo part
     auto relu_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {
@@ -261,6 +310,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
         x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v);
+        stage(q >> 1, v);
       }
     };
     auto relu_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {   // layer 8
@@ -277,6 +327,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         sg = __builtin_fmaf(w[1], v[1], sg);
         sg = __builtin_fmaf(w[2], v[2], sg);
         sg = __builtin_fmaf(w[3], v[3], sg);
+        stage(q >> 1, v);
       }
     };
     auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {   // xyz_encoding_final
@@ -287,6 +338,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
         x3_epi<false>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v);
+        stage(q >> 1, v);
       }
     };
 #define SNX_LW_CUR (ring.slot(cslot) + lane * 16)
@@ -294,14 +346,20 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
 #define SNX_SNEXT (s + 1 == n_used ? 0 : s + 1)
 #define SNX_ADVANCE() do { ++s; cslot = (cslot == 2) ? 0 : cslot + 1; } while (0)
 #define SNX_W(W_) std::integral_constant<int, W_>{}
+    // training forward: the youngest four vector-memory operations of a wave at a slab's sync point are the row stores the
+    // previous slab posted behind its DMA pieces (tile T-2's; at T = 0 the previous layer's last tile's) -- except at T = 1,
+    // whose predecessor posts none
 #define SNX_SLAB(T_, NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, BH_, BL_, EPI_, W_)                                              \
   do {                                                                                                                     \
+    constexpr int VW_ = (STORE && (T_) != 1) ? 4 : 0;                                                                      \
     if (((T_) & 1) == 0)                                                                                                   \
-      slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(a0, b0, a1, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
-                                                   [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNX_W(W_), (T_) - 1, a1, b1); }); \
+      slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a0, b0, a1, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
+                                                   [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNX_W(W_), (T_) - 1, a1, b1); }, \
+                                                   [&](int i) __attribute__((always_inline)) { if ((T_) > 0) store_rows(cur_slot, (T_) - 1, i); }); \
     else                                                                                                                   \
-      slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_>(a1, b1, a0, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
-                                                   [&]() __attribute__((always_inline)) { EPI_(SNX_W(W_), (T_) - 1, a0, b0); }); \
+      slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a1, b1, a0, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
+                                                   [&]() __attribute__((always_inline)) { EPI_(SNX_W(W_), (T_) - 1, a0, b0); }, \
+                                                   [&](int i) __attribute__((always_inline)) { store_rows(cur_slot, (T_) - 1, i); }); \
     SNX_ADVANCE();                                                                                                         \
   } while (0)
 #define SNX_LAYER(NK0_, NK1_, S0_, S1_, GB_, NBA_, NBB_, EPI_, W_)              \
@@ -316,16 +374,20 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     SNX_SLAB(7, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_);          \
     mfma_result_fence();                                                        \
     EPI_(SNX_W(W_), 7, a1, b1);                                                 \
+    store_rows(cur_slot, 7, 0); store_rows(cur_slot, 7, 1);                     \
+    store_rows(cur_slot, 7, 2); store_rows(cur_slot, 7, 3);                     \
   } while (0)
     // bytes of the slab kinds (K * 128): the NB_ argument is the slab TWO ahead in the stream
     constexpr int B_L0 = 64 * 128, B_H = 256 * 128, B_SKIP = 320 * 128, B_DIR = 288 * 128;
 
     // ---- layer 0: reads the xyz embedding (VGPRs), writes set 0
+    cur_slot = 0;
     SNX_LAYER(4, 0, -1, -1, 1, B_L0, B_H, relu_tile, 0);
     // ---- layers 1..7: odd layers read set 0 / write set 1, even layers the reverse; skip concat at layer 4 (xyz FIRST,
     //      nerf.py:133); layer 7's epilogues also feed the sigma head
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
+      cur_slot = l;
       if (l == 4) {
         SNX_LAYER(4, 16, -1, 1, 2, B_SKIP, B_H, relu_tile, 0);
       } else if (l == 7) {
@@ -345,6 +407,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
       continue;
     }
     // ---- xyz_encoding_final (no activation): reads set 1, writes set 0
+    cur_slot = 8;
     SNX_LAYER(16, 0, 1, 1, 2, B_H, B_DIR, copy_tile, 0);
 
     // ---- dir_encoding + ShiftedSoftplus: reads set 0 and the dir embedding (VGPRs); rgb head from the fp32 softplus outputs
@@ -365,6 +428,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
           f[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
         }
       }
+      if (STORE && INPUT_MODE == 0) store_emb_dir(emb + p_raw * 128 + 64, f, ht);      // columns [64, 91)
       x3_split8(f, dh[0], dl[0]);
       x3_split8(f + 8, dh[1], dl[1]);
       asm volatile("" : "+v"(dh[0]), "+v"(dh[1]), "+v"(dl[0]), "+v"(dl[1]));
@@ -385,16 +449,19 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
         float v[4];
         ssp4_rgb(x, w, c3, v);
+        stage(q, v);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     // 18 k-steps per slab: the fragment-ring phase alternates 0, 2, 0, 2; tiles 2, 3 stage the next point tile's first slabs
+    cur_slot = 9;
     SNX_SLAB(0, 16, 2, 0, -1, 2, 0, B_DIR, dh, dl, ssp_tile, 0);
     SNX_SLAB(1, 16, 2, 0, -1, 2, 2, B_DIR, dh, dl, ssp_tile, 0);
     SNX_SLAB(2, 16, 2, 0, -1, 2, 0, B_L0, dh, dl, ssp_tile, 0);
     SNX_SLAB(3, 16, 2, 0, -1, 2, 2, B_L0, dh, dl, ssp_tile, 0);
     mfma_result_fence();
     ssp_tile(SNX_W(0), 3, a1, b1);
+    store_rows(9, 3, 0); store_rows(9, 3, 1); store_rows(9, 3, 2); store_rows(9, 3, 3);
     {
       float o3[3];
 #pragma unroll
@@ -420,25 +487,31 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
 }  // namespace snk
 
 extern "C" int SN_LAUNCH_NAME(sn_mlp_forward_bf16x3)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                                            int sigma_only, int input_mode, float* out, hipStream_t stream) {
+                                            int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
+                                            hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
+  const bool store = acts != nullptr;
+  if (store && (sigma_only || emb == nullptr || slot_rows < tiles * 128)) return -1;
   const int n_cu = snh::cu_count();
   dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
   const char* b = reinterpret_cast<const char*>(blob);
-#define SN_LAUNCH(SO, IM)                                                                                \
-  do {                                                                                                   \
-    auto kfn = mlp_fwd_bf16x3_kernel<SO, IM>;                                                            \
-    SN_ENSURE_DYN_LDS(kfn, X3_LDS_BYTES);                                                                \
-    hipLaunchKernelGGL(kfn, grid, block, X3_LDS_BYTES, stream, b, in0, in1, n_points, s_or_ld, out);     \
+  const size_t lds = X3_LDS_BYTES + (store ? XPOSE_LDS_BYTES : 0);
+#define SN_LAUNCH(SO, IM, ST)                                                                                        \
+  do {                                                                                                               \
+    auto kfn = mlp_fwd_bf16x3_kernel<SO, IM, ST>;                                                                    \
+    SN_ENSURE_DYN_LDS(kfn, lds);                                                                                     \
+    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows);    \
   } while (0)
+  if (store) { if (input_mode == 0) SN_LAUNCH(false, 0, true); else SN_LAUNCH(false, 1, true); }
 #ifdef SN_CLASSIC_HEADS                         // the sigma-only kernels never reach the heads: sn_api.hip routes them to the main pass
-  if (sigma_only) return -4;
-  if (input_mode == 0) SN_LAUNCH(false, 0); else SN_LAUNCH(false, 1);
+  else if (sigma_only) return -4;
+  else if (input_mode == 0) SN_LAUNCH(false, 0, false);
+  else SN_LAUNCH(false, 1, false);
 #else
-  if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0); else SN_LAUNCH(false, 0); }
-  else { if (sigma_only) SN_LAUNCH(true, 1); else SN_LAUNCH(false, 1); }
+  else if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false); }
+  else { if (sigma_only) SN_LAUNCH(true, 1, false); else SN_LAUNCH(false, 1, false); }
 #endif
 #undef SN_LAUNCH
   return (int)hipGetLastError();

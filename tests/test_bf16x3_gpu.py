@@ -117,9 +117,8 @@ def test_bf16x3_ragged_shapes_vs_oracle(n, S, NI):
     check_render(to_np(res), ref, tag=f"bf16x3_n{n}_S{S}_NI{NI}")
 
 
-def test_bf16x3_classic_heads_and_training_falls_back_to_fp32_kernels():
-    """NeRF(use_new_activation=False) heads (nerf.py:91-100) in this arithmetic; and under autograd a bf16x3 network trains on the
-    fp32 kernels (it is an inference arithmetic): gradients identical to a compute_dtype='fp32' network's"""
+def test_bf16x3_classic_heads():
+    """NeRF(use_new_activation=False) heads (nerf.py:91-100) in this arithmetic"""
     import sinnerf_amd
     p = O.init_params(3, True)
     x = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (200, 90)).astype(np.float32)).to(dev())
@@ -131,13 +130,67 @@ def test_bf16x3_classic_heads_and_training_falls_back_to_fp32_kernels():
         with torch.no_grad():
             outs[dt] = m(x).cpu().numpy()
     assert (np.abs(outs[DT] - outs["fp32"]) / (np.abs(outs["fp32"]) + 1e-3)).max() <= 2e-4
-    grads = {}
-    rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::700][:96]).to(dev())
-    for dt in ("fp32", DT):
-        mc, _ = make_model(0, True, dtype=dt)
-        mf, _ = make_model(1, True, dtype=dt)
+
+
+@pytest.mark.parametrize("n_rays,S", [(60, 37), (512, 128)])
+def test_bf16x3_training_forward_writes_the_fp32_state(n_rays, S):
+    """sn_mlp_forward_train(SN_DTYPE_BF16X3) through the C ABI against sn_mlp_forward_train(SN_DTYPE_F32): output, all ten
+    activation slots and the embedded inputs agree at fp32 rounding level (the state the fp32 backward consumes); the training
+    forward equals the inference forward of the same arithmetic bit for bit.  2220 points = a ragged last tile."""
+    from sinnerf_amd import _lib, rendering
+    rays = O.lego_rays(400, 400, seed=0)[:: max(1, 160000 // n_rays)][:n_rays]
+    z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n_rays, S)).astype(np.float32))
+    rays_t, z_t = torch.from_numpy(rays).to(dev()), torch.from_numpy(z).to(dev())
+    P = n_rays * S
+    rows = -(-P // 128) * 128
+    state = {}
+    for dt, code in (("fp32", _lib.SN_DTYPE_F32), (DT, _lib.SN_DTYPE_BF16X3)):
+        model, _ = make_model(3, True, dtype=dt)
+        out = torch.zeros((n_rays, S, 4), device=dev())
+        acts = torch.full((10, rows, 256), float("nan"), device=dev())
+        emb = torch.full((rows, 128), float("nan"), device=dev())
+        _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(model.packed()), model.kernel_dtype(code), _lib.ptr(rays_t), _lib.ptr(z_t),
+                                                 n_rays, S, _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()),
+                   "sn_mlp_forward_train")
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            inf = rendering._mlp(model, rays_t, z_t, False)
+        assert torch.equal(inf, out), dt
+        state[dt] = (out.cpu().numpy(), acts.cpu().numpy(), emb.cpu().numpy())
+    o32, a32, e32 = state["fp32"]
+    o3, a3, e3 = state[DT]
+    assert np.array_equal(e3[:, :63], e32[:, :63]) and np.array_equal(e3[:, 64:91], e32[:, 64:91])      # the same exact embedding
+    for slot in range(10):
+        w = 128 if slot == 9 else 256
+        x, y = a3[slot, :, :w], a32[slot, :, :w]
+        assert np.isfinite(x).all(), slot                                      # whole point tiles are written, pad rows included
+        scale = np.abs(y).max()
+        assert np.abs(x - y).max() <= 2e-5 * scale, (slot, np.abs(x - y).max(), scale)
+        # ReLU masks agree except where the pre-activation is within rounding of zero
+        if slot < 8:
+            assert ((x > 0) != (y > 0)).mean() <= 1e-4, slot
+    assert (np.abs(o3 - o32) / (np.abs(o32) + 1e-3)).max() <= 2e-4
+
+
+def test_bf16x3_render_gradients_golden():
+    """compute_dtype='bf16x3' under autograd: bf16x3 training forward (fp32 state) + the fp32 backward chain / weight gradients,
+    held to the golden parameter gradients of the reference's autograd at the FP32 bars (coarse 1e-4, fine 5e-3)"""
+    import sinnerf_amd
+    from tests.test_oracle_grads import GRAD_CASES, check_grads, load_grad_case
+    from tests.test_grads_gpu import model_grads
+    for name in GRAD_CASES:
+        z, meta, rng, coef = load_grad_case(name)
+        rays = z["rays"]
+        mc, _ = make_model(meta["seed_coarse"], True, dtype=DT)
+        mf, _ = make_model(meta["seed_fine"], True, dtype=DT)
         mc.train(); mf.train()
-        res = sinnerf_amd.render_rays([mc, mf], embeddings(), rays, 64, False, 0, 0, 64, 32768, True)
-        (res["rgb_fine"].sum() + res["rgb_coarse"].sum()).backward()
-        grads[dt] = [q.grad.clone() for m in (mc, mf) for q in m.parameters()]
-    assert all(torch.equal(a, b) for a, b in zip(grads["fp32"], grads[DT]))
+        with injected_rng(rng_order(dict(meta, use_disp=0), rng, rays.shape[0])) as left:
+            res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays).to(dev()), meta["N_samples"], False,
+                                          meta["perturb"], meta["noise_std"], meta["N_importance"], 32768, bool(meta["white_back"]))
+            assert not left
+        loss = sum((res[k] * torch.from_numpy(v).to(dev())).sum() for k, v in coef.items())
+        assert abs(loss.item() - float(z["loss"])) <= 2e-4 * max(1.0, abs(float(z["loss"])))
+        loss.backward()
+        errs = check_grads(z, [model_grads(mc), model_grads(mf)], rel_coarse=1e-4, rel_fine=5e-3)
+        print(name, "bf16x3 forward + fp32 backward: max coarse %.2e, max fine %.2e" % (
+            max(e for (t, _), (e, _) in errs.items() if t == "coarse"), max(e for (t, _), (e, _) in errs.items() if t == "fine")))
