@@ -26,7 +26,8 @@ extern "C" {
 #define SN_DTYPE_BF16_STATE 2 /* training entries only: SN_DTYPE_BF16 arithmetic AND acts / g_acts stored as bf16
                                * (same shapes; the float* parameters then point at bf16 arrays; emb stays fp32
                                * unless SN_DTYPE_EMB_BF16 is OR-ed in)                                             */
-#define SN_DTYPE_BF16X3 3 /* inference entries (sn_mlp_forward, sn_mlp_forward_embedded) and the packer: fp32-LEVEL accuracy on the bf16
+#define SN_DTYPE_BF16X3 3 /* sn_mlp_forward, sn_mlp_forward_embedded, sn_mlp_forward_train[_embedded] (fp32 state), sn_mlp_backward_chain
+                           * (fp32 state) and the packer: fp32-LEVEL accuracy on the bf16
                            * MFMA -- every weight and activation as a (hi, lo) bf16 pair, W.x ~= Wh.xh + Wl.xh + Wh.xl with fp32
                            * accumulation (3 bf16 MFMAs instead of 8 fp32 ones per 16 k; SURVEY §7 "3-term bf16 split"); exact
                            * embeddings and fp32 heads as SN_DTYPE_F32.  Measured against the fp32 bars of the parity tests.  */
@@ -89,6 +90,10 @@ int sn_build_pack_table_bwd(int32_t* table_host);
 long sn_packed_weights_bytes_bwd_bf16(void);
 long sn_pack_table_entries_bwd_bf16(void);
 int sn_build_pack_table_bwd_bf16(int32_t* table_host);
+/* ... and its bf16x3 form (sn_mlp_backward_chain with dtype SN_DTYPE_BF16X3; pack with sn_pack_weights(..., SN_DTYPE_BF16X3)) */
+long sn_packed_weights_bytes_bwd_bf16x3(void);
+long sn_pack_table_entries_bwd_bf16x3(void);
+int sn_build_pack_table_bwd_bf16x3(int32_t* table_host);
 
 /* ---- models/rendering.py:264-282  z_vals = near*(1-t)+far*t (or disparity), stratified perturb -----------
  * rays (n_rays,8) = [o(3), d(3), near, far] (rendering.py:257-258); perturb_rand (n_rays,n_samples) = the
@@ -134,6 +139,8 @@ int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, l
  * gradient.  Writes g_acts (10, slot_rows, 256): slots 0..7 = dL/d(pre-activation) of xyz_encoding_1..8, 8 = of
  * xyz_encoding_final, 9 = of dir_encoding (128 wide); g_out (n_points,4) = dL/d(pre-activation) of rgb (3), sigma (1).
  * dtype SN_DTYPE_BF16: blob_bwd from the *_bwd_bf16 table, bf16-operand contractions, everything stored stays fp32.
+ * dtype SN_DTYPE_BF16X3: blob_bwd from the *_bwd_bf16x3 table; fp32-level accuracy on the bf16 MFMA (3-term hi/lo split), fp32 acts /
+ * g_acts exactly as for SN_DTYPE_F32 (slot_rows a multiple of 128).
  * dtype SN_DTYPE_BF16_STATE: acts / g_acts are bf16 arrays; the ReLU masks come from the sign words sn_mlp_forward_train
  * left in slot 9 (see there), gradients leave as whole 128-byte rows.
  * slot_rows as for sn_mlp_forward_train (>= n_points rounded up to 128, 256 for bf16; rows >= n_points of slots' 256

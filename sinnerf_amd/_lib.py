@@ -43,6 +43,9 @@ SIGNATURES = {
     "sn_packed_weights_bytes_bwd_bf16": (_long, []),
     "sn_pack_table_entries_bwd_bf16": (_long, []),
     "sn_build_pack_table_bwd_bf16": (_int, [c_vp]),
+    "sn_packed_weights_bytes_bwd_bf16x3": (_long, []),
+    "sn_pack_table_entries_bwd_bf16x3": (_long, []),
+    "sn_build_pack_table_bwd_bf16x3": (_int, [c_vp]),
     "sn_sample_coarse": (_int, [c_fp, _long, _int, _int, _float, c_fp, c_fp, c_vp]),
     "sn_mlp_forward": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, _int, _int, c_fp, c_vp]),
     "sn_mlp_forward_train": (_int, [c_vp, _int, c_fp, c_fp, _long, _int, c_fp, c_fp, c_fp, _long, c_vp]),

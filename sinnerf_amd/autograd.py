@@ -34,13 +34,6 @@ def _emb16_supported():
     return _EMB16_OK
 
 
-def _train_dtype(model):
-    """the arithmetic of a network's BACKWARD (and of its training state): 'bf16x3' (fp32-level accuracy on the bf16 MFMA) has a
-    training forward that writes the fp32 state (csrc/sn_mlp_fwd_bf16x3.hip STORE) and no backward kernels of its own -- the chain
-    and the weight gradients of such a network are the fp32 ones"""
-    return "fp32" if dtype_code(model.compute_dtype) == _lib.SN_DTYPE_BF16X3 else model.compute_dtype
-
-
 def _sched_flag():
     return _lib.SN_DTYPE_COMPILER_SCHEDULED if COMPILER_SCHEDULED else 0
 
@@ -158,10 +151,12 @@ class _MLPFn(torch.autograd.Function):
             G[:, P:].zero_()
         g_o = torch.empty((P, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            code = dtype_code(_train_dtype(model))   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
+            # bf16x3: forward and chain at fp32-level accuracy on the bf16 MFMA over the FP32 training state (_state_code: the
+            # weight gradients of such a network are the fp32 contractions)
+            code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
             if acts.dtype == torch.bfloat16:
                 code = _lib.SN_DTYPE_BF16_STATE
-            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(_train_dtype(model))), model.kernel_dtype(code) | _sched_flag(),
+            _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(model.compute_dtype)), model.kernel_dtype(code) | _sched_flag(),
                                                       _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_out), P, rows, _lib.ptr(G),
                                                       _lib.ptr(g_o), _lib.stream_ptr()), "sn_mlp_backward_chain")
             needs = ctx.needs_input_grad[3:]

@@ -20,6 +20,10 @@ int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float* acts, cons
 int sn_mlp_backward_chain_bf16_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                       long n_points, long slot_rows, float* G, float* g_out, int state_bf16,
                                       hipStream_t stream);
+int sn_mlp_backward_chain_bf16x3_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                        long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
+int sn_mlp_backward_chain_bf16x3_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                                long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
 long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype, int emb16);
 int sn_weight_grads_launch(const void* acts, const float* emb, const void* G, long slot_rows, int dtype, int emb16, void* workspace,
@@ -156,6 +160,14 @@ int sn_build_pack_table_bwd_bf16(int32_t* table_host) {
   return 0;
 }
 
+long sn_packed_weights_bytes_bwd_bf16x3(void) { return snl::bbxblob_bytes(); }
+long sn_pack_table_entries_bwd_bf16x3(void) { return snl::bbx_table_entries(); }
+int sn_build_pack_table_bwd_bf16x3(int32_t* table_host) {
+  if (!table_host) return SN_E_BADARG;
+  snl::build_pack_table_bwd_bf16x3(reinterpret_cast<snl::PackEntry*>(table_host));
+  return 0;
+}
+
 int sn_pack_weights(const float* const* raw, const int32_t* table, long n_entries, void* blob, int dtype, void* stream) {
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
   if (!raw || !table || !blob || n_entries <= 0) return SN_E_BADARG;
@@ -245,9 +257,11 @@ int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, co
   const bool classic = dtype & SN_DTYPE_CLASSIC_HEADS;
   const bool compiler_scheduled = dtype & SN_DTYPE_COMPILER_SCHEDULED;
   dtype &= ~(SN_DTYPE_CLASSIC_HEADS | SN_DTYPE_COMPILER_SCHEDULED);
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
-  const long tile = dtype == SN_DTYPE_F32 ? 128 : 256;                       // whole point tiles are written
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
+  const long tile = (dtype == SN_DTYPE_F32 || dtype == SN_DTYPE_BF16X3) ? 128 : 256;      // whole point tiles are written
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
+  if (dtype == SN_DTYPE_BF16X3)                  // fp32-level accuracy on the bf16 MFMA over the fp32 state (blob: *_bwd_bf16x3 table)
+    return SN_HEADS(classic, sn_mlp_backward_chain_bf16x3)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256)         // the hand-scheduled kernel
     return SN_HEADS(classic, sn_mlp_backward_chain_bf16_t)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32)

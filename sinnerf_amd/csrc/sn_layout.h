@@ -343,4 +343,37 @@ inline void build_pack_table_bwd_bf16(PackEntry* out) {
   }
 }
 
+
+// ================================================================================================
+// Backward-chain blob, bf16x3 (sn_mlp_bwd_bf16x3.hip): the slabs of the bf16 chain blob above with every weight as a (hi, lo)
+// bf16 pair -- per k-step the hi fragment then the lo fragment (DT_BF16X3) -- and the same fp32 tail (zero bias slots, rgbT, sigT).
+constexpr long bbx_tail_byte_offset() { return BB_TOTAL_ELEMS * 4; }
+constexpr long bbxblob_bytes() { return bbx_tail_byte_offset() + (long)BB_TAIL_FLOATS * 4; }
+constexpr long bbx_table_entries() { return 2 * BB_TOTAL_ELEMS + BB_TAIL_FLOATS; }
+
+inline void build_pack_table_bwd_bf16x3(PackEntry* out) {
+  // the weight entries of the bf16 table, doubled; its tail entries, moved
+  PackEntry* b16 = new PackEntry[bb_table_entries()];
+  build_pack_table_bwd_bf16(b16);
+  long n = 0;
+  for (long e = 0; e < BB_TOTAL_ELEMS; ++e) {
+    // element e of the bf16 blob sits at byte 2e = ((frag * 64 + lane) * 8 + j) * 2 with frag = 1 KB fragment index over the
+    // whole stream (slabs are whole numbers of fragments): its pair goes to fragments 2 frag (hi) and 2 frag + 1 (lo)
+    const long byte16 = b16[e].dst;
+    const long frag = byte16 / 1024, within = byte16 % 1024;
+    for (int part = 0; part < 2; ++part) {
+      PackEntry x;
+      x.dst = (int32_t)((2 * frag + part) * 1024 + within);
+      x.src = b16[e].src >= 0 ? (b16[e].src | (part ? SRC_LO_FLAG : 0)) : b16[e].src;
+      out[n++] = x;
+    }
+  }
+  for (long e = BB_TOTAL_ELEMS; e < bb_table_entries(); ++e) {
+    PackEntry x = b16[e];
+    x.dst = (int32_t)(x.dst - bb_tail_byte_offset() + bbx_tail_byte_offset());
+    out[n++] = x;
+  }
+  delete[] b16;
+}
+
 }  // namespace snl

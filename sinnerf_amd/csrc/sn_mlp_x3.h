@@ -1,0 +1,217 @@
+// sn_mlp_x3.h -- building blocks of the bf16x3 kernels (sn_mlp_fwd_bf16x3.hip, sn_mlp_bwd_bf16x3.hip): fp32-level accuracy on the
+// bf16 MFMA from the 3-term split  W.x ~= Wh.xh + Wl.xh + Wh.xl  of (hi, lo) bf16 operand pairs, fp32 accumulation.
+// A wave owns ONE 32-point tile; the hand-managed AGPR file holds two activation sets x (hi, lo) x 64 registers.
+#pragma once
+#include "sn_mlp_bf16.h"
+
+namespace snk {
+
+constexpr int X3_LDS_BYTES = MLP_F32_LDS_BYTES_V2;                      // tail + 3 x 40 KB
+// AGPR of (activation set, part 0 = hi / 1 = lo, k-step): 4 registers each
+constexpr int x3_reg(int set, int part, int ks) { return set * 128 + part * 64 + ks * 4; }
+
+// ---- MFMAs: D (+)= A.B ; A fragment in VGPRs, B in AGPRs (immediates) or VGPRs; ZERO = chain B's first MFMA (C = 0)
+template <bool FIRST, bool ZERO>
+SN_DEV void x3_mma_a(f32x16& acc, const u32x4& a, int reg) {
+  if (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], 0" : "=&v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
+  else if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
+}
+template <bool FIRST, bool ZERO>
+SN_DEV void x3_mma_v(f32x16& acc, const u32x4& a, const u32x4& b) {
+  if (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+  else if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+// (hi, lo) split of four fp32 values into packed bf16 pairs: h = RNE(x), l = RNE(x - float(h))
+SN_DEV void x3_split4(const float (&x)[4], uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
+  float r0, r1, r2, r3;
+  asm("v_cvt_pk_bf16_f32 %0, %8, %9\n\tv_cvt_pk_bf16_f32 %1, %10, %11\n\t"
+      "v_lshlrev_b32 %4, 16, %0\n\tv_and_b32 %5, 0xffff0000, %0\n\tv_lshlrev_b32 %6, 16, %1\n\tv_and_b32 %7, 0xffff0000, %1\n\t"
+      "v_sub_f32 %4, %8, %4\n\tv_sub_f32 %5, %9, %5\n\tv_sub_f32 %6, %10, %6\n\tv_sub_f32 %7, %11, %7\n\t"
+      "v_cvt_pk_bf16_f32 %2, %4, %5\n\tv_cvt_pk_bf16_f32 %3, %6, %7"
+      : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+}
+SN_DEV void x3_split8(const float* f, u32x4& hi, u32x4& lo) {
+  const float a[4] = {f[0], f[1], f[2], f[3]}, b[4] = {f[4], f[5], f[6], f[7]};
+  uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+  x3_split4(a, h0, h1, l0, l1);
+  x3_split4(b, h2, h3, l2, l3);
+  hi = u32x4{h0, h1, h2, h3};
+  lo = u32x4{l0, l1, l2, l3};
+}
+
+// Epilogue block: accumulator registers 4i..4i+3 of both chains -> v = act(A + B) (RELU: max with 0), its hi / lo pairs into
+// a[rh], a[rh+1] / a[rl], a[rl+1].  One volatile asm: program order relative to the MFMA asm is what keeps the hazard distances.
+template <bool RELU>
+SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], float (&v)[4]) {
+  uint32_t h0, h1, l0, l1;
+  float r0, r1, r2, r3;
+  if (RELU)
+    asm volatile("v_add_f32 %0, %12, %16\n\tv_add_f32 %1, %13, %17\n\tv_add_f32 %2, %14, %18\n\tv_add_f32 %3, %15, %19\n\t"
+                 "v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3\n\t"
+                 "v_cvt_pk_bf16_f32 %4, %0, %1\n\tv_cvt_pk_bf16_f32 %5, %2, %3\n\t"
+                 "v_lshlrev_b32 %8, 16, %4\n\tv_and_b32 %9, 0xffff0000, %4\n\tv_lshlrev_b32 %10, 16, %5\n\tv_and_b32 %11, 0xffff0000, %5\n\t"
+                 "v_accvgpr_write_b32 a[%20], %4\n\tv_accvgpr_write_b32 a[%21], %5\n\t"
+                 "v_sub_f32 %8, %0, %8\n\tv_sub_f32 %9, %1, %9\n\tv_sub_f32 %10, %2, %10\n\tv_sub_f32 %11, %3, %11\n\t"
+                 "v_cvt_pk_bf16_f32 %6, %8, %9\n\tv_cvt_pk_bf16_f32 %7, %10, %11\n\t"
+                 "v_accvgpr_write_b32 a[%22], %6\n\tv_accvgpr_write_b32 a[%23], %7"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1),
+                   "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+                   "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
+  else
+    asm volatile("v_add_f32 %0, %12, %16\n\tv_add_f32 %1, %13, %17\n\tv_add_f32 %2, %14, %18\n\tv_add_f32 %3, %15, %19\n\t"
+                 "v_cvt_pk_bf16_f32 %4, %0, %1\n\tv_cvt_pk_bf16_f32 %5, %2, %3\n\t"
+                 "v_lshlrev_b32 %8, 16, %4\n\tv_and_b32 %9, 0xffff0000, %4\n\tv_lshlrev_b32 %10, 16, %5\n\tv_and_b32 %11, 0xffff0000, %5\n\t"
+                 "v_accvgpr_write_b32 a[%20], %4\n\tv_accvgpr_write_b32 a[%21], %5\n\t"
+                 "v_sub_f32 %8, %0, %8\n\tv_sub_f32 %9, %1, %9\n\tv_sub_f32 %10, %2, %10\n\tv_sub_f32 %11, %3, %11\n\t"
+                 "v_cvt_pk_bf16_f32 %6, %8, %9\n\tv_cvt_pk_bf16_f32 %7, %10, %11\n\t"
+                 "v_accvgpr_write_b32 a[%22], %6\n\tv_accvgpr_write_b32 a[%23], %7"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1),
+                   "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+                   "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
+}
+
+// One slab: NK0 + NK1 k-steps (two K segments), barrier after k-step GB (the 3-slot protocol of sn_mlp_pipe.h).
+//   SET0/SET1  B operands of the segment: AGPR activation set 0/1, or -1 = the VGPR arrays bh / bl ([k-step])
+//   accA/accB  the two chains of this slab (accA bias-initialised on entry, accB started by its first MFMA with C = 0)
+//   nA         chain A of the NEXT slab: receives that slab's bias at the sync point (pending() has consumed the previous
+//              slab's results -- which live in nA / nB -- behind k-step 0)
+//   af         ring of A-fragment PAIRS (hi, lo), prefetch distance 3 k-steps: fragments of k-steps 0, 1, 2 of this slab sit in
+//              af[(PHASE + 0..2) & 3] at entry; PHASE' = (PHASE + NK) & 3 at exit
+//   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead), a multiple of 4 KB for every K
+//   VMW        counted wait at the sync point (training forward): the youngest VMW vector-memory operations of the wave are row
+//              stores issued BEHIND the previous slab's DMA pieces and may stay in flight; the barrier is then a raw s_barrier
+//   post(step, n)  memory operations of the caller, once per k-step behind the sync point (step = ks - GB of n = NK - GB): with
+//              before = true in FRONT of the k-step's DMA pieces (the chain's mask loads), with false BEHIND them (row stores:
+//              x3_store_step maps the LAST four steps to the four row-group stores of the previous tile)
+template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, int VMW = 0, class RingX, class Pending, class Post>
+SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], const char* lw, const u32x4* bh, const u32x4* bl,
+                    const char* lw_next, const float* lds_bias, int s_next, int h, RingX& ring, Pending&& pending, Post&& post) {
+  constexpr int NK = NK0 + NK1;
+  constexpr int NP = NBYTES / 4096;
+  constexpr int PPK = (NP + (NK - GB) - 1) / (NK - GB);
+  constexpr int NPS = (NP + PPK - 1) / PPK;                  // k-steps that carry DMA pieces: GB .. GB + NPS - 1
+  static_assert(NBYTES % 4096 == 0 && GB >= 1 && GB + 3 <= NK && NK >= 4, "whole pieces; sync point inside the slab");
+  static_assert(NK >= 8 ? GB + NPS <= NK : true, "one piece per k-step behind the sync point");
+  (void)NPS;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    if (ks == GB) {
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
+      if (VMW == 0) __syncthreads();
+      else __builtin_amdgcn_s_barrier();
+      ring.begin_static();
+      nA = load_bias(lds_bias, s_next, h);
+    }
+    {
+      const int kn = ks + 3;
+      const char* src = (kn < NK) ? lw + kn * 2048 : lw_next + (kn - NK) * 2048;
+      af[(PHASE + kn) & 3][0] = *reinterpret_cast<const u32x4*>(src);
+      af[(PHASE + kn) & 3][1] = *reinterpret_cast<const u32x4*>(src + 1024);
+    }
+    if (ks >= GB) {
+      post(ks - GB, NK - GB, true);
+#pragma unroll
+      for (int i = 0; i < PPK; ++i)
+        if ((ks - GB) * PPK + i < NP) ring.piece_static();
+      post(ks - GB, NK - GB, false);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const u32x4 a_hi = af[(PHASE + ks) & 3][0], a_lo = af[(PHASE + ks) & 3][1];
+    // even k-steps: A += Wh.xh ; B += Wl.xh ; A += Wh.xl        odd: B += Wh.xh ; A += Wl.xh ; B += Wh.xl
+    const bool even = (ks & 1) == 0;
+    f32x16& c0 = even ? accA : accB;
+    f32x16& c1 = even ? accB : accA;
+    const bool seg0 = ks < NK0;
+    const int kk = seg0 ? ks : ks - NK0;
+    const int set = seg0 ? SET0 : SET1;
+    if (ks == 0) {
+      if (set < 0) {
+        x3_mma_v<true, false>(c0, a_hi, bh[kk]);
+        x3_mma_v<false, true>(c1, a_lo, bh[kk]);
+        x3_mma_v<false, false>(c0, a_hi, bl[kk]);
+      } else {
+        x3_mma_a<true, false>(c0, a_hi, x3_reg(set, 0, kk));
+        x3_mma_a<false, true>(c1, a_lo, x3_reg(set, 0, kk));
+        x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
+      }
+    } else if (set < 0) {
+      x3_mma_v<false, false>(c0, a_hi, bh[kk]);
+      x3_mma_v<false, false>(c1, a_lo, bh[kk]);
+      x3_mma_v<false, false>(c0, a_hi, bl[kk]);
+    } else {
+      x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 0, kk));
+      x3_mma_a<false, false>(c1, a_lo, x3_reg(set, 0, kk));
+      x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks == 0) {
+      pending();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  ring.template end_static<NP>();
+}
+
+// 16-byte write into a wave's staging tile as inline asm (hipcc guards every LDS write it sees with s_waitcnt vmcnt(0) while
+// LDS-DMA pieces may be in flight, sn_mlp_bf16.h): lds = byte address in LDS (dynamic LDS starts at 0), off = compile-time part
+SN_DEV void x3_lds_write_b128(unsigned lds, int off, const float (&v)[4]) {
+  f32x4 o;
+  o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(lds), "v"(o), "n"(off) : "memory");
+}
+
+
+// four fp32 values -> their (hi, lo) bf16 pairs in a[rh], a[rh+1] / a[rl], a[rl+1] (no activation: values computed on the VALU)
+SN_DEV void x3_put(int rh, int rl, const float (&x)[4]) {
+  uint32_t h0, h1, l0, l1;
+  float r0, r1, r2, r3;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %8, %9\n\tv_cvt_pk_bf16_f32 %1, %10, %11\n\t"
+               "v_lshlrev_b32 %4, 16, %0\n\tv_and_b32 %5, 0xffff0000, %0\n\tv_lshlrev_b32 %6, 16, %1\n\tv_and_b32 %7, 0xffff0000, %1\n\t"
+               "v_accvgpr_write_b32 a[%12], %0\n\tv_accvgpr_write_b32 a[%13], %1\n\t"
+               "v_sub_f32 %4, %8, %4\n\tv_sub_f32 %5, %9, %5\n\tv_sub_f32 %6, %10, %6\n\tv_sub_f32 %7, %11, %7\n\t"
+               "v_cvt_pk_bf16_f32 %2, %4, %5\n\tv_cvt_pk_bf16_f32 %3, %6, %7\n\t"
+               "v_accvgpr_write_b32 a[%14], %2\n\tv_accvgpr_write_b32 a[%15], %3"
+               : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
+}
+// ... masked by the forward activations (backward of ReLU, nerf.py:73): v = a > 0 ? x : 0, then as x3_put
+SN_DEV void x3_put_masked(int rh, int rl, const float (&x)[4], const f32x4& a, float (&v)[4]) {
+  uint32_t h0, h1, l0, l1;
+  float r0, r1, r2, r3;
+  asm volatile("v_cmp_lt_f32 vcc, 0, %16\n\tv_cndmask_b32 %8, 0, %12, vcc\n\t"
+               "v_cmp_lt_f32 vcc, 0, %17\n\tv_cndmask_b32 %9, 0, %13, vcc\n\t"
+               "v_cmp_lt_f32 vcc, 0, %18\n\tv_cndmask_b32 %10, 0, %14, vcc\n\t"
+               "v_cmp_lt_f32 vcc, 0, %19\n\tv_cndmask_b32 %11, 0, %15, vcc\n\t"
+               "v_cvt_pk_bf16_f32 %0, %8, %9\n\tv_cvt_pk_bf16_f32 %1, %10, %11\n\t"
+               "v_lshlrev_b32 %4, 16, %0\n\tv_and_b32 %5, 0xffff0000, %0\n\tv_lshlrev_b32 %6, 16, %1\n\tv_and_b32 %7, 0xffff0000, %1\n\t"
+               "v_accvgpr_write_b32 a[%20], %0\n\tv_accvgpr_write_b32 a[%21], %1\n\t"
+               "v_sub_f32 %4, %8, %4\n\tv_sub_f32 %5, %9, %5\n\tv_sub_f32 %6, %10, %6\n\tv_sub_f32 %7, %11, %7\n\t"
+               "v_cvt_pk_bf16_f32 %2, %4, %5\n\tv_cvt_pk_bf16_f32 %3, %6, %7\n\t"
+               "v_accvgpr_write_b32 a[%22], %2\n\tv_accvgpr_write_b32 a[%23], %3"
+               : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3),
+                 "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]),
+                 "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1)
+               : "vcc");
+}
+
+// the four row-group stores of a finished tile over the memory steps of the next slab: the LAST four steps carry one each
+// (a 4-k-step slab has three steps behind its sync point: 1 + 1 + 2); f(i) issues store i
+template <class F>
+SN_DEV void x3_store_step(int step, int n, F&& f) {
+  if (n >= 4) {
+    if (step >= n - 4) f(step - (n - 4));
+  } else if (step < 2) {
+    f(step);
+  } else {
+    f(2); f(3);
+  }
+}
+
+}  // namespace snk

@@ -18,8 +18,8 @@ from . import _lib
 
 _DTYPES = {"fp32": _lib.SN_DTYPE_F32, "float32": _lib.SN_DTYPE_F32, torch.float32: _lib.SN_DTYPE_F32,
            "bf16": _lib.SN_DTYPE_BF16, "bfloat16": _lib.SN_DTYPE_BF16, torch.bfloat16: _lib.SN_DTYPE_BF16,
-           # fp32-level accuracy on the bf16 matrix cores (3-term hi/lo split, csrc/sn_mlp_fwd_bf16x3.hip): inference and the
-           # training FORWARD (fp32 state); the backward of such a network runs the fp32 kernels
+           # fp32-level accuracy on the bf16 matrix cores (3-term hi/lo split, csrc/sn_mlp_{fwd,bwd}_bf16x3.hip): inference, and
+           # under autograd the forward and the backward chain over the FP32 training state (weight gradients: the fp32 contractions)
            "bf16x3": _lib.SN_DTYPE_BF16X3}
 
 
@@ -76,6 +76,8 @@ def _pack_table_bwd(device, code):
     bf16 = code == _lib.SN_DTYPE_BF16
     n_entries, build, n_bytes = ((_lib.lib.sn_pack_table_entries_bwd_bf16, _lib.lib.sn_build_pack_table_bwd_bf16,
                                   _lib.lib.sn_packed_weights_bytes_bwd_bf16) if bf16 else
+                                 (_lib.lib.sn_pack_table_entries_bwd_bf16x3, _lib.lib.sn_build_pack_table_bwd_bf16x3,
+                                  _lib.lib.sn_packed_weights_bytes_bwd_bf16x3) if code == _lib.SN_DTYPE_BF16X3 else
                                  (_lib.lib.sn_pack_table_entries_bwd, _lib.lib.sn_build_pack_table_bwd,
                                   _lib.lib.sn_packed_weights_bytes_bwd))
     key = (str(device), "bwd", code)
@@ -179,7 +181,7 @@ class NeRF(nn.Module):
         for t in raws:
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("sinnerf_amd.NeRF: parameters must be contiguous float32 master weights")
-        if self._training_pack(raws) and code != _lib.SN_DTYPE_BF16X3:     # (bf16x3 trains with the fp32 backward blob: packed apart)
+        if self._training_pack(raws):
             return self._pack_both(code, raws, dev, sig)[0]
         blob = hit[0] if (hit is not None and hit[0].device == dev) else \
             torch.empty(_lib.lib.sn_packed_weights_bytes(code), dtype=torch.uint8, device=dev)
