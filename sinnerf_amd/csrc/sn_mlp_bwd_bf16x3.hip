@@ -2,18 +2,21 @@
 // (SN_DTYPE_BF16X3 of sn_mlp_backward_chain): g_x = W^T g_y, g_y = g_h (.) act'(.) through every layer -- what torch autograd
 // derives from models/nerf.py:122-148 (+ models/activations.py) -- with the 3-term split of sn_mlp_x3.h:
 //     W^T g ~= Wh^T gh + Wl^T gh + Wh^T gl      (hi / lo bf16 pairs of the transposed weights and of the gradient, fp32 accumulate)
-// Same data as the fp32 chain (sn_mlp_bwd.hip): it READS the fp32 forward activations (ReLU masks [h > 0], ShiftedSoftplus
-// derivative 1 - exp(-h2)) and the forward output (WidenedSigmoid derivative), and WRITES the fp32 pre-activation gradients
+// Same data as the fp32 chain (sn_mlp_bwd.hip), except that the ReLU masks [h > 0] come from the SIGN WORDS the bf16x3 training
+// forward left in the unused half of acts slot 9 (256 B per point and layer instead of 1 KB of activations; sn_mlp_x3.h
+// x3_sign_bits): it READS those, the dir_encoding outputs (ShiftedSoftplus derivative 1 - exp(-h2)) and the forward output
+// (WidenedSigmoid derivative) -- so `acts` must be the array sn_mlp_forward_train(SN_DTYPE_BF16X3) wrote -- and WRITES the fp32 pre-activation gradients
 // G[10][slot_rows][256] (+ the 4-wide head block in slot 9) that the weight-gradient contractions consume -- the fp32 training
 // state, value for value at fp32 rounding level.  Same machinery as the bf16x3 forward: one 32-point tile per wave, two
 // accumulator chains, (hi, lo) activation sets in the hand-managed AGPR file, transposed (hi, lo) weight slabs of K x 128 B
 // through a 3-slot LDS ring (csrc/sn_layout.h "Backward-chain blob, bf16x3").
 //
-// Memory operations of a slab (its time is 48 MFMAs x 32 cycles: no drain per slab is affordable): the four mask loads of the
-// tile THIS slab computes are inline-asm loads in FRONT of the first four DMA pieces, the four row-group stores of the previous
-// tile sit in the last four k-steps; every wait is COUNTED (vmcnt retires in issue order): the epilogue waits for the loads with
-// the later pieces and the stores still in flight, the sync point for the pieces with the stores in flight, at a fence-less
-// barrier.  Staging writes are inline asm (sn_mlp_bf16.h).
+// Memory operations of a slab (its time is 48 MFMAs x 32 cycles: no drain per slab is affordable): the four row-group stores of the
+// previous tile in its last four k-steps, behind the DMA pieces; the sync point waits for the pieces with those stores in flight
+// (COUNTED vmcnt, fence-less barrier); the four sign words of a layer are ONE 16-byte inline-asm load per lane issued a whole
+// layer ahead.  Staging writes are inline asm (sn_mlp_bf16.h).  (First version: the fp32 activation tiles as masks, four scattered
+// 16-byte loads per lane and slab one slab ahead -- 3.26 ms per 524 288 points against the forward's 1.99: latency- and
+// address-path-bound.)
 #include "sn_mlp_x3.h"
 
 namespace snk {
@@ -23,9 +26,10 @@ constexpr int BX3_TAIL_BYTES = snl::BB_TAIL_FLOATS * 4;                    // 11
 constexpr int BX3_LDS_BYTES = BX3_TAIL_BYTES + 3 * BX3_SLOT + XPOSE_LDS_BYTES;     // 128512
 typedef RingT<128, BX3_SLOT> RingX3B;
 
-// one 16-byte load of the mask tile as inline asm: the WAIT is ours (hipcc treats loads and stores in flight as unordered and would
-// drain the row stores issued behind this load with vmcnt(0)); s_nop 4: SALU write of the base -> its use as a VMEM address
-SN_DEV void x3_load_b128(f32x4& dst, unsigned voff, const char* base) {
+// the 16-byte load of a layer's sign words as inline asm: no compiler wait (hipcc treats loads and stores in flight as unordered and
+// would drain the row stores issued behind this load with vmcnt(0)); it is covered by the counted waits of the eight sync points
+// that follow before its first use.  s_nop 4: SALU write of the base -> its use as a VMEM address
+SN_DEV void x3_load_b128(u32x4& dst, unsigned voff, const char* base) {
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
 
@@ -85,7 +89,7 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
   const unsigned xp_w_lds = (unsigned)(BX3_TAIL_BYTES + 3 * BX3_SLOT + wave * XPOSE_WAVE_BYTES) + (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
-  const unsigned a_off = (unsigned)(j * 256 + 4 * h) * 4u;                 // this lane's 16 bytes of a point row (accumulator layout)
+  const unsigned s_off = (unsigned)((lane >> 4) * 1024 + (lane & 15) * 16);    // this lane's sign words inside a layer's four rows
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * 32;
@@ -122,13 +126,13 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
       }
     }
 
-    f32x4 av[4];                                                           // mask tile in flight (accumulator layout)
-    auto load_act = [&](int slot, int t, int i) __attribute__((always_inline)) {
-      const char* base = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + p_wave) * 256 + 32 * t + 8 * i) * 4;
-      unsigned ao = a_off;
-      asm volatile("" : "+v"(ao));
-      x3_load_b128(av[i], ao, base);
+    // ReLU sign words (sn_mlp_fwd_bf16x3.hip): layer l (acts slot l) = rows p_wave + 4 l .. + 3 of slot 9, bytes 512.. of each row
+    u32x4 sw, swn;                                                         // the running layer's four words; the next layer's, in flight
+    auto sign_base = [&](int slot) __attribute__((always_inline)) {
+      return reinterpret_cast<const char*>(acts) + (((long)9 * slot_rows + p_wave + 4 * slot) * 256 + 128) * 4;
     };
+    sw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sign_base(7) + s_off));      // xyz_encoding_8's (the first masked layer)
+    swn = sw;
     auto stage = [&](int qq, const float (&v)[4]) __attribute__((always_inline)) { x3_lds_write_b128(xp_w_lds, 32 * qq, v); };
     auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) {
       const f32x4 o = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
@@ -172,7 +176,6 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
     }
 
     int s = 0;
-    int mask_slot = 0;                                                     // acts slot of the ReLU mask of the running layer
     int out_slot = 0;                                                      // G slot the running layer writes
     auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {   // g_final: no activation
       constexpr int W = decltype(wset)::value;
@@ -189,6 +192,7 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
     auto mask_tile_impl = [&](auto wset, auto with_sigma, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {
       constexpr int W = decltype(wset)::value;
       constexpr bool SIG = decltype(with_sigma)::value;
+      const uint32_t word = sw[t >> 1];
 #pragma unroll
       for (int q = 0; q < 8; q += 2) {
         float x[4];
@@ -198,7 +202,7 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
           if (SIG) x[i] = __builtin_fmaf(lds_aux[snl::BB_AUX_SIGT + h * 128 + 16 * t + 2 * q + i], gsig, x[i]);
         }
         float v[4];
-        x3_put_masked(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), x, av[q >> 1], v);
+        x3_put_signed(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), x, word, q + 8 * (t & 1), v);
         stage(q >> 1, v);
       }
     };
@@ -212,72 +216,72 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
 #define SNY_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
 #define SNY_SNEXT (s + 1 == snl::NBB_SLABS ? 0 : s + 1)
 #define SNY_W(W_) std::integral_constant<int, W_>{}
-    // Slab of output tile T_ (literal), staging NB_ bytes (the slab two ahead).  Vector-memory operations it issues, in order:
-    //   steps 0..3 behind the sync point:  [mask load i of tile T_ (if MASK_)] [DMA piece i]
-    //   steps 4..NP-1:                     [DMA piece]
-    //   last four steps:                   [row-group store of tile T_ - 1 (if T_ > 0)]
-    // => younger than the last mask load: NP - 4 pieces (the piece of step 3 follows load 3: NP - 3) + the stores;
-    //    younger than the last piece: the stores.  The epilogue of tile T_ - 1 (it consumes the loads of slab T_ - 1) therefore
-    //    waits with LW_ = (NBP_ / 4096 - 3) + (T_ - 1 > 0 ? 4 : 0) in flight, NBP_ = what slab T_ - 1 staged; the sync point with
-    //    the previous slab's stores (T_ - 1 > 0: 4) in flight; at T_ = 0 the youngest eight are the previous layer's last stores.
-#define SNY_SLAB(T_, NK_, SET_, NB_, NBP_, EPI_, W_, MASK_, PMASK_)                                                \
+    // Slab of output tile T_ (literal), staging NB_ bytes (the slab two ahead).  The youngest four vector-memory operations of a wave
+    // at the sync point are the row stores the previous slab posted behind its DMA pieces (T_ = 1: its predecessor posts none; T_ = 0:
+    // the previous layer's last eight stores, and possibly the next layer's sign-word load behind them)
+#define SNY_SLAB(T_, NK_, SET_, NB_, EPI_, W_)                                                                     \
   do {                                                                                                             \
     constexpr int VW_ = ((T_) != 1) ? 4 : 0;                                                                       \
-    constexpr int LW_ = ((NBP_) / 4096 - 3) + ((T_) > 1 ? 4 : 0);                                                  \
     if (((T_) & 1) == 0)                                                                                           \
       slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a0, b0, a1, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
-          [&]() __attribute__((always_inline)) {                                                                   \
-            if ((T_) > 0) {                                                                                        \
-              if (PMASK_) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]) : "n"(LW_) : "memory"); \
-              EPI_(SNY_W(W_), (T_) - 1, a1, b1);                                                                   \
-            } },                                                                                                   \
+          [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNY_W(W_), (T_) - 1, a1, b1); },               \
           [&](int st, int n, bool before) __attribute__((always_inline)) {                                         \
-            if (before) { if (MASK_ && st < 4) load_act(mask_slot, T_, st); }                                      \
-            else if ((T_) > 0) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
+            if (!before && (T_) > 0) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
     else                                                                                                           \
       slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a1, b1, a0, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
-          [&]() __attribute__((always_inline)) {                                                                   \
-            if (PMASK_) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]) : "n"(LW_) : "memory"); \
-            EPI_(SNY_W(W_), (T_) - 1, a0, b0); },                                                                  \
+          [&]() __attribute__((always_inline)) { EPI_(SNY_W(W_), (T_) - 1, a0, b0); },                             \
           [&](int st, int n, bool before) __attribute__((always_inline)) {                                         \
-            if (before) { if (MASK_ && st < 4) load_act(mask_slot, T_, st); }                                      \
-            else x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
+            if (!before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
   } while (0)
-    // the 8 output tiles of a transposed layer; tiles 6, 7 stage the NEXT layer's slabs (NBB_).  The last tile's epilogue is not
-    // deferred: behind its loads slab 7 issued NBB_ / 4096 - 3 pieces and four stores
-#define SNY_LAYER(NK_, SET_, NBA_, NBB_, EPI_, W_, MASK_)                       \
+    // the 8 output tiles of a transposed layer; tiles 6, 7 stage the NEXT layer's slabs (NBB_); the last tile's epilogue is not deferred
+#define SNY_LAYER(NK_, SET_, NBA_, NBB_, EPI_, W_)                              \
   do {                                                                          \
-    SNY_SLAB(0, NK_, SET_, NBA_, NBA_, EPI_, W_, MASK_, MASK_);                 \
-    SNY_SLAB(1, NK_, SET_, NBA_, NBA_, EPI_, W_, MASK_, MASK_);                 \
-    SNY_SLAB(2, NK_, SET_, NBA_, NBA_, EPI_, W_, MASK_, MASK_);                 \
-    SNY_SLAB(3, NK_, SET_, NBA_, NBA_, EPI_, W_, MASK_, MASK_);                 \
-    SNY_SLAB(4, NK_, SET_, NBA_, NBA_, EPI_, W_, MASK_, MASK_);                 \
-    SNY_SLAB(5, NK_, SET_, NBA_, NBA_, EPI_, W_, MASK_, MASK_);                 \
-    SNY_SLAB(6, NK_, SET_, NBB_, NBA_, EPI_, W_, MASK_, MASK_);                 \
-    SNY_SLAB(7, NK_, SET_, NBB_, NBB_, EPI_, W_, MASK_, MASK_);                 \
-    mfma_result_fence();                                                        \
-    if (MASK_) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]) : "n"((NBB_) / 4096 - 3 + 4) : "memory"); \
+    SNY_SLAB(0, NK_, SET_, NBA_, EPI_, W_);                                     \
+    SNY_SLAB(1, NK_, SET_, NBA_, EPI_, W_);                                     \
+    SNY_SLAB(2, NK_, SET_, NBA_, EPI_, W_);                                     \
+    SNY_SLAB(3, NK_, SET_, NBA_, EPI_, W_);                                     \
+    SNY_SLAB(4, NK_, SET_, NBA_, EPI_, W_);                                     \
+    SNY_SLAB(5, NK_, SET_, NBA_, EPI_, W_);                                     \
+    SNY_SLAB(6, NK_, SET_, NBB_, EPI_, W_);                                     \
+    SNY_SLAB(7, NK_, SET_, NBB_, EPI_, W_);                                     \
+    x3_result_fence(a1, b1);                                                    \
     EPI_(SNY_W(W_), 7, a1, b1);                                                 \
     store_rows(out_slot, 7, 0); store_rows(out_slot, 7, 1);                     \
     store_rows(out_slot, 7, 2); store_rows(out_slot, 7, 3);                     \
   } while (0)
+    // the sign words of the NEXT masked layer (acts slot `slot`) are requested at the start of the running one: eight sync points
+    // with counted waits lie between the request and the hand-over at the next layer's start
+#define SNY_PREFETCH_SIGNS(slot_)                                               \
+  do {                                                                          \
+    unsigned so_ = s_off;                                                       \
+    asm volatile("" : "+v"(so_));                                               \
+    x3_load_b128(swn, so_, sign_base(slot_));                                   \
+  } while (0)
+#define SNY_TAKE_SIGNS()                                                        \
+  do {                                                                          \
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(swn) :: "memory");                 \
+    sw = swn;                                                                   \
+  } while (0)
 
     // ---- dir_encoding.0^T (first 256 inputs): g_final = W_d[:, :256]^T g_y2; reads set 0 (8 k-steps), writes set 1
     out_slot = 8;
-    SNY_LAYER(8, 0, B_D, B_H, copy_tile, 1, false);
+    SNY_LAYER(8, 0, B_D, B_H, copy_tile, 1);
     // ---- xyz_encoding_final^T (+ sigma^T on the VALU): g_y8 = (W_f^T g_final + w_sigma g_sigma) [h8 > 0]; set 1 -> set 0
-    mask_slot = 7; out_slot = 7;
-    SNY_LAYER(16, 1, B_H, B_H, mask_sigma_tile, 0, true);
-    // ---- xyz_encoding_{li+1}^T, li = 7..1: g_y_{li-1} = (W^T g_y_li) [h_li > 0]; odd li reads set 0 and writes set 1
+    out_slot = 7;                                                          // (sw = the words of acts slot 7, loaded above)
+    SNY_PREFETCH_SIGNS(6);
+    SNY_LAYER(16, 1, B_H, B_H, mask_sigma_tile, 0);
+    // ---- xyz_encoding_{li+1}^T, li = 7..1: g_y_{li-1} = (W^T g_y_li) [h_li > 0] (acts slot li - 1); odd li reads set 0, writes set 1
 #pragma unroll 1
     for (int li = 7; li >= 1; --li) {
-      mask_slot = li - 1; out_slot = li - 1;
-      if (li == 1) SNY_LAYER(16, 0, B_H, B_D, mask_tile, 1, true);          // tiles 6, 7 stage the next point tile's DIRT slabs
-      else if (li & 1) SNY_LAYER(16, 0, B_H, B_H, mask_tile, 1, true);
-      else SNY_LAYER(16, 1, B_H, B_H, mask_tile, 0, true);
+      out_slot = li - 1;
+      SNY_TAKE_SIGNS();
+      if (li >= 2) SNY_PREFETCH_SIGNS(li - 2);
+      if (li == 1) SNY_LAYER(16, 0, B_H, B_D, mask_tile, 1);                // tiles 6, 7 stage the next point tile's DIRT slabs
+      else if (li & 1) SNY_LAYER(16, 0, B_H, B_H, mask_tile, 1);
+      else SNY_LAYER(16, 1, B_H, B_H, mask_tile, 0);
     }
 #undef SNY_LW_CUR
 #undef SNY_LW_NEXT
@@ -285,6 +289,8 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
 #undef SNY_W
 #undef SNY_SLAB
 #undef SNY_LAYER
+#undef SNY_PREFETCH_SIGNS
+#undef SNY_TAKE_SIGNS
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -141,6 +141,31 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     };
     // Epilogues of output tile t (chains ra + rb) writing activation set W: dword q of the tile = results 2q, 2q+1 -> k-steps
     // 2t (q < 4), 2t+1 of the next layer, hi part and lo part
+    // training forward: ReLU sign words for the backward chain (sn_mlp_x3.h x3_sign_bits): one word per lane and tile PAIR, the four
+    // words of a layer leave as ONE 16-byte store per lane into the unused half of slot 9 -- for the 32 points a wave owns, layer l
+    // sits in rows first point + 4 l + (lane >> 4), bytes [512 + 16 (lane & 15), + 16): 256 B per point and layer
+    uint32_t sgn = 0;
+    u32x4 sgn4 = {0u, 0u, 0u, 0u};
+    uint32_t c01 = 0x00010001u;
+    asm volatile("" : "+v"(c01));
+    auto sign_pair = [&](int t, int q, uint32_t h0, uint32_t h1) __attribute__((always_inline)) {
+      if (STORE) {
+        if ((t & 1) == 0 && q == 0) sgn = 0;
+        x3_sign_bits(sgn, h0, q + 8 * (t & 1), c01);
+        x3_sign_bits(sgn, h1, q + 1 + 8 * (t & 1), c01);
+      }
+    };
+    auto sign_tile_done = [&](int t) __attribute__((always_inline)) {
+      if (STORE && (t & 1)) {
+        sgn4[t >> 1] = sgn;
+        if (t == 7) {
+          char* base = reinterpret_cast<char*>(acts) + (((long)9 * slot_rows + p_wave + 4 * cur_slot) * 256 + 128) * 4;
+          unsigned so = (unsigned)((lane >> 4) * 1024 + (lane & 15) * 16);
+          asm volatile("" : "+v"(so));
+          __builtin_nontemporal_store(sgn4, reinterpret_cast<u32x4*>(base + so));
+        }
+      }
+    };
     auto relu_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {
       constexpr int W = decltype(wset)::value;
 #pragma unroll
@@ -148,9 +173,12 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
-        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v);
+        uint32_t h0, h1;
+        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1);
         stage(q >> 1, v);
+        sign_pair(t, q, h0, h1);
       }
+      sign_tile_done(t);
     };
     auto relu_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {   // layer 8
       constexpr int W = decltype(wset)::value;
@@ -161,13 +189,16 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
-        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v);
+        uint32_t h0, h1;
+        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1);
+        sign_pair(t, q, h0, h1);
         sg = __builtin_fmaf(w[0], v[0], sg);                 // sigma head on the fp32 ReLU outputs (nerf.py:136)
         sg = __builtin_fmaf(w[1], v[1], sg);
         sg = __builtin_fmaf(w[2], v[2], sg);
         sg = __builtin_fmaf(w[3], v[3], sg);
         stage(q >> 1, v);
       }
+      sign_tile_done(t);
     };
     auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {   // xyz_encoding_final
       constexpr int W = decltype(wset)::value;
@@ -213,7 +244,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     SNX_SLAB(5, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_);          \
     SNX_SLAB(6, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_);          \
     SNX_SLAB(7, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_);          \
-    mfma_result_fence();                                                        \
+    x3_result_fence(a1, b1);                                                        \
     EPI_(SNX_W(W_), 7, a1, b1);                                                 \
     store_rows(cur_slot, 7, 0); store_rows(cur_slot, 7, 1);                     \
     store_rows(cur_slot, 7, 2); store_rows(cur_slot, 7, 3);                     \
@@ -300,7 +331,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     SNX_SLAB(1, 16, 2, 0, -1, 2, 2, B_DIR, dh, dl, ssp_tile, 0);
     SNX_SLAB(2, 16, 2, 0, -1, 2, 0, B_L0, dh, dl, ssp_tile, 0);
     SNX_SLAB(3, 16, 2, 0, -1, 2, 2, B_L0, dh, dl, ssp_tile, 0);
-    mfma_result_fence();
+    x3_result_fence(a1, b1);
     ssp_tile(SNX_W(0), 3, a1, b1);
     store_rows(9, 3, 0); store_rows(9, 3, 1); store_rows(9, 3, 2); store_rows(9, 3, 3);
     {

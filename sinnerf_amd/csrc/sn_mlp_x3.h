@@ -24,6 +24,10 @@ SN_DEV void x3_mma_v(f32x16& acc, const u32x4& a, const u32x4& b) {
   else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
+// MFMA (8 passes) -> VALU read of its result at a layer end: the wait states the compiler would insert for a builtin MFMA.  The two
+// chains are operands: plain C++ arithmetic on them (A + B) could otherwise be scheduled above the wait (tools/check_agpr.py).
+SN_DEV void x3_result_fence(f32x16& a, f32x16& b) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b)); }
+
 // (hi, lo) split of four fp32 values into packed bf16 pairs: h = RNE(x), l = RNE(x - float(h))
 SN_DEV void x3_split4(const float (&x)[4], uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
   float r0, r1, r2, r3;
@@ -46,8 +50,8 @@ SN_DEV void x3_split8(const float* f, u32x4& hi, u32x4& lo) {
 // Epilogue block: accumulator registers 4i..4i+3 of both chains -> v = act(A + B) (RELU: max with 0), its hi / lo pairs into
 // a[rh], a[rh+1] / a[rl], a[rl+1].  One volatile asm: program order relative to the MFMA asm is what keeps the hazard distances.
 template <bool RELU>
-SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], float (&v)[4]) {
-  uint32_t h0, h1, l0, l1;
+SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], float (&v)[4], uint32_t& h0, uint32_t& h1) {
+  uint32_t l0, l1;
   float r0, r1, r2, r3;
   if (RELU)
     asm volatile("v_add_f32 %0, %12, %16\n\tv_add_f32 %1, %13, %17\n\tv_add_f32 %2, %14, %18\n\tv_add_f32 %3, %15, %19\n\t"
@@ -74,6 +78,37 @@ SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], flo
                    "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
                    "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
+}
+
+template <bool RELU>
+SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], float (&v)[4]) {
+  uint32_t h0, h1;
+  x3_epi<RELU>(rh, rl, a, b, v, h0, h1);
+}
+// ReLU sign bits of a packed pair of post-ReLU bf16 values (>= 0: "positive" is "bits != 0") into a per-lane word: bit k <- the low
+// value, bit 16 + k <- the high value.  c01 = 0x00010001 in a register (VOP3P takes no literal).  The training forward leaves one word
+// per lane and PAIR of 32-feature tiles (k = pair index 0..7 + 8 x (tile & 1)) for the backward chain: 256 B per point and layer
+// instead of the 1 KB of activations (the bf16-state kernels' idea, sn_mlp_bf16.h epi_relu_bits, in this kernel's tile shape).
+SN_DEV void x3_sign_bits(uint32_t& word, uint32_t pk, int k, uint32_t c01) {
+  uint32_t m;
+  asm("v_pk_min_u16 %0, %2, %3\n\tv_lshl_or_b32 %1, %0, %4, %1" : "=&v"(m), "+v"(word) : "v"(pk), "v"(c01), "n"(k));
+}
+// ... and the chain's use of them: v = (bit ? x : 0) for the four values of a block (pairs d, d + 1 of tile parity par), then as x3_put
+SN_DEV void x3_put_signed(int rh, int rl, const float (&x)[4], uint32_t word, int k, float (&v)[4]) {
+  uint32_t h0, h1, l0, l1;
+  float r0, r1, r2, r3;
+  asm volatile("v_bfe_i32 %4, %16, %17, 1\n\tv_bfe_i32 %5, %16, %18, 1\n\tv_bfe_i32 %6, %16, %19, 1\n\tv_bfe_i32 %7, %16, %20, 1\n\t"
+               "v_and_b32 %8, %4, %12\n\tv_and_b32 %9, %5, %13\n\tv_and_b32 %10, %6, %14\n\tv_and_b32 %11, %7, %15\n\t"
+               "v_cvt_pk_bf16_f32 %0, %8, %9\n\tv_cvt_pk_bf16_f32 %1, %10, %11\n\t"
+               "v_lshlrev_b32 %4, 16, %0\n\tv_and_b32 %5, 0xffff0000, %0\n\tv_lshlrev_b32 %6, 16, %1\n\tv_and_b32 %7, 0xffff0000, %1\n\t"
+               "v_accvgpr_write_b32 a[%21], %0\n\tv_accvgpr_write_b32 a[%22], %1\n\t"
+               "v_sub_f32 %4, %8, %4\n\tv_sub_f32 %5, %9, %5\n\tv_sub_f32 %6, %10, %6\n\tv_sub_f32 %7, %11, %7\n\t"
+               "v_cvt_pk_bf16_f32 %2, %4, %5\n\tv_cvt_pk_bf16_f32 %3, %6, %7\n\t"
+               "v_accvgpr_write_b32 a[%23], %2\n\tv_accvgpr_write_b32 a[%24], %3"
+               : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3),
+                 "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(word), "n"(k), "n"(k + 16), "n"(k + 1), "n"(k + 17),
+                 "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
 }
 
 // One slab: NK0 + NK1 k-steps (two K segments), barrier after k-step GB (the 3-slot protocol of sn_mlp_pipe.h).

@@ -174,8 +174,9 @@ def test_bf16x3_training_forward_writes_the_fp32_state(n_rays, S):
 
 @pytest.mark.parametrize("n_rays,S", [(60, 37), (512, 128)])
 def test_bf16x3_backward_chain_writes_the_fp32_gradient_state(n_rays, S):
-    """sn_mlp_backward_chain(SN_DTYPE_BF16X3) against sn_mlp_backward_chain(SN_DTYPE_F32) on the SAME stored activations (so the
-    ReLU masks are the same bits): every G slot and the head block agree at fp32 rounding level, g_out bit for bit"""
+    """sn_mlp_backward_chain(SN_DTYPE_BF16X3) against sn_mlp_backward_chain(SN_DTYPE_F32) on the SAME training state -- the one the
+    bf16x3 forward wrote: fp32 activations (the fp32 chain's masks) AND the ReLU sign words in the unused half of slot 9 (the bf16x3
+    chain's masks), so both chains see the same masks: every G slot and the head block agree at fp32 rounding level, g_out bit for bit"""
     from sinnerf_amd import _lib
     rays = O.lego_rays(400, 400, seed=0)[:: max(1, 160000 // n_rays)][:n_rays]
     z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n_rays, S)).astype(np.float32))
@@ -187,8 +188,23 @@ def test_bf16x3_backward_chain_writes_the_fp32_gradient_state(n_rays, S):
     out = torch.zeros((n_rays, S, 4), device=dev())
     acts = torch.zeros((10, rows, 256), device=dev())
     emb = torch.zeros((rows, 128), device=dev())
-    _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m32.packed()), m32.kernel_dtype(_lib.SN_DTYPE_F32), _lib.ptr(rays_t), _lib.ptr(z_t),
+    _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m3.packed()), m3.kernel_dtype(_lib.SN_DTYPE_BF16X3), _lib.ptr(rays_t), _lib.ptr(z_t),
                                              n_rays, S, _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()), "fwd")
+    # the sign words are what the activations say: bit (pair d, tile parity) of lane (j, h) <-> [h_l[point j][32 t + feature] > 0]
+    a = acts.cpu().numpy()
+    words = a[9].view(np.uint32)[:, 128:192]                               # (rows, 64): per wave 32 rows = 8 layers x 4 rows x 16 lanes x 4 words
+    for wave0 in (0, 32 * ((P - 1) // 32)):                                 # first and last (ragged) wave tile
+        for l in (0, 3, 7):
+            w = words[wave0 + 4 * l: wave0 + 4 * l + 4].reshape(64, 4)      # [lane][tile pair]
+            for lane in (0, 17, 33, 63):
+                jj, hh = lane & 31, lane >> 5
+                for t in range(8):
+                    for d in range(8):
+                        for e in range(2):
+                            r = 2 * d + e
+                            feat = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh
+                            bit = (int(w[lane, t >> 1]) >> (d + 8 * (t & 1) + 16 * e)) & 1
+                            assert bit == int(a[l, wave0 + jj, feat] > 0), (wave0, l, lane, t, d, e)
     g_raw = torch.from_numpy(np.random.RandomState(2).standard_normal((P, 4)).astype(np.float32)).to(dev())
     res = {}
     for dt, model, code in (("fp32", m32, _lib.SN_DTYPE_F32), (DT, m3, _lib.SN_DTYPE_BF16X3)):

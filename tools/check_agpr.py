@@ -41,7 +41,7 @@ def sregs(tok):
     return out
 
 for ln, l in enumerate(open(sys.argv[1]), 1):
-    m = re.match(r'^(_Z\S*(?:mlp_(?:fwd_bf16|fwd_bf16_v3|fwd_bf16_t|fwd_f32|bwd_chain_bf16|bwd_chain_bf16_t|bwd_chain_f32)_kernel|dw_f32_asm_kernel|dw_bf16_asm_kernel|dw_narrow_bf16_asm_kernel)\S*):', l)
+    m = re.match(r'^(_Z\S*(?:mlp_(?:fwd_bf16|fwd_bf16x3|fwd_bf16_v3|fwd_bf16_t|fwd_f32|bwd_chain_bf16|bwd_chain_bf16x3|bwd_chain_bf16_t|bwd_chain_f32)_kernel|dw_f32_asm_kernel|dw_bf16_asm_kernel|dw_narrow_bf16_asm_kernel)\S*):', l)
     if m: kern = m.group(1); continue
     if kern is None: continue
     if re.match(r'^\s*s_endpgm', l): kern = None; continue
