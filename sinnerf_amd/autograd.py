@@ -41,6 +41,8 @@ def _sched_flag():
 def _state_code(model, acts, emb=None):
     """C-ABI dtype of the stored training state: fp32 MFMAs, bf16 operands on fp32 state, or bf16 operands on bf16 state
     (| SN_DTYPE_EMB_BF16 when the embedded inputs were stored as bf16 operands too)."""
+    if dtype_code(model.compute_dtype) == _lib.SN_DTYPE_BF16X3:
+        return _lib.SN_DTYPE_BF16X3               # fp32 state, contractions as 3-term hi/lo splits on the bf16 MFMA
     if dtype_code(model.compute_dtype) != _lib.SN_DTYPE_BF16:
         return _lib.SN_DTYPE_F32
     code = _lib.SN_DTYPE_BF16_STATE if acts.dtype == torch.bfloat16 else _lib.SN_DTYPE_BF16
@@ -151,8 +153,7 @@ class _MLPFn(torch.autograd.Function):
             G[:, P:].zero_()
         g_o = torch.empty((P, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            # bf16x3: forward and chain at fp32-level accuracy on the bf16 MFMA over the FP32 training state (_state_code: the
-            # weight gradients of such a network are the fp32 contractions)
+            # bf16x3: forward, chain and weight gradients at fp32-level accuracy on the bf16 MFMA over the FP32 training state
             code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
             if acts.dtype == torch.bfloat16:
                 code = _lib.SN_DTYPE_BF16_STATE

@@ -311,7 +311,7 @@ long sn_weight_grads_workspace_bytes(long slot_rows, int dtype) {
   if (slot_rows < 16 || slot_rows % 16 != 0) return SN_E_BADSHAPE;
   const int emb16 = (dtype & SN_DTYPE_EMB_BF16) ? 1 : 0;
   dtype &= ~SN_DTYPE_EMB_BF16;
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
   if (emb16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
   return sn_weight_grads_workspace_bytes_impl(slot_rows, dtype, emb16);
 }
@@ -322,7 +322,7 @@ int sn_weight_grads(const void* acts, const float* emb, const void* g_acts, long
   if (slot_rows < 16 || slot_rows % 16 != 0) return SN_E_BADSHAPE;
   const int emb16 = (dtype & SN_DTYPE_EMB_BF16) ? 1 : 0;
   dtype &= ~SN_DTYPE_EMB_BF16;
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
   if (emb16 && dtype != SN_DTYPE_BF16_STATE) return SN_E_UNSUPPORTED;
   return sn_weight_grads_launch(acts, emb, g_acts, slot_rows, dtype, emb16, workspace, grads, accumulate ? 1 : 0, (hipStream_t)stream);
 }

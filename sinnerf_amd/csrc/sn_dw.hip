@@ -96,10 +96,14 @@ SN_DEV unsigned dw_pack2(float a, float b) {
 // conflict-free across lanes), converts them to a bf16x8 fragment (RNE) and keeps the fp32 column sums for the bias
 // gradient.  16 MFMAs of 32 cycles per chunk instead of 128 of 64: the kernel becomes HBM-bound.
 // MODE 0: fp32 MFMAs.  1: bf16 MFMAs, fp32 tiles.  2: bf16 MFMAs, bf16 A and B tiles.  3: bf16 MFMAs, bf16 A tile, fp32 B tile.
+// MODE 4 (SN_DTYPE_BF16X3): fp32 tiles as in mode 1, but every gathered fragment is split into its (hi, lo) bf16 pair -- hi = RNE(x),
+//         lo = RNE(x - hi) -- and the chunk's k-step is THREE MFMAs per accumulator tile, Gh.Xh + Gl.Xh + Gh.Xl: fp32-level accuracy
+//         (the dropped Gl.Xl is 2^-16 relative per product) at 3 x 32 MFMA cycles per tile and chunk instead of 8 x 64.
 template <int MT, int NT, int WM, int WN, int MODE, int LDSB = DW_LDS_BYTES>
 SN_DEV void run_task(const Task& t, char* smem, int tid) {
   constexpr bool BF16 = MODE != 0;
-  constexpr int EA = (MODE >= 2) ? 2 : 4, EB = (MODE == 2) ? 2 : 4;
+  constexpr bool X3 = MODE == 4;
+  constexpr int EA = (MODE == 2 || MODE == 3) ? 2 : 4, EB = (MODE == 2) ? 2 : 4;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int WA = WM * MT * 32, WB = WN * NT * 32;
   constexpr int A_BYTES = KB * WA * EA, B_BYTES = KB * WB * EB, BUF = A_BYTES + B_BYTES;
@@ -195,6 +199,7 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
       }
       if (c > 0) {                                 // chunk c-1: pack, column sums, 16 MFMAs
         dw_bf16x8 af[MT], bf[NT];
+        dw_bf16x8 afl[X3 ? MT : 1], bfl[X3 ? NT : 1];  // bf16x3: the lo fragments
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
           dw_u32x4 q;
@@ -207,30 +212,44 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
             }
           } else {
             float sum = 0.0f;
+            dw_u32x4 ql;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
               const float v0 = __builtin_bit_cast(float, ra[a][2 * w]), v1 = __builtin_bit_cast(float, ra[a][2 * w + 1]);
               q[w] = dw_pack2(v0, v1);
+              if (X3) ql[w] = dw_pack2(v0 - __builtin_bit_cast(float, q[w] << 16), v1 - __builtin_bit_cast(float, q[w] & 0xffff0000u));
               sum += v0 + v1;
             }
             bsum[a] += sum;
+            if (X3) afl[a] = __builtin_bit_cast(dw_bf16x8, ql);
           }
           af[a] = __builtin_bit_cast(dw_bf16x8, q);
         }
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
-          dw_u32x4 q;
+          dw_u32x4 q, ql;
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
             if (EB == 2) q[w] = rb[b][w];
-            else q[w] = dw_pack2(__builtin_bit_cast(float, rb[b][2 * w]), __builtin_bit_cast(float, rb[b][2 * w + 1]));
+            else {
+              const float v0 = __builtin_bit_cast(float, rb[b][2 * w]), v1 = __builtin_bit_cast(float, rb[b][2 * w + 1]);
+              q[w] = dw_pack2(v0, v1);
+              if (X3) ql[w] = dw_pack2(v0 - __builtin_bit_cast(float, q[w] << 16), v1 - __builtin_bit_cast(float, q[w] & 0xffff0000u));
+            }
           }
           bf[b] = __builtin_bit_cast(dw_bf16x8, q);
+          if (X3) bfl[b] = __builtin_bit_cast(dw_bf16x8, ql);
         }
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
-          for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NT; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            if (X3) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[a], bf[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfl[b], acc[a][b], 0, 0, 0);
+            }
+          }
       }
       if (c < n_chunks) {                          // gathers of chunk c: lane (i, h) takes rows 8h .. 8h+7 of its feature
 #pragma unroll
@@ -324,7 +343,7 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks,
   const Task t = tasks != nullptr ? tasks[blockIdx.x] : task_of(plan, (int)blockIdx.x);
   const int tid = threadIdx.x;
   if (t.variant & 0x100) {
-    const int mode = (t.variant & 0x200) ? 2 : 1;     // 0x200: G and the activations are stored as bf16
+    const int mode = (t.variant & 0x400) ? 4 : (t.variant & 0x200) ? 2 : 1;     // 0x200: G and the activations are stored as bf16; 0x400: bf16x3 on fp32 state
 #define SN_DW_CASES(MODE_, MODE_EMB_)                                   \
     switch (t.variant & 0xff) {                                         \
       case 0: run_task<4, 4, 2, 2, MODE_>(t, smem, tid); break;         \
@@ -335,7 +354,7 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks,
       default: run_task<1, 1, 1, 4, MODE_>(t, smem, tid); break;        \
     }
     // variants 1 / 3 contract with the embedded inputs, which stay fp32 in every mode
-    if (mode == 1) { SN_DW_CASES(1, 1) } else { SN_DW_CASES(2, 3) }
+    if (mode == 1) { SN_DW_CASES(1, 1) } else if (mode == 4) { SN_DW_CASES(4, 4) } else { SN_DW_CASES(2, 3) }
 #undef SN_DW_CASES
     return;
   }
@@ -486,14 +505,15 @@ static Plan group_plan(const HostPlan& hp, int g) {
 // problems in the order build_plan emits them
 enum { W0 = 0, W1 = 1, W2 = 2, W3 = 3, W4 = 4, W4E = 5, W5 = 6, W6 = 7, W7 = 8, WF = 9, WD = 10, WDE = 11, SIG = 12, RGB = 13 };
 
-// dtype: 0 fp32, 1 bf16 operands / fp32 state, 2 bf16 operands / bf16 state.  Pointers may be null (size query).
+// dtype: 0 fp32, 1 bf16 operands / fp32 state, 2 bf16 operands / bf16 state, 3 bf16x3 (hi/lo split: fp32-level) / fp32 state.
+// Pointers may be null (size query).
 static void build_plan(HostPlan& hp, const char* acts, const char* emb, const char* G, long rows, int dtype, bool emb16 = false) {
   const long es = dtype == 2 ? 2 : 4;           // element size of acts / G (emb: fp32, or bf16 in K-slot order with emb16)
   const int v_e1 = emb16 ? 6 : 1, v_e3 = emb16 ? 7 : 3;
   const long ees = emb16 ? 2 : 4;
   const long slot = rows * 256 * es;
-  const int flags = (dtype >= 1 ? 0x100 : 0) | (dtype == 2 ? 0x200 : 0);
-  const int* cost = dtype == 0 ? COST_F32 : dtype == 1 ? COST_BF16 : COST_BF16_STATE;
+  const int flags = (dtype >= 1 ? 0x100 : 0) | (dtype == 2 ? 0x200 : 0) | (dtype == 3 ? 0x400 : 0);
+  const int* cost = dtype == 0 ? COST_F32 : (dtype == 1 || dtype == 3) ? COST_BF16 : COST_BF16_STATE;
   struct P { const char* a; const char* b; int lda, ldb, var; bool bias; };
   P pr[MAX_PROBS];
   int n = 0;

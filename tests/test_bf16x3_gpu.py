@@ -230,14 +230,55 @@ def test_bf16x3_backward_chain_writes_the_fp32_gradient_state(n_rays, S):
     print("bf16x3 chain vs fp32 chain: worst max|dG| / max|G| over the slots = %.2e" % worst)
 
 
+def test_bf16x3_weight_gradients_equal_the_fp32_contractions():
+    """sn_weight_grads(SN_DTYPE_BF16X3) against sn_weight_grads(SN_DTYPE_F32) on the SAME fp32 training state (acts, emb, G): all 24
+    parameter gradients within 2e-5 norm-wise (dW = G^T X over all points as Gh.Xh + Gl.Xh + Gh.Xl on the bf16 MFMA, fp32 column sums)"""
+    import ctypes
+    from sinnerf_amd import _lib
+    n_rays, S = 700, 64
+    rays = O.lego_rays(400, 400, seed=0)[::211][:n_rays]
+    z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n_rays, S)).astype(np.float32))
+    rays_t, z_t = torch.from_numpy(rays).to(dev()), torch.from_numpy(z).to(dev())
+    P = n_rays * S
+    rows = -(-P // 128) * 128
+    m3, _ = make_model(3, True, dtype=DT)
+    out = torch.zeros((n_rays, S, 4), device=dev())
+    acts = torch.zeros((10, rows, 256), device=dev())
+    emb = torch.zeros((rows, 128), device=dev())
+    _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m3.packed()), m3.kernel_dtype(_lib.SN_DTYPE_BF16X3), _lib.ptr(rays_t), _lib.ptr(z_t),
+                                             n_rays, S, _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()), "fwd")
+    g_raw = torch.from_numpy(np.random.RandomState(2).standard_normal((P, 4)).astype(np.float32)).to(dev())
+    G = torch.zeros((10, rows, 256), device=dev())
+    g_o = torch.zeros((P, 4), device=dev())
+    _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m3.packed_bwd(DT)), m3.kernel_dtype(_lib.SN_DTYPE_BF16X3), _lib.ptr(acts), _lib.ptr(out),
+                                              _lib.ptr(g_raw), P, rows, _lib.ptr(G), _lib.ptr(g_o), _lib.stream_ptr()), "chain")
+    grads = {}
+    for code in (_lib.SN_DTYPE_F32, _lib.SN_DTYPE_BF16X3):
+        ws = torch.empty(int(_lib.lib.sn_weight_grads_workspace_bytes(rows, code)), dtype=torch.uint8, device=dev())
+        outs = [torch.full_like(t, float("nan")) for t in m3.raw_tensors()]
+        arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[o.data_ptr() for o in outs])
+        _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(emb), _lib.ptr(G), rows, code, _lib.ptr(ws), arr, 0, _lib.stream_ptr()), "dw")
+        torch.cuda.synchronize()
+        grads[code] = [o.double().cpu().numpy() for o in outs]
+    worst = 0.0
+    for a, b in zip(grads[_lib.SN_DTYPE_BF16X3], grads[_lib.SN_DTYPE_F32]):
+        assert np.isfinite(a).all()
+        e = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        worst = max(worst, e)
+        assert e <= 2e-5, e
+    print("bf16x3 weight gradients vs fp32 contractions: worst norm-wise difference %.2e" % worst)
+
+
 def test_bf16x3_render_gradients_golden():
-    """compute_dtype='bf16x3' under autograd: bf16x3 training forward (fp32 state) + the fp32 backward chain / weight gradients.
-    Against the golden parameter gradients of the reference's autograd: the whole-tensor norms at the fp32 coarse bar (1e-4); the
-    256 SAMPLED weight entries per tensor at 1e-2 -- the bar tests/test_oracle_grads.py gives the numpy oracle itself on the fine
-    net -- because a ReLU pre-activation within ~1e-6 of zero takes the other branch under ANY arithmetic that is not bit-identical
-    (tests/test_grads_gpu.py::test_mlp_backward_vs_oracle: one point in ~2000 between oracle and fp32 kernel) and one flipped point
-    moves a sampled entry by 1e-3 while the tensor moves by 1e-5.  And against the all-fp32 HIP path on the same draws: every
-    tensor within 2e-3 norm-wise, cosine >= 0.99999."""
+    """compute_dtype='bf16x3' under autograd: forward, backward chain and weight gradients on the bf16 MFMA (3-term splits) over
+    the fp32 training state.  Every stage equals its fp32 counterpart at fp32 rounding level when fed the SAME state (the three tests
+    above: 1e-5); what a whole-render comparison adds are ReLU KINKS: a pre-activation within ~1e-6 of zero takes the other branch
+    under any arithmetic that is not bit-identical (tests/test_grads_gpu.py::test_mlp_backward_vs_oracle: one point in ~2000 between
+    oracle and fp32 kernel at 1e-7), and one flipped unit of one point moves the gradient of everything upstream of it.  Bars against
+    the golden parameter gradients of the reference's autograd: the 256 sampled weight entries per tensor at 1e-2 (the bar
+    tests/test_oracle_grads.py gives the numpy oracle itself on the fine net), whole-tensor norms at 2e-3; against the all-fp32 HIP path
+    on the same draws: every tensor within 5e-3 norm-wise, cosine >= 0.99999 (measured values are printed; convergence-length
+    evidence that nothing is lost: tools/convergence.py runs this arithmetic beside fp32)."""
     import sinnerf_amd
     from tests.test_oracle_grads import GRAD_CASES, grad_errors, load_grad_case
     from tests.test_grads_gpu import model_grads
@@ -259,19 +300,19 @@ def test_bf16x3_render_gradients_golden():
             got[dt] = [model_grads(mc), model_grads(mf)]
         errs = grad_errors(z, got[DT])
         e32 = grad_errors(z, got["fp32"])
-        print(name, "bf16x3 fwd + fp32 bwd vs golden: sampled-entry err coarse %.2e fine %.2e | norm err coarse %.2e fine %.2e   (all-fp32 path: %.2e %.2e | %.2e %.2e)" % (
+        print(name, "bf16x3 step vs golden: sampled-entry err coarse %.2e fine %.2e | norm err coarse %.2e fine %.2e   (all-fp32 path: %.2e %.2e | %.2e %.2e)" % (
             max(e for (t, _), (e, _) in errs.items() if t == "coarse"), max(e for (t, _), (e, _) in errs.items() if t == "fine"),
             max(d for (t, _), (_, d) in errs.items() if t == "coarse"), max(d for (t, _), (_, d) in errs.items() if t == "fine"),
             max(e for (t, _), (e, _) in e32.items() if t == "coarse"), max(e for (t, _), (e, _) in e32.items() if t == "fine"),
             max(d for (t, _), (_, d) in e32.items() if t == "coarse"), max(d for (t, _), (_, d) in e32.items() if t == "fine")))
         for (tag, k), (e, dn) in errs.items():
             assert e <= 1e-2, (tag, k, e)
-            assert dn <= (1e-4 if tag == "coarse" else 5e-3), (tag, k, dn)
+            assert dn <= 2e-3, (tag, k, dn)
         worst = 0.0
         for g3, g32 in zip(got[DT], got["fp32"]):
             for k, v in g32.items():
                 d = np.linalg.norm(g3[k] - v) / max(np.linalg.norm(v), 1e-30)
                 c = float((g3[k] * v).sum() / max(np.linalg.norm(g3[k]) * np.linalg.norm(v), 1e-30))
                 worst = max(worst, d)
-                assert d <= 2e-3 and c >= 0.99999, (k, d, c)
-        print(name, "bf16x3 fwd + fp32 bwd vs all-fp32 HIP path: worst per-tensor norm-wise difference %.2e" % worst)
+                assert d <= 5e-3 and c >= 0.99999, (k, d, c)
+        print(name, "bf16x3 step vs all-fp32 HIP path: worst per-tensor norm-wise difference %.2e" % worst)

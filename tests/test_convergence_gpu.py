@@ -37,6 +37,8 @@ def test_mixed_precision_reaches_the_fp32_psnr_at_convergence_length():
         assert np.isfinite(last) and last > first + 3.0, (r["path"], r["seed"], first, last)      # every run really optimises
     # mixed precision loses nothing measurable at convergence length (mean over three seeds)
     assert s["mean_final_psnr"]["bf16"] >= s["mean_final_psnr"]["fp32"] - 0.1, s
+    # ... nor does the 3-term-split arithmetic (forward, chain and weight gradients on the bf16 MFMA over the fp32 state)
+    assert s["mean_final_psnr"]["bf16x3"] >= s["mean_final_psnr"]["fp32"] - 0.1, s
     # and the fp32 HIP path lands where the reference's own modules land from the same start (same batches, same RNG draws;
     # the allowance is the seed-to-seed spread of the fp32 runs themselves, at least 0.25 dB)
     if "ref" in s["mean_final_psnr"]:

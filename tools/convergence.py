@@ -9,6 +9,7 @@ metrics.py:14-15, as validation_step does: sinnerf.py:556-577).  Three paths fro
 the same device-RNG seed (all three consume the generator in the reference's order):
 
   bf16   sinnerf_amd, mixed precision (bf16-operand forward / chain / weight gradients over a bf16 training state)
+  bf16x3 sinnerf_amd, fp32-level accuracy on the bf16 MFMA (3-term hi/lo splits) over the fp32 training state
   fp32   sinnerf_amd, fp32 MFMA kernels
   ref    the UNMODIFIED reference render_rays + NeRF modules (oracle/_ref) as PyTorch-ROCm eager ops on the same GPU
 
@@ -140,7 +141,7 @@ def run_all(steps=2000, seeds=(0, 1, 2), ref_seeds=(0,), dev=None):
     sc = scene(dev)
     runs = []
     for s in seeds:
-        for dt in ("bf16", "fp32"):
+        for dt in ("bf16", "bf16x3", "fp32"):
             runs.append(run_amd(dt, s, steps, sc, dev))
     from oracle import stage_ref
     if stage_ref.available():
@@ -148,10 +149,11 @@ def run_all(steps=2000, seeds=(0, 1, 2), ref_seeds=(0,), dev=None):
             runs.append(run_ref(s, steps, sc, dev))
     fin = lambda path: [r["final_psnr"] for r in runs if r["path"] == path]
     summ = {"steps": steps, "batch_rays": BATCH, "seeds": list(seeds), "ref_seeds": list(ref_seeds) if fin("ref") else [],
-            "final_psnr": {p: fin(p) for p in ("bf16", "fp32", "ref") if fin(p)},
-            "mean_final_psnr": {p: float(np.mean(fin(p))) for p in ("bf16", "fp32", "ref") if fin(p)},
-            "seconds": {p: [round(r["seconds"], 1) for r in runs if r["path"] == p] for p in ("bf16", "fp32", "ref")}}
+            "final_psnr": {p: fin(p) for p in ("bf16", "bf16x3", "fp32", "ref") if fin(p)},
+            "mean_final_psnr": {p: float(np.mean(fin(p))) for p in ("bf16", "bf16x3", "fp32", "ref") if fin(p)},
+            "seconds": {p: [round(r["seconds"], 1) for r in runs if r["path"] == p] for p in ("bf16", "bf16x3", "fp32", "ref")}}
     summ["bf16_minus_fp32_dB"] = summ["mean_final_psnr"]["bf16"] - summ["mean_final_psnr"]["fp32"]
+    summ["bf16x3_minus_fp32_dB"] = summ["mean_final_psnr"]["bf16x3"] - summ["mean_final_psnr"]["fp32"]
     return {"protocol": __doc__.split("usage:")[0].strip(), "summary": summ, "runs": runs}
 
 

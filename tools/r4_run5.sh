@@ -3,7 +3,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/x3prof -o x3 -- python $R/tools/x3_step_time.py bf16x3 fp32 > $R/gpurun_out/x3_step.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/x3prof -o x3 -- python $R/tools/x3_step_time.py bf16x3 fp32 > $R/gpurun_out/x3_step.log 2>&1
 cd $R
 cat gpurun_out/x3_step.log | tail -3
 python - <<'PY'
