@@ -243,13 +243,18 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
-          for (int b = 0; b < NT; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
-            if (X3) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[a], bf[b], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfl[b], acc[a][b], 0, 0, 0);
-            }
-          }
+          for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        if (X3) {                                    // the two cross terms as passes of their own: an accumulator tile is revisited
+                                                     // MT x NT MFMAs later, never by the next instruction
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[a], bf[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfl[b], acc[a][b], 0, 0, 0);
+        }
       }
       if (c < n_chunks) {                          // gathers of chunk c: lane (i, h) takes rows 8h .. 8h+7 of its feature
 #pragma unroll
