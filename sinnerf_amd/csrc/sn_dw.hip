@@ -99,6 +99,11 @@ SN_DEV unsigned dw_pack2(float a, float b) {
 // MODE 4 (SN_DTYPE_BF16X3): fp32 tiles as in mode 1, but every gathered fragment is split into its (hi, lo) bf16 pair -- hi = RNE(x),
 //         lo = RNE(x - hi) -- and the chunk's k-step is THREE MFMAs per accumulator tile, Gh.Xh + Gl.Xh + Gh.Xl: fp32-level accuracy
 //         (the dropped Gl.Xl is 2^-16 relative per product) at 3 x 32 MFMA cycles per tile and chunk instead of 8 x 64.
+//         Instruction-issue-bound (7.6 VALU per MFMA: both waves of a row / column of the 2 x 2 wave grid split the same tile).
+//         Measured and NOT kept: the workgroup splitting each chunk ONCE into hi / lo bf16 planes in LDS (fragments then by
+//         ds_read_b64_tr_b16, 4.6 VALU per MFMA) -- 5.5 ms against 4.6 for the fine pass: the extra LDS round trip (32 KB read +
+//         32 KB written per chunk beside the 64 KB of transpose reads, 18 % bank conflicts) and its sync cost more than the
+//         redundant conversions (tools/experiments/dw_x3_planes.cpp.txt, profiles/r04_x3_dw_forms.txt).
 template <int MT, int NT, int WM, int WN, int MODE, int LDSB = DW_LDS_BYTES>
 SN_DEV void run_task(const Task& t, char* smem, int tid) {
   constexpr bool BF16 = MODE != 0;
@@ -343,206 +348,6 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   }
 }
 
-// ---- bf16x3 on the fp32 state, second form (SN_DTYPE_BF16X3 default): the (hi, lo) split is done ONCE per chunk by the whole
-// workgroup instead of by every wave for the fragments it gathers (run_task MODE 4: each tile is converted by both waves of its
-// row / column of the 2 x 2 wave grid, 7.6 VALU instructions per MFMA, MFMA pipe 25 % busy -- profiles/r04_x3_train_kernels.txt).
-//   ring of fp32 chunks (DMA, as in every mode)  ->  [convert: 8 floats -> one 16-byte hi piece + one lo piece per thread step]
-//   -> two sets of four bf16 planes (A hi, A lo, B hi, B lo; the swizzled image the bf16-state kernels DMA)  ->  transpose reads
-//   (ds_read_b64_tr_b16) + three MFMAs per accumulator tile, as passes over the tiles (Gh.Xh, Gl.Xh, Gh.Xl).
-// Software pipeline, ONE barrier per chunk: iteration c converts chunk c into plane set c & 1 while the MFMAs of chunk c - 1 read set
-// (c - 1) & 1; the barrier at its top says (a) every wave's DMA pieces of chunk c have landed (counted vmcnt), (b) every wave has
-// finished converting chunk c - 1 (its fp32 slot is restaged right behind the barrier) and (c) reading set c & 1 (chunk c - 2).
-constexpr int DW_X3_LDS_BYTES = 163840;
-template <int MT, int NT, int WM, int WN>
-SN_DEV void run_task_x3(const Task& t, char* smem, int tid) {
-  static_assert(WM * WN == 4 && KB == 16, "4 waves per workgroup, one 32x32x16 k-step per chunk");
-  constexpr int WA = WM * MT * 32, WB = WN * NT * 32;
-  constexpr int A_BYTES = KB * WA * 4, B_BYTES = KB * WB * 4, BUF = A_BYTES + B_BYTES;           // fp32 chunk
-  constexpr int PA = KB * WA * 2, PB = KB * WB * 2, PSET = 2 * PA + 2 * PB;                       // one set of four bf16 planes (= BUF)
-  constexpr int NFIT = (DW_X3_LDS_BYTES - 2 * PSET) / BUF;
-  constexpr int NBUF = NFIT > 8 ? 8 : NFIT;
-  static_assert(NBUF >= 3, "ring of at least three fp32 chunks beside the two plane sets");
-  constexpr int CH_A = KB * WA * 4 / 16, CH_B = KB * WB * 4 / 16;
-  static_assert(CH_B % 256 == 0 && CH_A % 64 == 0, "staging predicates must be wave-uniform");
-  constexpr int IT_A = (CH_A + 255) / 256, IT_B = CH_B / 256, PART_A = (CH_A % 256) / 64;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 31, h = lane >> 5;
-  const int wr = wave / WN, wc = wave % WN;
-  const int m0 = wr * MT * 32, n0 = wc * NT * 32;
-  char* const planes = smem + NBUF * BUF;
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  float bsum[MT];
-#pragma unroll
-  for (int a = 0; a < MT; ++a) bsum[a] = 0.0f;
-
-  const long k0 = t.k0, k1 = t.k1;
-  if (k0 >= k1) return;
-  RowStager<WA, 4> sa;
-  RowStager<WB, 4> sb;
-  sa.init(t.lda, tid);
-  sb.init(t.ldb, tid);
-  const int n_chunks = (int)((k1 - k0 + KB - 1) / KB);
-#pragma unroll
-  for (int c = 0; c < NBUF - 1; ++c) {
-    sa.stage(t.a, t.lda, k0 + (long)c * KB, k1, smem + c * BUF, tid);
-    sb.stage(t.b, t.ldb, k0 + (long)c * KB, k1, smem + c * BUF + A_BYTES, tid);
-  }
-  // transpose-read addresses of this lane inside a plane: lane (q, G): feature block G & 1, point rows 8 (G >> 1) + (q >> 2)
-  unsigned ta[MT], tb[NT];
-  {
-    const int q = lane & 15, G = lane >> 4;
-#pragma unroll
-    for (int a = 0; a < MT; ++a) ta[a] = RowStager<WA, 2>::tr_offset(8 * (G >> 1) + (q >> 2), m0 + 32 * a + 16 * (G & 1) + 4 * (q & 3));
-#pragma unroll
-    for (int b = 0; b < NT; ++b) tb[b] = RowStager<WB, 2>::tr_offset(8 * (G >> 1) + (q >> 2), n0 + 32 * b + 16 * (G & 1) + 4 * (q & 3)) + 2 * PA;
-  }
-  // conversion of one fp32 tile (W floats per row) into its hi / lo planes: piece = 8 consecutive floats of a row
-  // (the plane writes are inline asm: hipcc guards every LDS write it sees with s_waitcnt vmcnt(0) while LDS-DMA pieces may be in
-  //  flight -- it cannot tell the planes from the ring slots -- which would drain the ring at every chunk)
-  auto convert = [&](auto wtag, const char* src, unsigned dst_hi, unsigned dst_lo) __attribute__((always_inline)) {
-    constexpr int W = decltype(wtag)::value;
-    constexpr int PER_ROW = W / 8, PIECES = KB * PER_ROW;
-    constexpr bool SWZ = RowStager<W, 2>::SWZ;
-#pragma unroll
-    for (int it = 0; it < (PIECES + 255) / 256; ++it) {
-      const int pc = it * 256 + tid;
-      if (PIECES % 256 == 0 || pc < PIECES) {
-        const int row = pc / PER_ROW, lp = pc % PER_ROW;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + (row * W + 8 * lp) * 4);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + (row * W + 8 * lp + 4) * 4);
-        const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        dw_u32x4 qh, ql;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          qh[w] = dw_pack2(v[2 * w], v[2 * w + 1]);
-          ql[w] = dw_pack2(v[2 * w] - __builtin_bit_cast(float, qh[w] << 16), v[2 * w + 1] - __builtin_bit_cast(float, qh[w] & 0xffff0000u));
-        }
-        const int dp = SWZ ? (lp ^ (4 * (row & 3))) : lp;
-        const unsigned po = (unsigned)((row * PER_ROW + dp) * 16);
-        asm volatile("ds_write_b128 %0, %1" :: "v"(dst_hi + po), "v"(qh) : "memory");
-        asm volatile("ds_write_b128 %0, %1" :: "v"(dst_lo + po), "v"(ql) : "memory");
-      }
-    }
-  };
-  auto frag = [&](const char* p, unsigned off, int rowpitch4) __attribute__((always_inline)) {
-    const dw_i16x4 lo = tr_read(p + off), hi = tr_read(p + off + rowpitch4);
-    const dw_i16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(dw_bf16x8, v);
-  };
-  // The loop is PEELED (chunk 0's conversion in front, the last chunk's MFMAs behind): with the MFMA block under `if (c > 0)` the 256
-  // accumulator registers cross a control-flow join every iteration and hipcc copies them AGPR -> VGPR -> AGPR there (256 + 242 moves
-  // and 60 spilled registers in the 4 x 4 variant).
-  int slot_c = 0;
-  auto produce = [&](int c) __attribute__((always_inline)) {      // sync point of chunk c, restage the slot of chunk c - 1, convert chunk c
-    if (PART_A != 0 && wave >= PART_A) wait_vmcnt<(NBUF - 2) * (IT_A - 1 + IT_B)>();
-    else wait_vmcnt<(NBUF - 2) * (IT_A + IT_B)>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // own plane writes / transpose reads of the previous iteration retired
-    __builtin_amdgcn_s_barrier();
-    const long k = k0 + (long)c * KB;
-    {                                                        // the fp32 slot of chunk c - 1 (converted by every wave; at c = 0 the one
-      const int sp = slot_c == 0 ? NBUF - 1 : slot_c - 1;    // slot the prologue left empty) takes chunk c + NBUF - 1
-      sa.stage(t.a, t.lda, k + (long)(NBUF - 1) * KB, k1, smem + sp * BUF, tid);
-      sb.stage(t.b, t.ldb, k + (long)(NBUF - 1) * KB, k1, smem + sp * BUF + A_BYTES, tid);
-    }
-    const unsigned ps = (unsigned)(NBUF * BUF + (c & 1) * PSET);             // LDS byte address (dynamic LDS starts at 0: no static __shared__ here)
-    const char* bc = smem + slot_c * BUF;
-    convert(std::integral_constant<int, WA>{}, bc, ps, ps + PA);
-    convert(std::integral_constant<int, WB>{}, bc + A_BYTES, ps + 2 * PA, ps + 2 * PA + PB);
-    // (the conversion and the MFMA phase are NOT interleaved: together they are ~2300 cycles per chunk against the ~3400 the chunk's
-    //  32 KB take to arrive at this CU's share of the HBM rate)
-    __builtin_amdgcn_sched_barrier(0);
-    slot_c = (slot_c + 1 == NBUF) ? 0 : slot_c + 1;
-  };
-  auto consume = [&](int c) __attribute__((always_inline)) {      // chunk c: fragments by transpose reads, three passes of MFMAs
-    const char* ps = planes + (c & 1) * PSET;
-    dw_bf16x8 ah[MT], bh[NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a) ah[a] = frag(ps, ta[a], 4 * WA * 2);
-#pragma unroll
-    for (int b = 0; b < NT; ++b) bh[b] = frag(ps, tb[b], 4 * WB * 2);
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-      for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      dw_bf16x8 al[MT];
-#pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        al[a] = frag(ps + PA, ta[a], 4 * WA * 2);
-        // column sums for the bias gradient (every wave: no branch around it): hi + lo = the fp32 value to 2^-17
-        const dw_u32x4 u = __builtin_bit_cast(dw_u32x4, ah[a]), v = __builtin_bit_cast(dw_u32x4, al[a]);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(bsum[a]) : "v"(u[w]), "v"(0x3f803f80u));
-          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(bsum[a]) : "v"(v[w]), "v"(0x3f803f80u));
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      dw_bf16x8 bl[NT];
-#pragma unroll
-      for (int b = 0; b < NT; ++b) bl[b] = frag(ps + PB, tb[b], 4 * WB * 2);
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  produce(0);
-  for (int c = 1; c < n_chunks; ++c) {
-    produce(c);
-    consume(c - 1);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                              // every wave's conversion of the last chunk is visible
-  consume(n_chunks - 1);
-  wait_vmcnt<0>();                               // drain the over-issued tail chunks before the LDS is released
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-        t.c[(long)m * t.ldc + n0 + 32 * b + i] = acc[a][b][r];
-      }
-  if (t.bias != nullptr && wc == 0) {
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-      const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-      if (h == 0) t.bias[m0 + 32 * a + i] = v;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) dw_x3_kernel(const Plan plan) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Task t = task_of(plan, (int)blockIdx.x);
-  const int tid = threadIdx.x;
-  switch (t.variant & 0xff) {
-    case 0: run_task_x3<4, 4, 2, 2>(t, smem, tid); break;
-    case 1: run_task_x3<4, 1, 2, 2>(t, smem, tid); break;
-    case 2: run_task_x3<2, 4, 2, 2>(t, smem, tid); break;
-    case 3: run_task_x3<2, 1, 2, 2>(t, smem, tid); break;
-    case 4: run_task_x3<1, 2, 1, 4>(t, smem, tid); break;
-    default: run_task_x3<1, 1, 1, 4>(t, smem, tid); break;
-  }
-}
-
 __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks, const Plan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Task t = tasks != nullptr ? tasks[blockIdx.x] : task_of(plan, (int)blockIdx.x);
@@ -676,6 +481,10 @@ static const VariantInfo VARIANTS[8] = {{256, 256}, {256, 64}, {128, 256}, {128,
 // FLOPs alone left the 32x128 problem streaming 168 MB through a single CU
 static const int COST_F32[8] = {512, 161, 260, 95, 101, 59, 0, 0};
 static const int COST_BF16[8] = {512, 189, 226, 126, 138, 125, 0, 0};          // bf16 operands, fp32 state
+// bf16x3 on the fp32 state (run_task MODE 4): instruction-issue-bound -- the cost of a point follows the tiles a wave splits and its
+// MFMAs, not the bytes (tools/dw_x3_time.py: each variant's tasks alone; with the bf16 table above the 128 x 256 problem's 11
+// workgroups ran 3.07 ms while the 208 of the eight 256 x 256 problems were done after 2.34)
+static const int COST_X3[8] = {512, 217, 284, 136, 148, 99, 0, 0};
 // bf16 operands, bf16 state (transpose-read fragments, a sync point every 2nd / 4th chunk): the 256x256 problems run at their
 // share of the HBM rate (52 ns per point per CU = 1 KB / 19.7 GB/s), the narrower ones at 19..35 ns per point
 #ifndef SN_DW_COST_STATE
@@ -718,7 +527,7 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
   const long ees = emb16 ? 2 : 4;
   const long slot = rows * 256 * es;
   const int flags = (dtype >= 1 ? 0x100 : 0) | (dtype == 2 ? 0x200 : 0) | (dtype == 3 ? 0x400 : 0);
-  const int* cost = dtype == 0 ? COST_F32 : (dtype == 1 || dtype == 3) ? COST_BF16 : COST_BF16_STATE;
+  const int* cost = dtype == 0 ? COST_F32 : dtype == 1 ? COST_BF16 : dtype == 3 ? COST_X3 : COST_BF16_STATE;
   struct P { const char* a; const char* b; int lda, ldb, var; bool bias; };
   P pr[MAX_PROBS];
   int n = 0;
@@ -811,13 +620,6 @@ static bool narrow_compiler_scheduled() {
   return v;
 }
 
-// SINNERF_DW_X3_GATHER=1 in the environment keeps the first bf16x3 form (every wave splits the fragments it gathers: run_task MODE 4;
-// A/B runs, read once)
-static bool x3_gather_form() {
-  static const bool v = [] { const char* e = getenv("SINNERF_DW_X3_GATHER"); return e != nullptr && e[0] == '1'; }();
-  return v;
-}
-
 extern "C" long sn_weight_grads_workspace_bytes_impl(long slot_rows, int dtype, int emb16) {
   // the same refusal as the launch below: a caller that asks here first (sinnerf_amd/autograd.py does) never stores a bf16 emb
   // that the backward cannot read
@@ -856,9 +658,6 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
     } else {
       hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, pb);
     }
-  } else if (dtype == 3 && !x3_gather_form()) {
-    SN_ENSURE_DYN_LDS(dw_x3_kernel, DW_X3_LDS_BYTES);
-    hipLaunchKernelGGL(dw_x3_kernel, dim3((unsigned)hp.plan.n_tasks), dim3(256), DW_X3_LDS_BYTES, stream, hp.plan);
   } else {
     hipLaunchKernelGGL(dw_kernel, dim3((unsigned)hp.plan.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, hp.plan);
   }
