@@ -119,8 +119,8 @@ SN_DEV void x3_put_signed(int rh, int rl, const float (&x)[4], uint32_t word, in
 //   af         ring of A-fragment PAIRS (hi, lo), prefetch distance 3 k-steps: fragments of k-steps 0, 1, 2 of this slab sit in
 //              af[(PHASE + 0..2) & 3] at entry; PHASE' = (PHASE + NK) & 3 at exit
 //   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead), a multiple of 4 KB for every K
-//   VMW        counted wait at the sync point (training forward): the youngest VMW vector-memory operations of the wave are row
-//              stores issued BEHIND the previous slab's DMA pieces and may stay in flight; the barrier is then a raw s_barrier
+//   VMW        counted wait at the sync point (training kernels): the youngest VMW vector-memory operations of the wave at the START of
+//              the slab are row stores issued BEHIND the previous slab's DMA pieces and may stay in flight; barriers are raw s_barriers
 //   post(step, n)  memory operations of the caller, once per k-step behind the sync point (step = ks - GB of n = NK - GB): with
 //              before = true in FRONT of the k-step's DMA pieces (the chain's mask loads), with false BEHIND them (row stores:
 //              x3_store_step maps the LAST four steps to the four row-group stores of the previous tile)
@@ -133,15 +133,27 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
   constexpr int NPS = (NP + PPK - 1) / PPK;                  // k-steps that carry DMA pieces: GB .. GB + NPS - 1
   static_assert(NBYTES % 4096 == 0 && GB >= 1 && GB + 3 <= NK && NK >= 4, "whole pieces; sync point inside the slab");
   static_assert(NK >= 8 ? GB + NPS <= NK : true, "one piece per k-step behind the sync point");
-  (void)NPS;
+  // Two sync points per slab (3-slot ring): with ONE (wait + barrier at k-step GB) a slab's weights are requested exactly one slab
+  // ahead of the wait -- 0.75 us at 48 MFMAs per slab, below the ~1.1 us an LDS-DMA piece takes to land under this load: the waves were
+  // parked 20-24 % of the time (profiles/r04_x3_train_kernels.txt).  Splitting the jobs -- B1 early ("slot free": start the DMA),
+  // B2 late ("next slab visible", just before its first fragments are prefetched at k-step NK - 3) -- gives the DMA 1.6 slabs.
+  constexpr int GB2 = (NK >= 8) ? NK - 4 : GB;
+  constexpr int ISSUED = ((GB2 - GB) * PPK < NP) ? (GB2 - GB) * PPK : NP;      // pieces of slab s+2 issued before B2
+  static_assert(GB2 >= GB && GB2 + 3 <= NK, "B2 in front of the first prefetch of the next slab's fragments");
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
     if (ks == GB) {
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
-      if (VMW == 0) __syncthreads();
-      else __builtin_amdgcn_s_barrier();
+      // B1: every wave has left slab s-1 -> its slot takes slab s+2 (one barrier does both jobs in the 4-k-step slabs)
+      if (GB2 == GB) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
+      __builtin_amdgcn_s_barrier();
       ring.begin_static();
       nA = load_bias(lds_bias, s_next, h);
+    }
+    if (GB2 != GB && ks == GB2) {
+      // B2: slab s+1 (requested at B1 of slab s-1) has landed for every wave.  Younger than its pieces: the previous slab's row stores
+      // (VMW) and the pieces of slab s+2 issued since B1
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW + ISSUED) : "memory");
+      __builtin_amdgcn_s_barrier();
     }
     {
       const int kn = ks + 3;
