@@ -177,10 +177,11 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
 
     int s = 0;
     int out_slot = 0;                                                      // G slot the running layer writes
-    auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {   // g_final: no activation
+    // (blk = 0..3: the block of accumulator registers 4 blk .. 4 blk + 3, q = 2 blk -- one block behind each of a slab's first k-steps)
+    auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {   // g_final: no activation
       constexpr int W = decltype(wset)::value;
-#pragma unroll
-      for (int q = 0; q < 8; q += 2) {
+      {
+        const int q = 2 * blk;
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = ra[2 * q + i] + rb[2 * q + i];
@@ -189,12 +190,12 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
       }
     };
     // g_y = g_h [h > 0]; with_sigma: g_h8 also gets the sigma head's term  sigma.weight[f] g_sigma  (nerf.py:136)
-    auto mask_tile_impl = [&](auto wset, auto with_sigma, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {
+    auto mask_tile_impl = [&](auto wset, auto with_sigma, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {
       constexpr int W = decltype(wset)::value;
       constexpr bool SIG = decltype(with_sigma)::value;
       const uint32_t word = sw[t >> 1];
-#pragma unroll
-      for (int q = 0; q < 8; q += 2) {
+      {
+        const int q = 2 * blk;
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -206,11 +207,11 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
         stage(q >> 1, v);
       }
     };
-    auto mask_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {
-      mask_tile_impl(wset, std::false_type{}, t, ra, rb);
+    auto mask_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {
+      mask_tile_impl(wset, std::false_type{}, t, ra, rb, blk);
     };
-    auto mask_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {
-      mask_tile_impl(wset, std::true_type{}, t, ra, rb);
+    auto mask_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {
+      mask_tile_impl(wset, std::true_type{}, t, ra, rb, blk);
     };
 #define SNY_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SNY_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
@@ -225,13 +226,13 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
     if (((T_) & 1) == 0)                                                                                           \
       slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a0, b0, a1, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
-          [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNY_W(W_), (T_) - 1, a1, b1); },               \
+          [&](int blk) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNY_W(W_), (T_) - 1, a1, b1, blk); },   \
           [&](int st, int n, bool before) __attribute__((always_inline)) {                                         \
             if (!before && (T_) > 0) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
     else                                                                                                           \
       slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a1, b1, a0, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
-          [&]() __attribute__((always_inline)) { EPI_(SNY_W(W_), (T_) - 1, a0, b0); },                             \
+          [&](int blk) __attribute__((always_inline)) { EPI_(SNY_W(W_), (T_) - 1, a0, b0, blk); },                 \
           [&](int st, int n, bool before) __attribute__((always_inline)) {                                         \
             if (!before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
@@ -248,7 +249,8 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
     SNY_SLAB(6, NK_, SET_, NBB_, EPI_, W_);                                     \
     SNY_SLAB(7, NK_, SET_, NBB_, EPI_, W_);                                     \
     x3_result_fence(a1, b1);                                                    \
-    EPI_(SNY_W(W_), 7, a1, b1);                                                 \
+    EPI_(SNY_W(W_), 7, a1, b1, 0); EPI_(SNY_W(W_), 7, a1, b1, 1);               \
+    EPI_(SNY_W(W_), 7, a1, b1, 2); EPI_(SNY_W(W_), 7, a1, b1, 3);               \
     store_rows(out_slot, 7, 0); store_rows(out_slot, 7, 1);                     \
     store_rows(out_slot, 7, 2); store_rows(out_slot, 7, 3);                     \
   } while (0)

@@ -166,10 +166,11 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         }
       }
     };
-    auto relu_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {
+    // (blk = 0..3: the block of accumulator registers 4 blk .. 4 blk + 3, q = 2 blk)
+    auto relu_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {
       constexpr int W = decltype(wset)::value;
-#pragma unroll
-      for (int q = 0; q < 8; q += 2) {
+      {
+        const int q = 2 * blk;
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
@@ -178,13 +179,13 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         stage(q >> 1, v);
         sign_pair(t, q, h0, h1);
       }
-      sign_tile_done(t);
+      if (blk == 3) sign_tile_done(t);
     };
-    auto relu_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {   // layer 8
+    auto relu_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {   // layer 8
       constexpr int W = decltype(wset)::value;
       const f32x4* ws = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t);
-#pragma unroll
-      for (int q = 0; q < 8; q += 2) {
+      {
+        const int q = 2 * blk;
         const f32x4 w = ws[q >> 1];
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
@@ -198,12 +199,12 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         sg = __builtin_fmaf(w[3], v[3], sg);
         stage(q >> 1, v);
       }
-      sign_tile_done(t);
+      if (blk == 3) sign_tile_done(t);
     };
-    auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {   // xyz_encoding_final
+    auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {   // xyz_encoding_final
       constexpr int W = decltype(wset)::value;
-#pragma unroll
-      for (int q = 0; q < 8; q += 2) {
+      {
+        const int q = 2 * blk;
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
@@ -224,12 +225,12 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     constexpr int VW_ = (STORE && (T_) != 1) ? 4 : 0;                                                                      \
     if (((T_) & 1) == 0)                                                                                                   \
       slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a0, b0, a1, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
-                                                   [&]() __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNX_W(W_), (T_) - 1, a1, b1); }, \
+                                                   [&](int blk) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNX_W(W_), (T_) - 1, a1, b1, blk); }, \
                                                    [&](int st, int n, bool before) __attribute__((always_inline)) {                    \
                                                      if ((T_) > 0 && !before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(cur_slot, (T_) - 1, i); }); }); \
     else                                                                                                                   \
       slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a1, b1, a0, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
-                                                   [&]() __attribute__((always_inline)) { EPI_(SNX_W(W_), (T_) - 1, a0, b0); }, \
+                                                   [&](int blk) __attribute__((always_inline)) { EPI_(SNX_W(W_), (T_) - 1, a0, b0, blk); }, \
                                                    [&](int st, int n, bool before) __attribute__((always_inline)) {                    \
                                                      if (!before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(cur_slot, (T_) - 1, i); }); }); \
     SNX_ADVANCE();                                                                                                         \
@@ -245,7 +246,8 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     SNX_SLAB(6, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_);          \
     SNX_SLAB(7, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_);          \
     x3_result_fence(a1, b1);                                                        \
-    EPI_(SNX_W(W_), 7, a1, b1);                                                 \
+    EPI_(SNX_W(W_), 7, a1, b1, 0); EPI_(SNX_W(W_), 7, a1, b1, 1);               \
+    EPI_(SNX_W(W_), 7, a1, b1, 2); EPI_(SNX_W(W_), 7, a1, b1, 3);               \
     store_rows(cur_slot, 7, 0); store_rows(cur_slot, 7, 1);                     \
     store_rows(cur_slot, 7, 2); store_rows(cur_slot, 7, 3);                     \
   } while (0)
@@ -308,9 +310,8 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     }
     f32x2 c3[3];
     c3[0] = c3[1] = c3[2] = f32x2{0.0f, 0.0f};
-    auto ssp_tile = [&](auto, int t, const f32x16& ra, const f32x16& rb) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
+    auto ssp_tile = [&](auto, int t, const f32x16& ra, const f32x16& rb, int q) __attribute__((always_inline)) {
+      {
         f32x4 w[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -332,7 +333,8 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     SNX_SLAB(2, 16, 2, 0, -1, 2, 0, B_L0, dh, dl, ssp_tile, 0);
     SNX_SLAB(3, 16, 2, 0, -1, 2, 2, B_L0, dh, dl, ssp_tile, 0);
     x3_result_fence(a1, b1);
-    ssp_tile(SNX_W(0), 3, a1, b1);
+    ssp_tile(SNX_W(0), 3, a1, b1, 0); ssp_tile(SNX_W(0), 3, a1, b1, 1);
+    ssp_tile(SNX_W(0), 3, a1, b1, 2); ssp_tile(SNX_W(0), 3, a1, b1, 3);
     store_rows(9, 3, 0); store_rows(9, 3, 1); store_rows(9, 3, 2); store_rows(9, 3, 3);
     {
       float o3[3];

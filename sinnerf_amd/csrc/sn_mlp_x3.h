@@ -114,8 +114,8 @@ SN_DEV void x3_put_signed(int rh, int rl, const float (&x)[4], uint32_t word, in
 // One slab: NK0 + NK1 k-steps (two K segments), barrier after k-step GB (the 3-slot protocol of sn_mlp_pipe.h).
 //   SET0/SET1  B operands of the segment: AGPR activation set 0/1, or -1 = the VGPR arrays bh / bl ([k-step])
 //   accA/accB  the two chains of this slab (accA bias-initialised on entry, accB started by its first MFMA with C = 0)
-//   nA         chain A of the NEXT slab: receives that slab's bias at the sync point (pending() has consumed the previous
-//              slab's results -- which live in nA / nB -- behind k-step 0)
+//   nA         chain A of the NEXT slab: receives that slab's bias behind k-step 4 (pending(0..3) have consumed the previous
+//              slab's results -- which live in nA / nB -- behind k-steps 0..3)
 //   af         ring of A-fragment PAIRS (hi, lo), prefetch distance 3 k-steps: fragments of k-steps 0, 1, 2 of this slab sit in
 //              af[(PHASE + 0..2) & 3] at entry; PHASE' = (PHASE + NK) & 3 at exit
 //   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead), a multiple of 4 KB for every K
@@ -147,7 +147,6 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
       if (GB2 == GB) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
       __builtin_amdgcn_s_barrier();
       ring.begin_static();
-      nA = load_bias(lds_bias, s_next, h);
     }
     if (GB2 != GB && ks == GB2) {
       // B2: slab s+1 (requested at B1 of slab s-1) has landed for every wave.  Younger than its pieces: the previous slab's row stores
@@ -197,10 +196,19 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
       x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (ks == 0) {
-      pending();
-      __builtin_amdgcn_sched_barrier(0);
+    // the previous tile's deferred epilogue, one block of four accumulator registers (~25 VALU) behind each of the first four
+    // k-steps -- as ONE block behind k-step 0 (~100 VALU against 3 MFMAs in flight) it left the MFMA pipe idle for a third of every slab
+    // (45 % busy, profiles/r04_x3_train_kernels.txt); the 4-k-step slabs take two blocks per k-step.  The next slab's bias goes into
+    // the vacated chain A right behind the last block.
+    if (NK >= 8) {
+      if (ks < 4) pending(ks);
+      if (ks == 4) nA = load_bias(lds_bias, s_next, h);
+    } else {
+      if (ks == 0) { pending(0); pending(1); }
+      if (ks == 1) { pending(2); pending(3); }
+      if (ks == 2) nA = load_bias(lds_bias, s_next, h);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   ring.template end_static<NP>();
 }
