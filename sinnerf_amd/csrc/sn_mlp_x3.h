@@ -198,15 +198,14 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
     __builtin_amdgcn_sched_barrier(0);
     // the previous tile's deferred epilogue, one block of four accumulator registers (~25 VALU) behind each of the first four
     // k-steps -- as ONE block behind k-step 0 (~100 VALU against 3 MFMAs in flight) it left the MFMA pipe idle for a third of every slab
-    // (45 % busy, profiles/r04_x3_train_kernels.txt); the 4-k-step slabs take two blocks per k-step.  The next slab's bias goes into
+    // (45 % busy, profiles/r04_x3_train_kernels.txt); the 4-k-step slabs keep it whole.  The next slab's bias goes into
     // the vacated chain A right behind the last block.
     if (NK >= 8) {
       if (ks < 4) pending(ks);
       if (ks == 4) nA = load_bias(lds_bias, s_next, h);
-    } else {
-      if (ks == 0) { pending(0); pending(1); }
-      if (ks == 1) { pending(2); pending(3); }
-      if (ks == 2) nA = load_bias(lds_bias, s_next, h);
+    } else {                                                 // (4-k-step slabs: the row stores of the tile start at k-step 1)
+      if (ks == 0) { pending(0); pending(1); pending(2); pending(3); }
+      if (ks == 1) nA = load_bias(lds_bias, s_next, h);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
