@@ -177,46 +177,41 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
 
     int s = 0;
     int out_slot = 0;                                                      // G slot the running layer writes
-    // Epilogue of output tile t as micro-steps (sn_mlp_x3.h): idx = 7 blk + step, blk = 0..3 the block of accumulator registers
-    // 4 blk .. 4 blk + 3 (q = 2 blk).  MASK: g_y = g_h [h > 0] from the sign words; SIG: g_h8 also gets the sigma head's term
-    // sigma.weight[f] g_sigma (nerf.py:136); neither: g_final, no activation
-    X3Blk eb;
-    auto epi_common = [&](auto wset, auto mask, auto with_sigma, int t, const f32x16& ra, const f32x16& rb, int idx) __attribute__((always_inline)) {
+    // (blk = 0..3: the block of accumulator registers 4 blk .. 4 blk + 3, q = 2 blk -- one block behind each of a slab's first k-steps)
+    auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {   // g_final: no activation
       constexpr int W = decltype(wset)::value;
-      constexpr bool MASK = decltype(mask)::value, SIG = decltype(with_sigma)::value;
-      const int blk = idx / X3_BWD_STEPS, step = idx % X3_BWD_STEPS, q = 2 * blk;
-      const int rh = x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), rl = x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3);
-      if (step == 0) {
-        const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
-        const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
-        x3_step_sum(a, b, eb);
-        if (SIG) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::BB_AUX_SIGT + h * 128 + 16 * t + 4 * blk);
-          x3_step_fma_sig(eb, w, gsig);
-        }
-      } else if (step == 1) {
-        if (MASK) x3_step_bits(sw[t >> 1], q + 8 * (t & 1), eb);
-      } else if (step == 2) {
-        if (MASK) x3_step_mask(eb);
-        stage(q >> 1, eb.s);
-      } else if (step == 3) {
-        x3_step_hi0(eb);
-      } else if (step == 4) {
-        x3_step_hi1(rh, eb);
-      } else if (step == 5) {
-        x3_step_rem(eb);
-      } else {
-        x3_step_lo(rl, eb);
+      {
+        const int q = 2 * blk;
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = ra[2 * q + i] + rb[2 * q + i];
+        x3_put(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), x);
+        stage(q >> 1, x);
       }
     };
-    auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int idx) __attribute__((always_inline)) {   // g_final: no activation
-      epi_common(wset, std::false_type{}, std::false_type{}, t, ra, rb, idx);
+    // g_y = g_h [h > 0]; with_sigma: g_h8 also gets the sigma head's term  sigma.weight[f] g_sigma  (nerf.py:136)
+    auto mask_tile_impl = [&](auto wset, auto with_sigma, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {
+      constexpr int W = decltype(wset)::value;
+      constexpr bool SIG = decltype(with_sigma)::value;
+      const uint32_t word = sw[t >> 1];
+      {
+        const int q = 2 * blk;
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = ra[2 * q + i] + rb[2 * q + i];
+          if (SIG) x[i] = __builtin_fmaf(lds_aux[snl::BB_AUX_SIGT + h * 128 + 16 * t + 2 * q + i], gsig, x[i]);
+        }
+        float v[4];
+        x3_put_signed(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), x, word, q + 8 * (t & 1), v);
+        stage(q >> 1, v);
+      }
     };
-    auto mask_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int idx) __attribute__((always_inline)) {
-      epi_common(wset, std::true_type{}, std::false_type{}, t, ra, rb, idx);
+    auto mask_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {
+      mask_tile_impl(wset, std::false_type{}, t, ra, rb, blk);
     };
-    auto mask_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int idx) __attribute__((always_inline)) {
-      epi_common(wset, std::true_type{}, std::true_type{}, t, ra, rb, idx);
+    auto mask_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {
+      mask_tile_impl(wset, std::true_type{}, t, ra, rb, blk);
     };
 #define SNY_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SNY_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
@@ -229,15 +224,15 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
   do {                                                                                                             \
     constexpr int VW_ = ((T_) != 1) ? 4 : 0;                                                                       \
     if (((T_) & 1) == 0)                                                                                           \
-      slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_, ((T_) > 0 ? 4 * X3_BWD_STEPS : 0)>(a0, b0, a1, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
+      slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a0, b0, a1, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
-          [&](int idx) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNY_W(W_), (T_) - 1, a1, b1, idx); },   \
+          [&](int blk) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNY_W(W_), (T_) - 1, a1, b1, blk); },   \
           [&](int st, int n, bool before) __attribute__((always_inline)) {                                         \
             if (!before && (T_) > 0) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
     else                                                                                                           \
-      slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_, 4 * X3_BWD_STEPS>(a1, b1, a0, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
+      slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a1, b1, a0, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
-          [&](int idx) __attribute__((always_inline)) { EPI_(SNY_W(W_), (T_) - 1, a0, b0, idx); },                 \
+          [&](int blk) __attribute__((always_inline)) { EPI_(SNY_W(W_), (T_) - 1, a0, b0, blk); },                 \
           [&](int st, int n, bool before) __attribute__((always_inline)) {                                         \
             if (!before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
@@ -254,7 +249,8 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
     SNY_SLAB(6, NK_, SET_, NBB_, EPI_, W_);                                     \
     SNY_SLAB(7, NK_, SET_, NBB_, EPI_, W_);                                     \
     x3_result_fence(a1, b1);                                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4 * X3_BWD_STEPS; ++i_) EPI_(SNY_W(W_), 7, a1, b1, i_);   \
+    EPI_(SNY_W(W_), 7, a1, b1, 0); EPI_(SNY_W(W_), 7, a1, b1, 1);               \
+    EPI_(SNY_W(W_), 7, a1, b1, 2); EPI_(SNY_W(W_), 7, a1, b1, 3);               \
     store_rows(out_slot, 7, 0); store_rows(out_slot, 7, 1);                     \
     store_rows(out_slot, 7, 2); store_rows(out_slot, 7, 3);                     \
   } while (0)

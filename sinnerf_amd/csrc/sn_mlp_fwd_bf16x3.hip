@@ -166,45 +166,51 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         }
       }
     };
-    // Epilogue of output tile t as micro-steps (sn_mlp_x3.h): idx = 6 blk + step, blk = 0..3 the block of accumulator registers
-    // 4 blk .. 4 blk + 3 (q = 2 blk: dwords q, q + 1 of the tile = k-steps 2t (q < 4), 2t + 1 of the next layer, hi part and lo part)
-    X3Blk eb;
-    auto epi_common = [&](auto wset, auto relu, auto sigma, int t, const f32x16& ra, const f32x16& rb, int idx) __attribute__((always_inline)) {
+    // (blk = 0..3: the block of accumulator registers 4 blk .. 4 blk + 3, q = 2 blk)
+    auto relu_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {
       constexpr int W = decltype(wset)::value;
-      constexpr bool RELU = decltype(relu)::value, SIGMA = decltype(sigma)::value;
-      const int blk = idx / X3_FWD_STEPS, step = idx % X3_FWD_STEPS, q = 2 * blk;
-      const int rh = x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), rl = x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3);
-      if (step == 0) {
+      {
+        const int q = 2 * blk;
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
-        x3_step_sum(a, b, eb);
-      } else if (step == 1) {
-        if (RELU) x3_step_relu(eb);
-        stage(q >> 1, eb.s);
-      } else if (step == 2) {
-        x3_step_hi0(eb);
-      } else if (step == 3) {
-        x3_step_hi1(rh, eb);
-        if (RELU) sign_pair(t, q, eb.h0, eb.h1);
-      } else if (step == 4) {
-        x3_step_rem(eb);
-      } else {
-        x3_step_lo(rl, eb);
-        if (SIGMA) {                                         // sigma head on the fp32 ReLU outputs (nerf.py:136)
-          const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t + 4 * blk);
-          x3_step_fmac(sg, w, eb);
-        }
-        if (RELU && blk == 3) sign_tile_done(t);
+        float v[4];
+        uint32_t h0, h1;
+        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1);
+        stage(q >> 1, v);
+        sign_pair(t, q, h0, h1);
       }
+      if (blk == 3) sign_tile_done(t);
     };
-    auto relu_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int idx) __attribute__((always_inline)) {
-      epi_common(wset, std::true_type{}, std::false_type{}, t, ra, rb, idx);
+    auto relu_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {   // layer 8
+      constexpr int W = decltype(wset)::value;
+      const f32x4* ws = reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t);
+      {
+        const int q = 2 * blk;
+        const f32x4 w = ws[q >> 1];
+        const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
+        const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
+        float v[4];
+        uint32_t h0, h1;
+        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1);
+        sign_pair(t, q, h0, h1);
+        sg = __builtin_fmaf(w[0], v[0], sg);                 // sigma head on the fp32 ReLU outputs (nerf.py:136)
+        sg = __builtin_fmaf(w[1], v[1], sg);
+        sg = __builtin_fmaf(w[2], v[2], sg);
+        sg = __builtin_fmaf(w[3], v[3], sg);
+        stage(q >> 1, v);
+      }
+      if (blk == 3) sign_tile_done(t);
     };
-    auto relu_sigma_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int idx) __attribute__((always_inline)) {   // layer 8
-      epi_common(wset, std::true_type{}, std::true_type{}, t, ra, rb, idx);
-    };
-    auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int idx) __attribute__((always_inline)) {   // xyz_encoding_final
-      epi_common(wset, std::false_type{}, std::false_type{}, t, ra, rb, idx);
+    auto copy_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {   // xyz_encoding_final
+      constexpr int W = decltype(wset)::value;
+      {
+        const int q = 2 * blk;
+        const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
+        const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
+        float v[4];
+        x3_epi<false>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v);
+        stage(q >> 1, v);
+      }
     };
 #define SNX_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SNX_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
@@ -214,33 +220,34 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     // training forward: the youngest four vector-memory operations of a wave at a slab's sync point are the row stores the
     // previous slab posted behind its DMA pieces (tile T-2's; at T = 0 the previous layer's last tile's) -- except at T = 1,
     // whose predecessor posts none
-#define SNX_SLAB(T_, NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, BH_, BL_, EPI_, W_, NP_)                                              \
+#define SNX_SLAB(T_, NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, BH_, BL_, EPI_, W_)                                              \
   do {                                                                                                                     \
     constexpr int VW_ = (STORE && (T_) != 1) ? 4 : 0;                                                                      \
     if (((T_) & 1) == 0)                                                                                                   \
-      slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_, ((T_) > 0 ? NP_ : 0)>(a0, b0, a1, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
-                                                   [&](int idx) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNX_W(W_), (T_) - 1, a1, b1, idx); }, \
+      slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a0, b0, a1, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
+                                                   [&](int blk) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNX_W(W_), (T_) - 1, a1, b1, blk); }, \
                                                    [&](int st, int n, bool before) __attribute__((always_inline)) {                    \
                                                      if ((T_) > 0 && !before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(cur_slot, (T_) - 1, i); }); }); \
     else                                                                                                                   \
-      slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_, NP_>(a1, b1, a0, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
-                                                   [&](int idx) __attribute__((always_inline)) { EPI_(SNX_W(W_), (T_) - 1, a0, b0, idx); }, \
+      slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a1, b1, a0, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
+                                                   [&](int blk) __attribute__((always_inline)) { EPI_(SNX_W(W_), (T_) - 1, a0, b0, blk); }, \
                                                    [&](int st, int n, bool before) __attribute__((always_inline)) {                    \
                                                      if (!before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(cur_slot, (T_) - 1, i); }); }); \
     SNX_ADVANCE();                                                                                                         \
   } while (0)
 #define SNX_LAYER(NK0_, NK1_, S0_, S1_, GB_, NBA_, NBB_, EPI_, W_)              \
   do {                                                                          \
-    SNX_SLAB(0, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_, 4 * X3_FWD_STEPS);          \
-    SNX_SLAB(1, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_, 4 * X3_FWD_STEPS);          \
-    SNX_SLAB(2, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_, 4 * X3_FWD_STEPS);          \
-    SNX_SLAB(3, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_, 4 * X3_FWD_STEPS);          \
-    SNX_SLAB(4, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_, 4 * X3_FWD_STEPS);          \
-    SNX_SLAB(5, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_, 4 * X3_FWD_STEPS);          \
-    SNX_SLAB(6, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_, 4 * X3_FWD_STEPS);          \
-    SNX_SLAB(7, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_, 4 * X3_FWD_STEPS);          \
+    SNX_SLAB(0, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_);          \
+    SNX_SLAB(1, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_);          \
+    SNX_SLAB(2, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_);          \
+    SNX_SLAB(3, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_);          \
+    SNX_SLAB(4, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_);          \
+    SNX_SLAB(5, NK0_, NK1_, S0_, S1_, GB_, 0, NBA_, xh, xl, EPI_, W_);          \
+    SNX_SLAB(6, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_);          \
+    SNX_SLAB(7, NK0_, NK1_, S0_, S1_, GB_, 0, NBB_, xh, xl, EPI_, W_);          \
     x3_result_fence(a1, b1);                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4 * X3_FWD_STEPS; ++i_) EPI_(SNX_W(W_), 7, a1, b1, i_);   \
+    EPI_(SNX_W(W_), 7, a1, b1, 0); EPI_(SNX_W(W_), 7, a1, b1, 1);               \
+    EPI_(SNX_W(W_), 7, a1, b1, 2); EPI_(SNX_W(W_), 7, a1, b1, 3);               \
     store_rows(cur_slot, 7, 0); store_rows(cur_slot, 7, 1);                     \
     store_rows(cur_slot, 7, 2); store_rows(cur_slot, 7, 3);                     \
   } while (0)
@@ -321,11 +328,10 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     };
     // 18 k-steps per slab: the fragment-ring phase alternates 0, 2, 0, 2; tiles 2, 3 stage the next point tile's first slabs
     cur_slot = 9;
-    // (ShiftedSoftplus + rgb head of a tile: four blocks of ~26 VALU incl. two exp / log pairs each -- one block per gap)
-    SNX_SLAB(0, 16, 2, 0, -1, 2, 0, B_DIR, dh, dl, ssp_tile, 0, 4);
-    SNX_SLAB(1, 16, 2, 0, -1, 2, 2, B_DIR, dh, dl, ssp_tile, 0, 4);
-    SNX_SLAB(2, 16, 2, 0, -1, 2, 0, B_L0, dh, dl, ssp_tile, 0, 4);
-    SNX_SLAB(3, 16, 2, 0, -1, 2, 2, B_L0, dh, dl, ssp_tile, 0, 4);
+    SNX_SLAB(0, 16, 2, 0, -1, 2, 0, B_DIR, dh, dl, ssp_tile, 0);
+    SNX_SLAB(1, 16, 2, 0, -1, 2, 2, B_DIR, dh, dl, ssp_tile, 0);
+    SNX_SLAB(2, 16, 2, 0, -1, 2, 0, B_L0, dh, dl, ssp_tile, 0);
+    SNX_SLAB(3, 16, 2, 0, -1, 2, 2, B_L0, dh, dl, ssp_tile, 0);
     x3_result_fence(a1, b1);
     ssp_tile(SNX_W(0), 3, a1, b1, 0); ssp_tile(SNX_W(0), 3, a1, b1, 1);
     ssp_tile(SNX_W(0), 3, a1, b1, 2); ssp_tile(SNX_W(0), 3, a1, b1, 3);

@@ -111,60 +111,6 @@ SN_DEV void x3_put_signed(int rh, int rl, const float (&x)[4], uint32_t word, in
                  "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
 }
 
-// ---- The epilogue of a block (four accumulator registers of both chains) as MICRO-STEPS of four instructions, one per MFMA gap.
-// In-order issue: a wave that has issued its three MFMAs of a k-step waits for the pipe at each of them, and what follows the third
-// runs in the shadow of that one MFMA only -- the epilogue as a block behind a k-step (round-4 first form) cost its full issue time
-// (profiles/r04_x3_infer_floor.txt: the components of the kernel ADD).  One micro-step behind EACH MFMA is hidden.
-// State of the block between its steps: s = the activated fp32 values, u = scratch (hi parts as fp32, then the remainders), h0 / h1 =
-// the packed hi pairs.  `step`, rh, rl must fold to constants.  Forward (RELU / copy), 6 steps:
-//   0 s = A + B   1 s = max(s, 0)   2 h0, h1 = cvt_pk(s); u0, u1 = unpack(h0)   3 u2, u3 = unpack(h1); a[rh..] = h0, h1
-//   4 u = s - u   5 a[rl..] = cvt_pk(u)
-struct X3Blk { float s[4]; float u[4]; uint32_t h0, h1; };
-constexpr int X3_FWD_STEPS = 6, X3_BWD_STEPS = 7;
-SN_DEV void x3_step_sum(const float (&a)[4], const float (&b)[4], X3Blk& e) {
-  asm volatile("v_add_f32 %0, %4, %8\n\tv_add_f32 %1, %5, %9\n\tv_add_f32 %2, %6, %10\n\tv_add_f32 %3, %7, %11"
-               : "=&v"(e.s[0]), "=&v"(e.s[1]), "=&v"(e.s[2]), "=&v"(e.s[3])
-               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
-}
-SN_DEV void x3_step_relu(X3Blk& e) {
-  asm volatile("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
-               : "+v"(e.s[0]), "+v"(e.s[1]), "+v"(e.s[2]), "+v"(e.s[3]));
-}
-SN_DEV void x3_step_hi0(X3Blk& e) {
-  asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_lshlrev_b32 %2, 16, %0\n\tv_and_b32 %3, 0xffff0000, %0"
-               : "=&v"(e.h0), "=&v"(e.h1), "=&v"(e.u[0]), "=&v"(e.u[1]) : "v"(e.s[0]), "v"(e.s[1]), "v"(e.s[2]), "v"(e.s[3]));
-}
-SN_DEV void x3_step_hi1(int rh, X3Blk& e) {
-  asm volatile("v_lshlrev_b32 %0, 16, %3\n\tv_and_b32 %1, 0xffff0000, %3\n\tv_accvgpr_write_b32 a[%4], %2\n\tv_accvgpr_write_b32 a[%5], %3"
-               : "=&v"(e.u[2]), "=&v"(e.u[3]) : "v"(e.h0), "v"(e.h1), "n"(rh), "n"(rh + 1));
-}
-SN_DEV void x3_step_rem(X3Blk& e) {
-  asm volatile("v_sub_f32 %0, %4, %0\n\tv_sub_f32 %1, %5, %1\n\tv_sub_f32 %2, %6, %2\n\tv_sub_f32 %3, %7, %3"
-               : "+v"(e.u[0]), "+v"(e.u[1]), "+v"(e.u[2]), "+v"(e.u[3]) : "v"(e.s[0]), "v"(e.s[1]), "v"(e.s[2]), "v"(e.s[3]));
-}
-SN_DEV void x3_step_lo(int rl, X3Blk& e) {
-  uint32_t l0, l1;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\tv_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
-               : "=&v"(l0), "=&v"(l1) : "v"(e.u[0]), "v"(e.u[1]), "v"(e.u[2]), "v"(e.u[3]), "n"(rl), "n"(rl + 1));
-}
-// Backward chain, 7 steps:  0 s = A + B (+ the caller's sigma term)   1 m = -bit (v_bfe_i32)   2 s &= m   3..6 = forward steps 2..5
-SN_DEV void x3_step_bits(uint32_t word, int k, X3Blk& e) {
-  asm volatile("v_bfe_i32 %0, %4, %5, 1\n\tv_bfe_i32 %1, %4, %6, 1\n\tv_bfe_i32 %2, %4, %7, 1\n\tv_bfe_i32 %3, %4, %8, 1"
-               : "=&v"(e.u[0]), "=&v"(e.u[1]), "=&v"(e.u[2]), "=&v"(e.u[3]) : "v"(word), "n"(k), "n"(k + 16), "n"(k + 1), "n"(k + 17));
-}
-SN_DEV void x3_step_mask(X3Blk& e) {
-  asm volatile("v_and_b32 %0, %4, %0\n\tv_and_b32 %1, %5, %1\n\tv_and_b32 %2, %6, %2\n\tv_and_b32 %3, %7, %3"
-               : "+v"(e.s[0]), "+v"(e.s[1]), "+v"(e.s[2]), "+v"(e.s[3]) : "v"(e.u[0]), "v"(e.u[1]), "v"(e.u[2]), "v"(e.u[3]));
-}
-SN_DEV void x3_step_fmac(float& acc, const f32x4& w, const X3Blk& e) {        // acc += w . s  (sigma head, nerf.py:136)
-  asm volatile("v_fmac_f32 %0, %1, %5\n\tv_fmac_f32 %0, %2, %6\n\tv_fmac_f32 %0, %3, %7\n\tv_fmac_f32 %0, %4, %8"
-               : "+v"(acc) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(e.s[0]), "v"(e.s[1]), "v"(e.s[2]), "v"(e.s[3]));
-}
-SN_DEV void x3_step_fma_sig(X3Blk& e, const f32x4& w, float g) {               // s += w g   (sigma^T term of the chain)
-  asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
-               : "+v"(e.s[0]), "+v"(e.s[1]), "+v"(e.s[2]), "+v"(e.s[3]) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(g));
-}
-
 // One slab: NK0 + NK1 k-steps (two K segments), barrier after k-step GB (the 3-slot protocol of sn_mlp_pipe.h).
 //   SET0/SET1  B operands of the segment: AGPR activation set 0/1, or -1 = the VGPR arrays bh / bl ([k-step])
 //   accA/accB  the two chains of this slab (accA bias-initialised on entry, accB started by its first MFMA with C = 0)
@@ -178,10 +124,7 @@ SN_DEV void x3_step_fma_sig(X3Blk& e, const f32x4& w, float g) {               /
 //   post(step, n)  memory operations of the caller, once per k-step behind the sync point (step = ks - GB of n = NK - GB): with
 //              before = true in FRONT of the k-step's DMA pieces (the chain's mask loads), with false BEHIND them (row stores:
 //              x3_store_step maps the LAST four steps to the four row-group stores of the previous tile)
-//   NPEND      micro-steps of the previous tile's deferred epilogue: pending(0 .. NPEND-1) in order, ONE behind each MFMA starting with
-//              the third of k-step 0 (an accumulator is read two MFMAs behind its last write; slabs of 8 k-steps take two per gap, the
-//              4-k-step slabs all of them behind k-step 0); the next slab's bias goes into the vacated chain A one k-step behind the last
-template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, int VMW, int NPEND, class RingX, class Pending, class Post>
+template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, int VMW = 0, class RingX, class Pending, class Post>
 SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], const char* lw, const u32x4* bh, const u32x4* bl,
                     const char* lw_next, const float* lds_bias, int s_next, int h, RingX& ring, Pending&& pending, Post&& post) {
   constexpr int NK = NK0 + NK1;
@@ -233,46 +176,36 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
     const bool seg0 = ks < NK0;
     const int kk = seg0 ? ks : ks - NK0;
     const int set = seg0 ? SET0 : SET1;
-    // micro-steps of the deferred epilogue behind MFMA j of this k-step
-    constexpr int SPG = (NK >= 12) ? 1 : 2;                  // steps per gap
-    auto gap = [&](int j) __attribute__((always_inline)) {
-      if (NK < 8) {                                          // 4-k-step slabs: everything behind k-step 0 (their row stores start at k-step 1)
-        if (ks == 0 && j == 2) {
-#pragma unroll
-          for (int i = 0; i < NPEND; ++i) pending(i);
-        }
-      } else {
-        const int g = 3 * ks + j - 2;
-#pragma unroll
-        for (int i = 0; i < SPG; ++i)
-          if (g >= 0 && SPG * g + i < NPEND) pending(SPG * g + i);
-      }
-    };
     if (ks == 0) {
       if (set < 0) {
-        x3_mma_v<true, false>(c0, a_hi, bh[kk]); gap(0);
-        x3_mma_v<false, true>(c1, a_lo, bh[kk]); gap(1);
-        x3_mma_v<false, false>(c0, a_hi, bl[kk]); gap(2);
+        x3_mma_v<true, false>(c0, a_hi, bh[kk]);
+        x3_mma_v<false, true>(c1, a_lo, bh[kk]);
+        x3_mma_v<false, false>(c0, a_hi, bl[kk]);
       } else {
-        x3_mma_a<true, false>(c0, a_hi, x3_reg(set, 0, kk)); gap(0);
-        x3_mma_a<false, true>(c1, a_lo, x3_reg(set, 0, kk)); gap(1);
-        x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk)); gap(2);
+        x3_mma_a<true, false>(c0, a_hi, x3_reg(set, 0, kk));
+        x3_mma_a<false, true>(c1, a_lo, x3_reg(set, 0, kk));
+        x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
       }
     } else if (set < 0) {
-      x3_mma_v<false, false>(c0, a_hi, bh[kk]); gap(0);
-      x3_mma_v<false, false>(c1, a_lo, bh[kk]); gap(1);
-      x3_mma_v<false, false>(c0, a_hi, bl[kk]); gap(2);
+      x3_mma_v<false, false>(c0, a_hi, bh[kk]);
+      x3_mma_v<false, false>(c1, a_lo, bh[kk]);
+      x3_mma_v<false, false>(c0, a_hi, bl[kk]);
     } else {
-      x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 0, kk)); gap(0);
-      x3_mma_a<false, false>(c1, a_lo, x3_reg(set, 0, kk)); gap(1);
-      x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk)); gap(2);
+      x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 0, kk));
+      x3_mma_a<false, false>(c1, a_lo, x3_reg(set, 0, kk));
+      x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
     }
     __builtin_amdgcn_sched_barrier(0);
-    {
-      constexpr int LAST_GAP = (NK < 8 || NPEND == 0) ? 0 : (NPEND + SPG - 1) / SPG + 1;     // gap index (3 ks + j) of the last micro-step
-      constexpr int KBIAS = (NK < 8) ? 1 : LAST_GAP / 3 + 1;
-      static_assert(KBIAS < NK, "the bias of the next slab is loaded inside this one");
-      if (ks == KBIAS) nA = load_bias(lds_bias, s_next, h);
+    // the previous tile's deferred epilogue, one block of four accumulator registers (~25 VALU) behind each of the first four
+    // k-steps -- as ONE block behind k-step 0 (~100 VALU against 3 MFMAs in flight) it left the MFMA pipe idle for a third of every slab
+    // (45 % busy, profiles/r04_x3_train_kernels.txt); the 4-k-step slabs keep it whole.  The next slab's bias goes into
+    // the vacated chain A right behind the last block.
+    if (NK >= 8) {
+      if (ks < 4) pending(ks);
+      if (ks == 4) nA = load_bias(lds_bias, s_next, h);
+    } else {                                                 // (4-k-step slabs: the row stores of the tile start at k-step 1)
+      if (ks == 0) { pending(0); pending(1); pending(2); pending(3); }
+      if (ks == 1) nA = load_bias(lds_bias, s_next, h);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
