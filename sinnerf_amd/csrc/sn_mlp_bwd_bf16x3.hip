@@ -134,13 +134,17 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
     sw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sign_base(7) + s_off));      // xyz_encoding_8's (the first masked layer)
     swn = sw;
     auto stage = [&](int qq, const float (&v)[4]) __attribute__((always_inline)) { x3_lds_write_b128(xp_w_lds, 32 * qq, v); };
-    auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
+    f32x4 rowbuf[1];                                         // row groups between their ds_read and their store (x3_store_step)
+    auto rows_read = [&](int i) __attribute__((always_inline)) {
+      rowbuf[0] = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
+    };
+    auto rows_write = [&](int slot, int t, int i) __attribute__((always_inline)) {
       const char* base = reinterpret_cast<const char*>(G) + (((long)slot * slot_rows + p_wave + 8 * i) * 256 + 32 * t) * 4;
       unsigned go = g_off;
       asm volatile("" : "+v"(go));
-      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
+      __builtin_nontemporal_store(rowbuf[0], reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
     };
+    auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) { rows_read(i); rows_write(slot, t, i); };
 
     // ---- rgb.0^T on the VALU: g_h2 = W_r^T g_y3 ; g_y2 = g_h2 (1 - exp(-h2)); written to set 0 (K-slots 16t + r).  All four
     //      softplus tiles are requested first (one latency, not four)
@@ -227,14 +231,14 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
       slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a0, b0, a1, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
           [&](int blk) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNY_W(W_), (T_) - 1, a1, b1, blk); },   \
-          [&](int st, int n, bool before) __attribute__((always_inline)) {                                         \
-            if (!before && (T_) > 0) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
+          [&](int ks, int nk, int gb, bool before) __attribute__((always_inline)) {                                         \
+            if (!before && (T_) > 0) x3_store_step(ks, nk, gb, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(out_slot, (T_) - 1, i); }); }); \
     else                                                                                                           \
       slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a1, b1, a0, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
           [&](int blk) __attribute__((always_inline)) { EPI_(SNY_W(W_), (T_) - 1, a0, b0, blk); },                 \
-          [&](int st, int n, bool before) __attribute__((always_inline)) {                                         \
-            if (!before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(out_slot, (T_) - 1, i); }); }); \
+          [&](int ks, int nk, int gb, bool before) __attribute__((always_inline)) {                                         \
+            if (!before) x3_store_step(ks, nk, gb, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(out_slot, (T_) - 1, i); }); }); \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
   } while (0)
     // the 8 output tiles of a transposed layer; tiles 6, 7 stage the NEXT layer's slabs (NBB_); the last tile's epilogue is not deferred

@@ -130,15 +130,19 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     auto stage = [&](int qq, const float (&v)[4]) __attribute__((always_inline)) {
       if (STORE) x3_lds_write_b128(xp_w_lds, 32 * qq, v);
     };
-    auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) {
+    f32x4 rowbuf[1];                                         // row groups between their ds_read and their store (x3_store_step)
+    auto rows_read = [&](int i) __attribute__((always_inline)) {
+      if (STORE) rowbuf[0] = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
+    };
+    auto rows_write = [&](int slot, int t, int i) __attribute__((always_inline)) {
       if (STORE) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
         const char* base = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + p_wave + 8 * i) * 256 + 32 * t) * 4;
         unsigned go = g_off;
         asm volatile("" : "+v"(go));             // opaque per store: no hoisted per-slot address registers
-        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
+        __builtin_nontemporal_store(rowbuf[0], reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
       }
     };
+    auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) { rows_read(i); rows_write(slot, t, i); };
     // Epilogues of output tile t (chains ra + rb) writing activation set W: dword q of the tile = results 2q, 2q+1 -> k-steps
     // 2t (q < 4), 2t+1 of the next layer, hi part and lo part
     // training forward: ReLU sign words for the backward chain (sn_mlp_x3.h x3_sign_bits): one word per lane and tile PAIR, the four
@@ -226,13 +230,13 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     if (((T_) & 1) == 0)                                                                                                   \
       slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a0, b0, a1, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
                                                    [&](int blk) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNX_W(W_), (T_) - 1, a1, b1, blk); }, \
-                                                   [&](int st, int n, bool before) __attribute__((always_inline)) {                    \
-                                                     if ((T_) > 0 && !before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(cur_slot, (T_) - 1, i); }); }); \
+                                                   [&](int ks, int nk, int gb, bool before) __attribute__((always_inline)) {                    \
+                                                     if ((T_) > 0 && !before) x3_store_step(ks, nk, gb, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(cur_slot, (T_) - 1, i); }); }); \
     else                                                                                                                   \
       slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a1, b1, a0, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
                                                    [&](int blk) __attribute__((always_inline)) { EPI_(SNX_W(W_), (T_) - 1, a0, b0, blk); }, \
-                                                   [&](int st, int n, bool before) __attribute__((always_inline)) {                    \
-                                                     if (!before) x3_store_step(st, n, [&](int i) __attribute__((always_inline)) { store_rows(cur_slot, (T_) - 1, i); }); }); \
+                                                   [&](int ks, int nk, int gb, bool before) __attribute__((always_inline)) {                    \
+                                                     if (!before) x3_store_step(ks, nk, gb, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(cur_slot, (T_) - 1, i); }); }); \
     SNX_ADVANCE();                                                                                                         \
   } while (0)
 #define SNX_LAYER(NK0_, NK1_, S0_, S1_, GB_, NBA_, NBB_, EPI_, W_)              \

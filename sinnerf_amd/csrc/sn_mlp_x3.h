@@ -24,6 +24,14 @@ SN_DEV void x3_mma_v(f32x16& acc, const u32x4& a, const u32x4& b) {
   else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
+// the three MFMAs of a k-step (c0 += Ah.Bh ; c1 += Al.Bh ; c0 += Ah.Bl) as ONE asm: hipcc pads an `s_nop 0` in front of the third
+// (it depends on the first) when they are separate statements -- one issue slot per k-step of a kernel that is issue-bound
+SN_DEV void x3_mma3_a(f32x16& c0, f32x16& c1, const u32x4& ah, const u32x4& al, int rh, int rl) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, a[%4:%5], %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, a[%4:%5], %1\n\t"
+               "v_mfma_f32_32x32x16_bf16 %0, %2, a[%6:%7], %0"
+               : "+v"(c0), "+v"(c1) : "v"(ah), "v"(al), "n"(rh), "n"(rh + 3), "n"(rl), "n"(rl + 3));
+}
+
 // MFMA (8 passes) -> VALU read of its result at a layer end: the wait states the compiler would insert for a builtin MFMA.  The two
 // chains are operands: plain C++ arithmetic on them (A + B) could otherwise be scheduled above the wait (tools/check_agpr.py).
 SN_DEV void x3_result_fence(f32x16& a, f32x16& b) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b)); }
@@ -121,7 +129,7 @@ SN_DEV void x3_put_signed(int rh, int rl, const float (&x)[4], uint32_t word, in
 //   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead), a multiple of 4 KB for every K
 //   VMW        counted wait at the sync point (training kernels): the youngest VMW vector-memory operations of the wave at the START of
 //              the slab are row stores issued BEHIND the previous slab's DMA pieces and may stay in flight; barriers are raw s_barriers
-//   post(step, n)  memory operations of the caller, once per k-step behind the sync point (step = ks - GB of n = NK - GB): with
+//   post(ks, NK, GB, before)  memory operations of the caller, once per k-step behind the sync point: with
 //              before = true in FRONT of the k-step's DMA pieces (the chain's mask loads), with false BEHIND them (row stores:
 //              x3_store_step maps the LAST four steps to the four row-group stores of the previous tile)
 template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, int VMW = 0, class RingX, class Pending, class Post>
@@ -154,6 +162,8 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW + ISSUED) : "memory");
       __builtin_amdgcn_s_barrier();
     }
+    const bool dma = ks >= GB && (ks - GB) * PPK < NP;       // this k-step carries DMA pieces; the first one's m0 write goes in FRONT of
+    if (dma) ring.piece_m0();                           // the fragment reads (they are the wait state between it and the load)
     {
       const int kn = ks + 3;
       const char* src = (kn < NK) ? lw + kn * 2048 : lw_next + (kn - NK) * 2048;
@@ -161,11 +171,12 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
       af[(PHASE + kn) & 3][1] = *reinterpret_cast<const u32x4*>(src + 1024);
     }
     if (ks >= GB) {
-      post(ks - GB, NK - GB, true);
+      post(ks, NK, GB, true);
+      if (dma) ring.piece_load();
 #pragma unroll
-      for (int i = 0; i < PPK; ++i)
+      for (int i = 1; i < PPK; ++i)
         if ((ks - GB) * PPK + i < NP) ring.piece_static();
-      post(ks - GB, NK - GB, false);
+      post(ks, NK, GB, false);
     }
     __builtin_amdgcn_sched_barrier(0);
     const u32x4 a_hi = af[(PHASE + ks) & 3][0], a_lo = af[(PHASE + ks) & 3][1];
@@ -186,14 +197,12 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
         x3_mma_a<false, true>(c1, a_lo, x3_reg(set, 0, kk));
         x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
       }
-    } else if (set < 0) {
-      x3_mma_v<false, false>(c0, a_hi, bh[kk]);
+    } else if (set < 0) {                                    // (as three statements: bundled, the kernels with pre-embedded inputs run
+      x3_mma_v<false, false>(c0, a_hi, bh[kk]);              //  out of VGPRs and hipcc spills into the hand-managed AGPR file)
       x3_mma_v<false, false>(c1, a_lo, bh[kk]);
       x3_mma_v<false, false>(c0, a_hi, bl[kk]);
     } else {
-      x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 0, kk));
-      x3_mma_a<false, false>(c1, a_lo, x3_reg(set, 0, kk));
-      x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
+      x3_mma3_a(c0, c1, a_hi, a_lo, x3_reg(set, 0, kk), x3_reg(set, 1, kk));
     }
     __builtin_amdgcn_sched_barrier(0);
     // the previous tile's deferred epilogue, one block of four accumulator registers (~25 VALU) behind each of the first four
@@ -255,16 +264,25 @@ SN_DEV void x3_put_masked(int rh, int rl, const float (&x)[4], const f32x4& a, f
                : "vcc");
 }
 
-// the four row-group stores of a finished tile over the memory steps of the next slab: the LAST four steps carry one each
-// (a 4-k-step slab has three steps behind its sync point: 1 + 1 + 2); f(i) issues store i
-template <class F>
-SN_DEV void x3_store_step(int step, int n, F&& f) {
-  if (n >= 4) {
-    if (step >= n - 4) f(step - (n - 4));
-  } else if (step < 2) {
-    f(step);
+// the four row-group stores of a finished tile over the memory steps of the next slab.  A row group leaves the staging tile with a
+// ds_read_b128 and goes out with a global_store one step LATER (rd(i) then, a k-step on, wr(i)): read + store in one step parks the wave
+// for the LDS latency with nothing but the previous k-step's MFMAs in flight -- four times per slab (measured: the training forward lost
+// a third of its rate to it).  The LAST five steps carry rd(0) | wr(0) rd(1) | wr(1) rd(2) | wr(2) rd(3) | wr(3); a 4-k-step slab has
+// three steps behind its sync point and keeps read + store together (1 + 1 + 2), as do the 8-k-step slabs (last four steps).  The stores stay the youngest four vector-memory
+// operations of the slab (VMW of slab_x3).
+template <class R, class W>
+SN_DEV void x3_store_step(int ks, int nk, int gb, R&& rd, W&& wr) {
+  if (nk >= 9) {                                 // rd(0) not before k-step 4: pending(0..3) fill the staging tile behind k-steps 0..3
+    const int j = ks - (nk - 5);
+    if (j >= 1) wr(j - 1);
+    if (j >= 0 && j < 4) rd(j);
+  } else if (nk - gb >= 4) {
+    const int j = ks - (nk - 4);
+    if (j >= 0) { rd(j); wr(j); }
+  } else if (ks - gb < 2) {
+    rd(ks - gb); wr(ks - gb);
   } else {
-    f(2); f(3);
+    rd(2); wr(2); rd(3); wr(3);                 // (one row buffer)
   }
 }
 

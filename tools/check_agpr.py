@@ -15,6 +15,8 @@ guarantees are checked on the generated code instead:
      that wrote it (hipcc pads this hazard for its own instructions only);
   6. a v_permlane32_swap_b32 does not read a register a VALU instruction wrote within the previous 2 wait states (hipcc inserts
      s_nop 1 for its own code).
+  7. an LDS-DMA load (global_load_lds_*) does not issue in the wait state right behind the SALU write of m0 (its LDS address): the
+     kernels issue their DMA pieces from inline asm, some with the m0 write and the load in separate statements.
 usage: check_agpr.py file.s"""
 import re, sys
 
@@ -31,7 +33,7 @@ def vregs(tok):
     return out
 
 kern = None; ina = False; ins = []; bad_agpr = []; spills = 0; pend_ld = {}; bad_async = []; VMEM = ('global_', 'buffer_', 'flat_', 'scratch_')
-sgpr_written = {}; clock = 0; bad_sgpr = []
+sgpr_written = {}; clock = 0; bad_sgpr = []; m0_written = -100; bad_m0 = []
 
 def sregs(tok):
     out = set()
@@ -68,6 +70,9 @@ for ln, l in enumerate(open(sys.argv[1]), 1):
             if r in sgpr_written and clock - sgpr_written[r] < 6: bad_sgpr.append((ln, t))
     if op.startswith('s_') and not op.startswith(('s_nop', 's_waitcnt', 's_barrier', 's_cmp', 's_cbranch', 's_branch', 's_endpgm')) and parts:
         for r in sregs(parts[0]): sgpr_written[r] = clock
+        if parts[0] == 'm0': m0_written = clock
+    # 7. SALU write of m0 -> LDS-DMA load
+    if op.startswith('global_load_lds') and clock - m0_written < 2: bad_m0.append((ln, t))
     clock += (int(t.split()[1], 0) + 1) if op == 's_nop' else 8 if op.startswith('v_mfma') else 1
     # 4. destination registers of a global load issued from inline asm (the wait is hand-placed) are not touched by anything
     #    until an s_waitcnt vmcnt has issued
@@ -110,10 +115,11 @@ for i, (ln, op, dst, src, is_valu, t, _rr) in enumerate(ins):
         j += 1
 
 print(f"compiler-allocated AGPR references: {len(bad_agpr)}; scratch instructions: {spills}; "
-      f"VALU->MFMA read hazards: {len(haz1)}; MFMA->VALU read hazards: {len(haz2)}; early uses of asm loads: {len(bad_async)}; SALU->VMEM address hazards in asm: {len(bad_sgpr)}")
+      f"VALU->MFMA read hazards: {len(haz1)}; MFMA->VALU read hazards: {len(haz2)}; early uses of asm loads: {len(bad_async)}; SALU->VMEM address hazards in asm: {len(bad_sgpr)}; m0->LDS-DMA hazards: {len(bad_m0)}")
+for b in bad_m0[:5]: print("  m0    line %d: %s" % b)
 for b in bad_sgpr[:5]: print("  sgpr  line %d: %s" % b)
 for b in bad_async[:5]: print("  async line %d: %s" % b)
 for b in bad_agpr[:5]: print("  agpr  line %d: %s" % b)
 for b in haz1[:5]: print("  haz1  line %d: %s  ->  %s" % b)
 for b in haz2[:5]: print("  haz2  line %d: %s  ->  %s" % b)
-sys.exit(1 if bad_agpr or spills or haz1 or haz2 or bad_async or bad_sgpr else 0)
+sys.exit(1 if bad_agpr or spills or haz1 or haz2 or bad_async or bad_sgpr or bad_m0 else 0)
