@@ -26,6 +26,23 @@ cd /tmp
 echo "== pmc train (HBM bytes of the training kernels)"
 timeout 600 $P --pmc FETCH_SIZE -o pmc_train_fetch -- python $R/tools/train_bench.py > $R/gpurun_out/prof_pmc_train_fetch.log 2>&1; echo "exit $?"
 timeout 600 $P --pmc WRITE_SIZE -o pmc_train_write -- python $R/tools/train_bench.py > $R/gpurun_out/prof_pmc_train_write.log 2>&1; echo "exit $?"
+echo "== bf16x3 inference launch: stats, then cycles / MFMA-busy / clock"
+timeout 300 $P --stats -o stats_x3 -- python $R/tools/x3_infer_time.py fp32 bf16 bf16x3 > $R/gpurun_out/x3_infer.log 2>&1; echo "exit $?"; cat $R/gpurun_out/x3_infer.log | tail -3
+timeout 300 $P --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -o pmc_x3 -- python $R/tools/x3_infer_time.py fp32 bf16 bf16x3 > /dev/null 2>&1; echo "exit $?"
 cd $R
+python - <<'PY' | tee gpurun_out/x3_infer_pmc.txt
+import csv, glob, collections, statistics
+for f in glob.glob("gpurun_out/prof/**/pmc_x3_counter_collection.csv", recursive=True):
+    per = collections.defaultdict(lambda: collections.defaultdict(float)); dur = {}
+    for r in csv.DictReader(open(f)):
+        k = (r["Kernel_Name"][:44], r["Dispatch_Id"])
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"]); dur[k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    for name in sorted({k[0] for k in dur}):
+        ks = [k for k in dur if k[0] == name]
+        if max(dur[k] for k in ks) < 5: continue
+        med = lambda c: statistics.median(per[k][c] for k in ks); ms = statistics.median(dur[k] for k in ks); cyc = med("GRBM_GUI_ACTIVE") / 8
+        print("%-44s %8.3f ms %8.2f Mcyc  clock %.2f GHz  mfma_busy %.3f  parked %.3f  issue-wait %.3f" % (name, ms, cyc / 1e6, cyc / ms / 1e6,
+              med("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / cyc, med("SQ_WAIT_ANY") / med("SQ_WAVE_CYCLES"), med("SQ_WAIT_INST_ANY") / med("SQ_WAVE_CYCLES")))
+PY
 echo "== pmc train (cycles, MFMA-busy, clock of the training kernels)"
 bash tools/train_pmc.sh > gpurun_out/train_pmc.log 2>&1; echo "exit $?"; tail -12 gpurun_out/train_pmc.txt

@@ -14,7 +14,8 @@ tag = sys.argv[1]
 G, P = "gpurun_out", "profiles"
 subprocess.run([sys.executable, "tools/summarize_prof.py", tag], check=True, stdout=subprocess.DEVNULL)
 for src, dst in (("prof/stats_bf16_kernel_stats.csv", "bf16_kernel_stats.csv"), ("prof/stats_train_kernel_stats.csv", "train_kernel_stats.csv"),
-                 ("train_bench.json", "train_bench.json"), ("train_pmc_cycles.json", "train_pmc_cycles.json")):
+                 ("train_bench.json", "train_bench.json"), ("train_pmc_cycles.json", "train_pmc_cycles.json"),
+                 ("prof/stats_x3_kernel_stats.csv", "infer_launch_kernel_stats.csv"), ("x3_infer_pmc.txt", "infer_launch_pmc.txt"), ("x3_infer.log", "infer_launch.txt")):
     if os.path.exists(f"{G}/{src}"):
         shutil.copy(f"{G}/{src}", f"{P}/{tag}_{dst}")
 for log, dst in (("bench.log", "bench_fp32.json"), ("bench_bf16.log", "bench_bf16.json")):
@@ -35,7 +36,7 @@ for cnt, f in (("FETCH_SIZE", "pmc_train_fetch"), ("WRITE_SIZE", "pmc_train_writ
         d["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
         d[cnt] = d.get(cnt, 0.0) + float(r["Counter_Value"])
 POINTS = 524288
-out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python tools/train_bench.py  (4096 rays, 64+64; fp32 step then bf16 mixed-precision step)",
+out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python tools/train_bench.py  (4096 rays, 64+64; fp32 step, bf16 mixed-precision step, bf16x3 step)",
        "note": "median over the fine-pass-sized dispatches of each kernel (524 288 points). FETCH_SIZE doubled per MI355X_MICROARCH.md (wide coalesced reads are tallied at half size on gfx950); WRITE_SIZE as reported. dw_kernel: fp32 and bf16-state launches share one kernel name -- split by duration.",
        "kernels": {}}
 import statistics
@@ -54,7 +55,7 @@ for name, disp in per.items():
         if not f or not w:
             continue
         fetch, write, ms = 2 * 1024 * statistics.median(f), 1024 * statistics.median(w), statistics.median(d["ms"] for d in ds)
-        mode = "bf16" if ("bf16" in name or "shorter" in suffix) else "fp32"      # step the launch belongs to (train_bench.py runs both)
+        mode = "bf16x3" if ("bf16x3" in name or "dw_kernel" in name) else "bf16" if ("bf16" in name or "shorter" in suffix) else "fp32"   # step the launch belongs to
         out["kernels"][name + suffix] = {"step": mode, "fetch_bytes_x2": fetch, "write_bytes": write, "ms": ms,
                                          "hbm_TB_per_s": (fetch + write) / ms / 1e9, "bytes_per_point": (fetch + write) / POINTS}
 out["git_head"] = subprocess.run(["git", "describe", "--always", "--dirty"], capture_output=True, text=True).stdout.strip() or "unknown"

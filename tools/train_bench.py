@@ -99,6 +99,21 @@ ms_chain_b, _ = timed(lambda: _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr
 ms_dw_b, _ = timed(lambda: A._weight_grads(mb[1], acts_b, emb_b, G_b, [True] * 24))
 out["bf16_training"] = {"ms_per_step": dtb * 1e3, "train_rays_per_s": N / dtb, "fine_fwd_train_ms": ms_fwd_b,
                         "fine_bwd_chain_ms": ms_chain_b, "fine_dW_ms": ms_dw_b}
+# fp32-level accuracy on the bf16 MFMA: compute_dtype="bf16x3" (3-term split forward, chain and weight gradients over the fp32 state)
+mx = []
+for seed in (0, 1):
+    mm = sinnerf_amd.NeRF(use_new_activation=True, compute_dtype="bf16x3")
+    mm.load_state_dict({k: torch.from_numpy(v) for k, v in O.init_params(seed, True).items()})
+    mx.append(mm.to(dev).train())
+models = mx
+step(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K):
+    step()
+torch.cuda.synchronize()
+dtx = (time.perf_counter() - t0) / K
+out["bf16x3_training"] = {"ms_per_step": dtx * 1e3, "train_rays_per_s": N / dtx, "tflops_algorithmic": flop / dtx / 1e12,
+                          "x_fp32_mfma_peak": flop / dtx / 157.3e12}
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/train_bench.json", "w"), indent=1)
 print(json.dumps(out))
