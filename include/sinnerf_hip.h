@@ -19,7 +19,7 @@ extern "C" {
 
 #define SN_ABI_VERSION 4   /* 2: sn_sample_pdf_bins gained eps, dtype carries SN_DTYPE_CLASSIC_HEADS, sn_mlp_forward flag bits
                             * 3: dtype carries SN_DTYPE_COMPILER_SCHEDULED and SN_DTYPE_EMB_BF16
-                            * 4: SN_DTYPE_BF16X3 (inference entries + packer), sn_pack_table_entries_dtype */
+                            * 4: SN_DTYPE_BF16X3 (inference and training entries, packers), sn_pack_table_entries_dtype */
 
 #define SN_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32                                          */
 #define SN_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate                    */
