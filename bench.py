@@ -32,9 +32,9 @@ sys.path.insert(0, REPO)
 FLOP_PER_POINT = 1186816            # SURVEY §8d / BASELINE.md §2 (un-padded MACs x2)
 FLOP_PER_POINT_TRAIN = 3489024      # forward + backward
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md: dense MFMA peaks
-# compute_dtype="bf16x3" under autograd = bf16x3 training forward (fp32-level values, fp32 state) + the fp32 backward kernels: its
-# algorithmic rate is reported against the fp32 MFMA peak that bounds the all-fp32 step (a fraction above what the exact-fp32 step
-# can reach means the forward left the fp32 MFMA)
+# compute_dtype="bf16x3" under autograd = forward, backward chain and weight gradients in the 3-term split on the bf16 MFMA (fp32-level
+# values; training state stored as (hi, lo) pairs in the bytes of the fp32 state): its algorithmic rate is reported against the fp32
+# MFMA peak that bounds the all-fp32 step (a fraction above 1 means the step left the fp32 MFMA)
 TRAIN_PEAK = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 157.3}
 
 
@@ -241,9 +241,10 @@ def train_cfg_record(O, dev, dtype, cfg, steps=3, warmup=2):
     if dtype == "bf16":
         rec["roofline"] = train_hbm_roofline(step_s * 1e3, pts)
     else:
-        rec["roofline"] = {"bound": "mfma", "kernel": ("fp32 training step: mlp_fwd_f32_kernel<STORE>" if dtype == "fp32" else
-                                                       "bf16x3 forward (mlp_fwd_bf16x3_kernel<STORE>, fp32 state)") +
-                                                      " + mlp_bwd_chain_f32_kernel + dw_f32_asm_kernel + dw_kernel (4 renders, coarse + fine)",
+        rec["roofline"] = {"bound": "mfma", "kernel": ("fp32 training step: mlp_fwd_f32_kernel<STORE> + mlp_bwd_chain_f32_kernel + dw_f32_asm_kernel + "
+                                                       "dw_narrow_f32_kernel" if dtype == "fp32" else
+                                                       "bf16x3 training step: mlp_fwd_bf16x3_kernel<STORE> + mlp_bwd_chain_bf16x3_kernel + dw_kernel "
+                                                       "(3-term split, (hi, lo) state)") + " (4 renders, coarse + fine)",
                            "achieved": tflop, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": tflop / PEAK_TFLOPS["fp32"], "traffic": None}
     return rec
 

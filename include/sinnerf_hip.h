@@ -26,8 +26,8 @@ extern "C" {
 #define SN_DTYPE_BF16_STATE 2 /* training entries only: SN_DTYPE_BF16 arithmetic AND acts / g_acts stored as bf16
                                * (same shapes; the float* parameters then point at bf16 arrays; emb stays fp32
                                * unless SN_DTYPE_EMB_BF16 is OR-ed in)                                             */
-#define SN_DTYPE_BF16X3 3 /* sn_mlp_forward, sn_mlp_forward_embedded, sn_mlp_forward_train[_embedded] (fp32 state), sn_mlp_backward_chain
-                           * (fp32 state) and the packer: fp32-LEVEL accuracy on the bf16
+#define SN_DTYPE_BF16X3 3 /* sn_mlp_forward, sn_mlp_forward_embedded, sn_mlp_forward_train[_embedded], sn_mlp_backward_chain,
+                           * sn_weight_grads (training state: see sn_mlp_forward_train) and the packer: fp32-LEVEL accuracy on the bf16
                            * MFMA -- every weight and activation as a (hi, lo) bf16 pair, W.x ~= Wh.xh + Wl.xh + Wh.xl with fp32
                            * accumulation (3 bf16 MFMAs instead of 8 fp32 ones per 16 k; SURVEY §7 "3-term bf16 split"); exact
                            * embeddings and fp32 heads as SN_DTYPE_F32.  Measured against the fp32 bars of the parity tests.  */
@@ -123,7 +123,14 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
  * SIGN WORDS of xyz_encoding_1..8 -- for the 64 consecutive points a wave owns, the 32-bit word of (layer l, 32-feature
  * tile t) and lane L sits in row (first point + 8 l + t), bytes [256 + 4 L, 256 + 4 L + 4).  sn_mlp_backward_chain with
  * SN_DTYPE_BF16_STATE takes its ReLU masks from these words (and reads no other activation but slot 9's values): pass it
- * the acts array THIS entry wrote.                                                                             */
+ * the acts array THIS entry wrote.
+ * SN_DTYPE_BF16X3: buffers of the fp32 shapes and sizes (slot_rows a multiple of 128).  emb and slot 9 are fp32 exactly as above;
+ * SLOTS 0..8 hold every value as the (hi, lo) bf16 PAIR the kernels compute with -- hi = RNE(x), lo = RNE(x - hi), x = hi + lo to
+ * 2^-17 relative -- in the 1 KB an fp32 row takes: per 8 consecutive features 16 B of hi parts, then 16 B of lo parts (feature f of a
+ * row: hi at byte 32 (f / 8) + 2 (f % 8), lo 16 B further).  sn_mlp_backward_chain writes slots 0..8 of g_acts the same way,
+ * sn_weight_grads reads both (no conversion on its way to the MFMA).  The unused half of slot 9 receives ReLU sign words for the
+ * chain as with SN_DTYPE_BF16_STATE, in this kernel's tile shape: for the 32 points a wave owns, layer l sits in rows
+ * first point + 4 l + (lane >> 4), bytes [512 + 16 (lane & 15), + 16) -- one word per lane and pair of 32-feature tiles.      */
 int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const float* z_vals, long n_rays, int n_samples,
                          float* out, float* acts, float* emb, long slot_rows, void* stream);
 
@@ -139,8 +146,9 @@ int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, l
  * gradient.  Writes g_acts (10, slot_rows, 256): slots 0..7 = dL/d(pre-activation) of xyz_encoding_1..8, 8 = of
  * xyz_encoding_final, 9 = of dir_encoding (128 wide); g_out (n_points,4) = dL/d(pre-activation) of rgb (3), sigma (1).
  * dtype SN_DTYPE_BF16: blob_bwd from the *_bwd_bf16 table, bf16-operand contractions, everything stored stays fp32.
- * dtype SN_DTYPE_BF16X3: blob_bwd from the *_bwd_bf16x3 table; fp32-level accuracy on the bf16 MFMA (3-term hi/lo split), fp32 acts /
- * g_acts exactly as for SN_DTYPE_F32 (slot_rows a multiple of 128).
+ * dtype SN_DTYPE_BF16X3: blob_bwd from the *_bwd_bf16x3 table; fp32-level accuracy on the bf16 MFMA (3-term hi/lo split); acts as
+ * sn_mlp_forward_train(SN_DTYPE_BF16X3) wrote them (masks from the sign words, h2 from slot 9), g_acts in the same layout: slots 0..8
+ * as (hi, lo) pairs, slot 9 (128 columns + the head block) fp32 (slot_rows a multiple of 128).
  * dtype SN_DTYPE_BF16_STATE: acts / g_acts are bf16 arrays; the ReLU masks come from the sign words sn_mlp_forward_train
  * left in slot 9 (see there), gradients leave as whole 128-byte rows.
  * slot_rows as for sn_mlp_forward_train (>= n_points rounded up to 128, 256 for bf16; rows >= n_points of slots' 256

@@ -42,7 +42,7 @@ def _state_code(model, acts, emb=None):
     """C-ABI dtype of the stored training state: fp32 MFMAs, bf16 operands on fp32 state, or bf16 operands on bf16 state
     (| SN_DTYPE_EMB_BF16 when the embedded inputs were stored as bf16 operands too)."""
     if dtype_code(model.compute_dtype) == _lib.SN_DTYPE_BF16X3:
-        return _lib.SN_DTYPE_BF16X3               # fp32 state, contractions as 3-term hi/lo splits on the bf16 MFMA
+        return _lib.SN_DTYPE_BF16X3               # 3-term hi/lo splits on the bf16 MFMA; state = (hi, lo) pairs in fp32-sized buffers
     if dtype_code(model.compute_dtype) != _lib.SN_DTYPE_BF16:
         return _lib.SN_DTYPE_F32
     code = _lib.SN_DTYPE_BF16_STATE if acts.dtype == torch.bfloat16 else _lib.SN_DTYPE_BF16
@@ -106,7 +106,7 @@ class _MLPFn(torch.autograd.Function):
         n, s = (rays.shape[0], 1) if embedded else z_vals.shape
         P = n * s
         dev = rays.device
-        code = dtype_code(model.compute_dtype)      # (bf16x3: its own forward, fp32 state -- then the fp32 backward)
+        code = dtype_code(model.compute_dtype)      # (bf16x3: fp32-sized buffers, slots 0..8 written as (hi, lo) bf16 pairs)
         # mixed precision keeps the training state (activations, pre-activation gradients) in bf16 as well: every stage of
         # that mode is HBM-bound on exactly this traffic, and the stored values are the ones the kernels consume anyway
         bf16 = code == _lib.SN_DTYPE_BF16
@@ -153,7 +153,7 @@ class _MLPFn(torch.autograd.Function):
             G[:, P:].zero_()
         g_o = torch.empty((P, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            # bf16x3: forward, chain and weight gradients at fp32-level accuracy on the bf16 MFMA over the FP32 training state
+            # bf16x3: forward, chain and weight gradients at fp32-level accuracy on the bf16 MFMA; the state holds (hi, lo) pairs
             code = dtype_code(model.compute_dtype)   # bf16: bf16-operand chain on bf16 state; weight gradients and Adam stay fp32
             if acts.dtype == torch.bfloat16:
                 code = _lib.SN_DTYPE_BF16_STATE

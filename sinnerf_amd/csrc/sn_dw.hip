@@ -24,6 +24,13 @@ namespace snd {
 #ifndef SN_DW_CPOL
 #define SN_DW_CPOL 2      // nt: G and X are streamed once (measured -3 % in the bandwidth-bound bf16 mode, neutral in fp32)
 #endif
+#if SN_DW_CPOL == 2
+#define SN_DW_CPOL_ASM " nt"
+#elif SN_DW_CPOL == 0
+#define SN_DW_CPOL_ASM ""
+#else
+#error "SN_DW_CPOL: 0 or 2 (nt)"
+#endif
 
 // copy KB x W floats (row-major, W*4 bytes per row) global -> LDS.  A chunk past k_end (the ring's prefetch overrun) is
 // replaced by the last real chunk of the task ((k1-k0) % KB == 0) -- a wave-uniform select on the chunk base, so the
@@ -34,36 +41,61 @@ namespace snd {
 // side of global_load_lds is lane-linear, but each lane's GLOBAL address is free, so LDS piece (row, lp) receives the global
 // 16-byte piece (row, lp ^ 4 (row & 3)) -- rows r..r+3 of a 64-byte column group land in four different 64-byte bank groups.
 // (32-wide tiles: a row is 64 B, four rows fill the 256-byte bank window by themselves -- no swizzle.)
-template <int W, int ES>                        // ES = element size in bytes (4: fp32 tile, 2: bf16 tile)
-struct RowStager {
+// SPLIT tiles (bf16x3 training state, slots 0..8 of acts / G -- sn_layout.h "x3 state"): a row of W features is W*4 bytes like an fp32
+// row, but holds per 8 features 16 B of hi parts (bf16) then 16 B of lo parts.  Fragments come out by transpose reads of 8 B = four
+// features of one part: a half-wave touches, per row, every second 16-byte piece of a 128-byte span -- the swizzle puts rows r, r+1
+// on the even / odd pieces (xor 1: hi and lo pieces trade places on odd rows) and rows r+2, r+3 on the next 128 B (xor 8): the 32 lanes
+// cover one 256-byte bank window exactly.
+template <int W, int ES, int SPLIT = 0, bool SPLIT_ASM_DMA = false>   // ES = element size in bytes (4: fp32 tile, 2: bf16 tile); SPLIT: (hi, lo)
+struct RowStager {                                                    // tile, ES = 4; SPLIT_ASM_DMA: the DMA from inline asm (bf16x3 modes)
   static constexpr int CHUNKS = KB * W * ES / 16;   // 16-byte pieces per chunk
   static constexpr int PER_ROW = W * ES / 16;
   static constexpr int IT = (CHUNKS + 255) / 256;
   static constexpr bool SWZ = (ES == 2) && PER_ROW >= 16;
+  static_assert(!SPLIT || (ES == 4 && PER_ROW >= 16), "split tiles are at least 64 features wide");
   unsigned off[IT];
+  static SN_DEV int swz(int row) { return SPLIT ? ((row & 1) | ((row & 2) << 2)) : SWZ ? 4 * (row & 3) : 0; }
   SN_DEV void init(int ld, int tid) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int c = it * 256 + tid;
       const int row = c / PER_ROW, lp = c % PER_ROW;
-      const int gp = SWZ ? (lp ^ (4 * (row & 3))) : lp;
+      const int gp = lp ^ swz(row);
       off[it] = (unsigned)(row * ld * ES + gp * 16);
     }
   }
   // byte offset inside a staged chunk of the 8-byte group (row, columns col .. col+3), col % 4 == 0
   static SN_DEV unsigned tr_offset(int row, int col) {
     const int cp = col * ES / 16;
-    const int lp = SWZ ? (cp ^ (4 * (row & 3))) : cp;
+    const int lp = cp ^ swz(row);
     return (unsigned)(row * W * ES + lp * 16 + (col * ES) % 16);
+  }
+  // split tile: the 8-byte group of the HI parts of features f .. f+3 (f % 4 == 0) of a row; the lo parts sit at this offset ^ 16
+  static SN_DEV unsigned tr_offset_split(int row, int f) {
+    const int lp = (2 * (f >> 3)) ^ swz(row);
+    return (unsigned)(row * W * 4 + lp * 16 + 8 * ((f >> 2) & 1));
   }
   SN_DEV void stage(const void* __restrict__ g, int ld, long k, long k_end, char* lds, int tid) const {
     const long kc = k < k_end ? k : k_end - KB;
     const char* base = reinterpret_cast<const char*>(g) + kc * ld * ES;        // wave-uniform
+    if (SPLIT_ASM_DMA) {                                                        // ... and provably so for the "s" operand of the asm below
+      const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+      base = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                           (unsigned)__builtin_amdgcn_readfirstlane((int)b));
+    }
     const int wbase = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      if (CHUNKS % 256 == 0 || it * 256 + tid < CHUNKS)
-        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(base + off[it]), (lds_void*)(lds + it * 4096 + wbase), 16, 0, SN_DW_CPOL);
+      if (CHUNKS % 256 == 0 || it * 256 + tid < CHUNKS) {
+        if (SPLIT_ASM_DMA) {
+          // inline asm: while a __builtin_amdgcn_global_load_lds is pending, every wait hipcc inserts is vmcnt(0) / lgkmcnt(0)
+          // (sn_mlp_pipe.h) -- here that would drain the fragment reads of the NEXT chunk in front of this chunk's MFMAs
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" SN_DW_CPOL_ASM
+                       :: "v"(off[it]), "s"(base), "s"((unsigned)(size_t)(lds + it * 4096 + wbase)) : "memory");
+        } else {
+          __builtin_amdgcn_global_load_lds((gbl_cvoid*)(base + off[it]), (lds_void*)(lds + it * 4096 + wbase), 16, 0, SN_DW_CPOL);
+        }
+      }
     }
   }
 };
@@ -104,10 +136,15 @@ SN_DEV unsigned dw_pack2(float a, float b) {
 //         ds_read_b64_tr_b16, 4.6 VALU per MFMA) -- 5.5 ms against 4.6 for the fine pass: the extra LDS round trip (32 KB read +
 //         32 KB written per chunk beside the 64 KB of transpose reads, 18 % bank conflicts) and its sync cost more than the
 //         redundant conversions (tools/experiments/dw_x3_planes.cpp.txt, profiles/r04_x3_dw_forms.txt).
+// MODES 5, 6, 7 (SN_DTYPE_BF16X3, what the library runs): the 256-wide slots of the training state hold the (hi, lo) pairs the forward
+//         and the chain computed anyway (SPLIT tiles, RowStager) -- their fragments are four transpose reads and NO conversion; only the
+//         operands that stay fp32 (embedded inputs, slot 9: dir_encoding's 128 columns and the head block) are split in registers.
+//         5: A and B split.  6: A split, B fp32.  7: A fp32, B split.
 template <int MT, int NT, int WM, int WN, int MODE, int LDSB = DW_LDS_BYTES>
 SN_DEV void run_task(const Task& t, char* smem, int tid) {
   constexpr bool BF16 = MODE != 0;
-  constexpr bool X3 = MODE == 4;
+  constexpr bool X3 = MODE >= 4;
+  constexpr bool SA = MODE == 5 || MODE == 6, SB = MODE == 5 || MODE == 7;       // operand arrives as a split tile
   constexpr int EA = (MODE == 2 || MODE == 3) ? 2 : 4, EB = (MODE == 2) ? 2 : 4;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int WA = WM * MT * 32, WB = WN * NT * 32;
@@ -147,8 +184,8 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
 
   const long k0 = t.k0, k1 = t.k1;
   if (k0 >= k1) return;
-  RowStager<WA, EA> sa;
-  RowStager<WB, EB> sb;
+  RowStager<WA, EA, SA, X3> sa;
+  RowStager<WB, EB, SB, X3> sb;
   sa.init(t.lda, tid);
   sb.init(t.ldb, tid);
   const int n_chunks = (int)((k1 - k0 + KB - 1) / KB);
@@ -168,7 +205,9 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
     // (packed, summed, multiplied) in iteration c+1: their LDS latency hides behind the 16 MFMAs of chunk c-1 -- consumed in
     // place hipcc waits on them 19 times per chunk (measured: 2.5 k cycles per chunk against 512 of MFMA work).
     static_assert(KB == 16, "one 32x32x16 k-step per chunk");
-    unsigned ra[MT][EA == 2 ? 4 : 8], rb[NT][EB == 2 ? 4 : 8];   // fragments as read: packed bf16 pairs (transpose reads) or raw fp32 bits
+    constexpr int RA_N = EA == 2 ? 4 : 8, RB_N = EB == 2 ? 4 : 8;
+    unsigned ra0[MT][RA_N], rb0[NT][RB_N];           // fragments as read: packed bf16 pairs (transpose reads: hi [0..3], lo [4..7] of a split tile) or raw fp32 bits
+    unsigned ra1[X3 ? MT : 1][RA_N], rb1[X3 ? NT : 1][RB_N];   // bf16x3: a second set, the gathers run one chunk further ahead (below)
     // transpose-read addresses of this lane inside a staged chunk: lane (q, G): feature block G & 1, point rows 8 (G >> 1) + (q >> 2)
     unsigned ta[MT], tb[NT];
     {
@@ -181,12 +220,17 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) tb[b] = RowStager<WB, EB>::tr_offset(8 * (G >> 1) + (q >> 2), n0 + 32 * b + 16 * (G & 1) + 4 * (q & 3)) + A_BYTES;
       }
+      if constexpr (SA) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) ta[a] = RowStager<WA, 4, 1>::tr_offset_split(8 * (G >> 1) + (q >> 2), m0 + 32 * a + 16 * (G & 1) + 4 * (q & 3));
+      }
+      if constexpr (SB) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) tb[b] = RowStager<WB, 4, 1>::tr_offset_split(8 * (G >> 1) + (q >> 2), n0 + 32 * b + 16 * (G & 1) + 4 * (q & 3)) + A_BYTES;
+      }
     }
     const bool want_bias = t.bias != nullptr && wc == 0;
-    int slot_c = 0;                                  // = c % NBUF (NBUF need not be a power of two)
-    for (int c = 0; c <= n_chunks; ++c, slot_c = (slot_c + 1 == NBUF) ? 0 : slot_c + 1) {
-      char* bc = smem + slot_c * BUF;
-      if (c < n_chunks && c % SY == 0) {
+    auto sync_point = [&](int c, int slot_c) __attribute__((always_inline)) {
         // sync point, every SY-th chunk: chunks c .. c+SY-1 have landed for every wave (the NBUF-2*SY younger ones may still be
         // in flight), chunks c-SY .. c-1 are fully gathered -> their slots are restaged with chunks c+NBUF-SY .. c+NBUF-1
         const long k = k0 + (long)c * KB;
@@ -201,14 +245,26 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
           sa.stage(t.a, t.lda, k + (long)(NBUF - SY + u) * KB, k1, bn, tid);
           sb.stage(t.b, t.ldb, k + (long)(NBUF - SY + u) * KB, k1, bn + A_BYTES, tid);
         }
-      }
-      if (c > 0) {                                 // chunk c-1: pack, column sums, 16 MFMAs
+    };
+    auto compute = [&](auto& ra, auto& rb, auto&& mid) __attribute__((always_inline)) {   // one chunk: pack, column sums, MFMAs (mid(): between the passes)
         dw_bf16x8 af[MT], bf[NT];
         dw_bf16x8 afl[X3 ? MT : 1], bfl[X3 ? NT : 1];  // bf16x3: the lo fragments
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
           dw_u32x4 q;
-          if (EA == 2) {                             // already the operand: 8 points of one feature, packed in k order
+          if (SA) {                                  // split tile: hi and lo fragments as read
+            dw_u32x4 ql;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { q[w] = ra[a][w]; ql[w] = ra[a][4 + w]; }
+            // column sums for the bias gradient, by every wave (a wave-uniform `if (want_bias)` here splits the loop body into basic
+            // blocks, and hipcc drains the NEXT chunk's fragment reads -- s_waitcnt lgkmcnt(0) -- at each of their joins)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(bsum[a]) : "v"(q[w]), "v"(0x3f803f80u));
+              asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(bsum[a]) : "v"(ql[w]), "v"(0x3f803f80u));
+            }
+            afl[a] = __builtin_bit_cast(dw_bf16x8, ql);
+          } else if (EA == 2) {                      // already the operand: 8 points of one feature, packed in k order
 #pragma unroll
             for (int w = 0; w < 4; ++w) q[w] = ra[a][w];
             if (want_bias) {                         // column sums for the bias gradient: fp32 accumulation of the bf16 values
@@ -235,7 +291,8 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
           dw_u32x4 q, ql;
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
-            if (EB == 2) q[w] = rb[b][w];
+            if (SB) { q[w] = rb[b][w]; ql[w] = rb[b][4 + w]; }
+            else if (EB == 2) q[w] = rb[b][w];
             else {
               const float v0 = __builtin_bit_cast(float, rb[b][2 * w]), v1 = __builtin_bit_cast(float, rb[b][2 * w + 1]);
               q[w] = dw_pack2(v0, v1);
@@ -249,6 +306,7 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
         for (int a = 0; a < MT; ++a)
 #pragma unroll
           for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        mid();
         if (X3) {                                    // the two cross terms as passes of their own: an accumulator tile is revisited
                                                      // MT x NT MFMAs later, never by the next instruction
 #pragma unroll
@@ -260,11 +318,18 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
 #pragma unroll
             for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfl[b], acc[a][b], 0, 0, 0);
         }
-      }
-      if (c < n_chunks) {                          // gathers of chunk c: lane (i, h) takes rows 8h .. 8h+7 of its feature
+    };
+    auto gather_a = [&](char* bc, auto& ra) __attribute__((always_inline)) {     // lane (i, h) takes rows 8h .. 8h+7 of its feature
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
-          if (EA == 2) {                             // two transpose reads: points 8h .. 8h+3 and 8h+4 .. 8h+7 of this lane's feature
+          if (SA) {                                  // hi: two transpose reads as for a bf16 tile; lo: the same 8-byte groups of the neighbouring piece
+            const dw_i16x4 h0 = tr_read(bc + ta[a]), h1 = tr_read(bc + ta[a] + 4 * WA * 4);
+            const dw_i16x4 l0 = tr_read(bc + (ta[a] ^ 16u)), l1 = tr_read(bc + (ta[a] ^ 16u) + 4 * WA * 4);
+            const dw_u32x4 uh = __builtin_bit_cast(dw_u32x4, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+            const dw_u32x4 ul = __builtin_bit_cast(dw_u32x4, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { ra[a][w] = uh[w]; ra[a][4 + w] = ul[w]; }
+          } else if (EA == 2) {                      // two transpose reads: points 8h .. 8h+3 and 8h+4 .. 8h+7 of this lane's feature
             const dw_i16x4 lo = tr_read(bc + ta[a]), hi = tr_read(bc + ta[a] + 4 * WA * EA);
             const dw_i16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             const dw_u32x4 u = __builtin_bit_cast(dw_u32x4, v);
@@ -275,9 +340,18 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
             for (int jj = 0; jj < 8; ++jj) ra[a][jj] = reinterpret_cast<const unsigned*>(bc)[(8 * h + jj) * WA + m0 + i + 32 * a];
           }
         }
+    };
+    auto gather_b = [&](char* bc, auto& rb) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
-          if (EB == 2) {
+          if (SB) {
+            const dw_i16x4 h0 = tr_read(bc + tb[b]), h1 = tr_read(bc + tb[b] + 4 * WB * 4);
+            const dw_i16x4 l0 = tr_read(bc + (tb[b] ^ 16u)), l1 = tr_read(bc + (tb[b] ^ 16u) + 4 * WB * 4);
+            const dw_u32x4 uh = __builtin_bit_cast(dw_u32x4, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+            const dw_u32x4 ul = __builtin_bit_cast(dw_u32x4, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { rb[b][w] = uh[w]; rb[b][4 + w] = ul[w]; }
+          } else if (EB == 2) {
             const dw_i16x4 lo = tr_read(bc + tb[b]), hi = tr_read(bc + tb[b] + 4 * WB * EB);
             const dw_i16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             const dw_u32x4 u = __builtin_bit_cast(dw_u32x4, v);
@@ -288,6 +362,56 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
             for (int jj = 0; jj < 8; ++jj) rb[b][jj] = reinterpret_cast<const unsigned*>(bc + A_BYTES)[(8 * h + jj) * WB + n0 + i + 32 * b];
           }
         }
+    };
+    int slot_c = 0;                                  // = c % NBUF (NBUF need not be a power of two)
+    if constexpr (!X3) {
+      for (int c = 0; c <= n_chunks; ++c, slot_c = (slot_c + 1 == NBUF) ? 0 : slot_c + 1) {
+        if (c < n_chunks && c % SY == 0) sync_point(c, slot_c);
+        if (c > 0) compute(ra0, rb0, [] {});         // chunk c-1
+        if (c < n_chunks) { gather_a(smem + slot_c * BUF, ra0); gather_b(smem + slot_c * BUF, rb0); }
+      }
+    } else {
+      // bf16x3: with split tiles a chunk is 32 transpose reads and 48 MFMAs and nothing else -- the reads of chunk c go out IN FRONT of
+      // the MFMAs of chunk c-1 (two register sets, the loop unrolled by two), so their latency hides behind 1.5 k cycles of MFMA work
+      // instead of behind the next sync point.  No control flow inside the loop that touches the accumulators (hipcc answers a
+      // conditional compute with ~70 v_accvgpr_mov per iteration): step c = sync point, gathers of chunk c, MFMAs of chunk c-1 for
+      // c = 1 .. n_chunks -- the gathers of "chunk n_chunks" read a staged clamp copy nobody consumes -- an odd step count is evened
+      // out by one peeled step in front.
+      // The reads are pinned by scheduling fences -- hipcc otherwise sinks them to their uses a step later (register pressure) and
+      // waits for each with lgkmcnt(0) -- in two halves, the second between the MFMA passes: a counted LDS wait cannot leave more
+      // than 15 reads outstanding.
+      auto step = [&](int c, auto& ga, auto& gb, auto& ca, auto& cb) __attribute__((always_inline)) {
+        if (c % SY == 0) sync_point(c, slot_c);
+        char* bc = smem + slot_c * BUF;
+        gather_a(bc, ga);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(ca, cb, [&]() __attribute__((always_inline)) {           // chunk c-1
+          __builtin_amdgcn_sched_barrier(0);
+          gather_b(bc, gb);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        slot_c = (slot_c + 1 == NBUF) ? 0 : slot_c + 1;
+      };
+      sync_point(0, 0);
+      gather_a(smem, ra0);
+      gather_b(smem, rb0);
+      slot_c = 1;
+      int c = 1;
+      if (n_chunks & 1) {
+        step(1, ra1, rb1, ra0, rb0);
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int w = 0; w < RA_N; ++w) ra0[a][w] = ra1[a][w];
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int w = 0; w < RB_N; ++w) rb0[b][w] = rb1[b][w];
+        c = 2;
+      }
+      for (; c < n_chunks; c += 2) {
+        step(c, ra1, rb1, ra0, rb0);
+        step(c + 1, ra0, rb0, ra1, rb1);
       }
     }
   } else {
@@ -348,9 +472,12 @@ SN_DEV void run_task(const Task& t, char* smem, int tid) {
   }
 }
 
+constexpr int DW_KERNEL_LDS_BYTES = 163840;     // the launch asks for the whole 160 KB; the bf16x3 modes use it (a 5th chunk in flight), the others 128 KB
 __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks, const Plan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Task t = tasks != nullptr ? tasks[blockIdx.x] : task_of(plan, (int)blockIdx.x);
+  // (bf16x3 plans run several workgroups per CU in turn: last problems first -- the narrow ones, whose tasks are the longest)
+  const int wg = (tasks == nullptr && (plan.p[0].variant & 0x400)) ? plan.n_tasks - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const Task t = tasks != nullptr ? tasks[blockIdx.x] : task_of(plan, wg);
   const int tid = threadIdx.x;
   if (t.variant & 0x100) {
     const int mode = (t.variant & 0x400) ? 4 : (t.variant & 0x200) ? 2 : 1;     // 0x200: G and the activations are stored as bf16; 0x400: bf16x3 on fp32 state
@@ -364,7 +491,17 @@ __global__ void __launch_bounds__(256) dw_kernel(const Task* __restrict__ tasks,
       default: run_task<1, 1, 1, 4, MODE_>(t, smem, tid); break;        \
     }
     // variants 1 / 3 contract with the embedded inputs, which stay fp32 in every mode
-    if (mode == 1) { SN_DW_CASES(1, 1) } else if (mode == 4) { SN_DW_CASES(4, 4) } else { SN_DW_CASES(2, 3) }
+    if (mode == 1) { SN_DW_CASES(1, 1) } else if (mode == 4) {
+      // bf16x3: G slots 0..8 and acts slots 0..8 are split tiles, slot 9 (dir_encoding's 128 columns + the head block, h2) and emb are fp32
+      switch (t.variant & 0xff) {
+        case 0: run_task<4, 4, 2, 2, 5, DW_KERNEL_LDS_BYTES>(t, smem, tid); break;         // G[l] x acts[l-1]   (5 chunks of 32 KB)
+        case 1: run_task<4, 1, 2, 2, 6, DW_KERNEL_LDS_BYTES>(t, smem, tid); break;         // G[0], G[4] x emb
+        case 2: run_task<2, 4, 2, 2, 7, DW_KERNEL_LDS_BYTES>(t, smem, tid); break;         // G[9][:, :128] x acts[8]
+        case 3: run_task<2, 1, 2, 2, 4, DW_KERNEL_LDS_BYTES>(t, smem, tid); break;         // G[9][:, :128] x emb
+        case 4: run_task<1, 2, 1, 4, 7, DW_KERNEL_LDS_BYTES>(t, smem, tid); break;         // head block x acts[7]
+        default: run_task<1, 1, 1, 4, 4, DW_KERNEL_LDS_BYTES>(t, smem, tid); break;        // head block x acts[9]
+      }
+    } else { SN_DW_CASES(2, 3) }
 #undef SN_DW_CASES
     return;
   }
@@ -484,7 +621,7 @@ static const int COST_BF16[8] = {512, 189, 226, 126, 138, 125, 0, 0};          /
 // bf16x3 on the fp32 state (run_task MODE 4): instruction-issue-bound -- the cost of a point follows the tiles a wave splits and its
 // MFMAs, not the bytes (tools/dw_x3_time.py: each variant's tasks alone; with the bf16 table above the 128 x 256 problem's 11
 // workgroups ran 3.07 ms while the 208 of the eight 256 x 256 problems were done after 2.34)
-static const int COST_X3[8] = {512, 217, 284, 136, 148, 99, 0, 0};
+static const int COST_X3[8] = {512, 182, 231, 162, 123, 117, 0, 0};
 // bf16 operands, bf16 state (transpose-read fragments, a sync point every 2nd / 4th chunk): the 256x256 problems run at their
 // share of the HBM rate (52 ns per point per CU = 1 KB / 19.7 GB/s), the narrower ones at 19..35 ns per point
 #ifndef SN_DW_COST_STATE
@@ -493,6 +630,9 @@ static const int COST_X3[8] = {512, 217, 284, 136, 148, 99, 0, 0};
 #endif
 static const int COST_BF16_STATE[8] = {SN_DW_COST_STATE};
 constexpr int TARGET_WGS = 256;                 // one workgroup per CU
+#ifndef SN_DW_X3_WAVES_OF_WGS
+#define SN_DW_X3_WAVES_OF_WGS 4                 // bf16x3: several workgroups per CU IN TURN (160 KB of LDS each): the tail of an imperfect K-split is one short task
+#endif
 
 struct HostPlan {
   Plan plan;                                    // all problems (task numbering of the single-launch modes)
@@ -560,7 +700,8 @@ static void build_plan(HostPlan& hp, const char* acts, const char* emb, const ch
     if (tot == 0) continue;
     // (the bf16-state narrow problems run two workgroups per CU: dw_narrow_bf16_kernel)
     const int target = (gsel == 1 && dtype == 2 && SN_DW_NARROW_2WG) ? SN_DW_NARROW_WGS * TARGET_WGS
-                       : (gsel == 1 && dtype == 0 && SN_DW_NARROW_F32_2WG) ? 2 * TARGET_WGS : TARGET_WGS;
+                       : (gsel == 1 && dtype == 0 && SN_DW_NARROW_F32_2WG) ? 2 * TARGET_WGS
+                       : dtype == 3 ? SN_DW_X3_WAVES_OF_WGS * TARGET_WGS : TARGET_WGS;
     double frac[MAX_PROBS];
     int sum = 0;
     for (int i = 0; i < n; ++i) {
@@ -640,7 +781,7 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
     hp.plan.p[i].c = (float*)(ws + hp.c_off[i]);
     hp.plan.p[i].bias = hp.b_off[i] >= 0 ? (float*)(ws + hp.b_off[i]) : nullptr;
   }
-  SN_ENSURE_DYN_LDS(dw_kernel, DW_LDS_BYTES);
+  SN_ENSURE_DYN_LDS(dw_kernel, DW_KERNEL_LDS_BYTES);
   int rc;
   if (hp.two_launches) {
     const Plan pa = group_plan(hp, 0), pb = group_plan(hp, 1);
@@ -656,10 +797,10 @@ extern "C" int sn_weight_grads_launch(const void* acts, const float* emb, const 
       SN_ENSURE_DYN_LDS(dw_narrow_f32_kernel, DW_NARROW_F32_LDS_BYTES);
       hipLaunchKernelGGL(dw_narrow_f32_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_NARROW_F32_LDS_BYTES, stream, pb);
     } else {
-      hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, pb);
+      hipLaunchKernelGGL(dw_kernel, dim3((unsigned)pb.n_tasks), dim3(256), DW_KERNEL_LDS_BYTES, stream, (const Task*)nullptr, pb);
     }
   } else {
-    hipLaunchKernelGGL(dw_kernel, dim3((unsigned)hp.plan.n_tasks), dim3(256), DW_LDS_BYTES, stream, (const Task*)nullptr, hp.plan);
+    hipLaunchKernelGGL(dw_kernel, dim3((unsigned)hp.plan.n_tasks), dim3(256), DW_KERNEL_LDS_BYTES, stream, (const Task*)nullptr, hp.plan);
   }
   rc = (int)hipGetLastError();
   if (rc) return rc;
@@ -704,10 +845,10 @@ extern "C" int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream) 
   using namespace snd;
   if (n_tasks <= 0) return 0;
   static_assert(sizeof(Task) == 64, "Task must be 64 bytes (host packs it as 8 x int64)");
-  SN_ENSURE_DYN_LDS(dw_kernel, DW_LDS_BYTES);
+  SN_ENSURE_DYN_LDS(dw_kernel, DW_KERNEL_LDS_BYTES);
   Plan none;
   none.n_probs = 0; none.n_tasks = 0; none.P = 0;
-  hipLaunchKernelGGL(dw_kernel, dim3((unsigned)n_tasks), dim3(256), DW_LDS_BYTES, stream,
+  hipLaunchKernelGGL(dw_kernel, dim3((unsigned)n_tasks), dim3(256), DW_KERNEL_LDS_BYTES, stream,
                      reinterpret_cast<const Task*>(tasks), none);
   return (int)hipGetLastError();
 }

@@ -32,6 +32,11 @@ namespace snl {
 // product  W.x ~= Wh.xh + Wl.xh + Wh.xl  on the bf16 MFMA at fp32-level accuracy.  Slabs are K x 128 B like the fp32 ones:
 //   bf16x3: [K/16 k-steps][hi, lo][64 lanes][8] bf16    (two ds_read_b128 feed three MFMAs)
 enum { DT_F32 = 0, DT_BF16 = 1, DT_BF16X3 = 3 };
+// "x3 state" -- the training state of the bf16x3 kernels (acts / G, slots 0..8; slot 9 and emb stay fp32): a row of 256 features is
+// 1 KB like an fp32 row, but holds every value as its (hi, lo) bf16 pair: per 8 consecutive features 16 B of hi parts, then 16 B of
+// lo parts.  The forward / chain epilogues have the pairs in registers anyway (they are the next layer's B operand); the
+// weight-gradient kernel (sn_dw.hip, modes 5..7) stages the rows by DMA with the swizzle of RowStager<.., SPLIT> and takes MFMA
+// fragments by ds_read_b64_tr_b16 -- no conversion anywhere.  tests/helpers.py x3_state_decode / _encode restate it in numpy.
 
 // ---- network constants (padded K per layer kind)
 constexpr int W_HID = 256;

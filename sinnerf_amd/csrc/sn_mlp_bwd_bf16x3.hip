@@ -87,6 +87,7 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
   a0 = load_bias(lds_zero, 0, h);
   const char* const xp = smem + BX3_TAIL_BYTES + 3 * BX3_SLOT + wave * XPOSE_WAVE_BYTES;
   const unsigned xp_w_lds = (unsigned)(BX3_TAIL_BYTES + 3 * BX3_SLOT + wave * XPOSE_WAVE_BYTES) + (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
+  const unsigned xp_s_lds = xp_w_lds - 8u * (unsigned)h;           // split-state tiles (slots 0..8): 8 B of hi parts per lane, lo parts 16 B on
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
   const unsigned s_off = (unsigned)((lane >> 4) * 1024 + (lane & 15) * 16);    // this lane's sign words inside a layer's four rows
@@ -133,7 +134,11 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
     };
     sw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sign_base(7) + s_off));      // xyz_encoding_8's (the first masked layer)
     swn = sw;
-    auto stage = [&](int qq, const float (&v)[4]) __attribute__((always_inline)) { x3_lds_write_b128(xp_w_lds, 32 * qq, v); };
+    auto stage = [&](int qq, const float (&v)[4]) __attribute__((always_inline)) { x3_lds_write_b128(xp_w_lds, 32 * qq, v); };   // fp32 (slot 9)
+    // slots 0..8: the (hi, lo) pairs the epilogue builds for the next transposed layer ARE the stored gradient state
+    auto stage_split = [&](int qq, uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1) __attribute__((always_inline)) {
+      x3_lds_write_split(xp_s_lds, 32 * qq, h0, h1, l0, l1);
+    };
     f32x4 rowbuf[1];                                         // row groups between their ds_read and their store (x3_store_step)
     auto rows_read = [&](int i) __attribute__((always_inline)) {
       rowbuf[0] = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
@@ -189,8 +194,9 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = ra[2 * q + i] + rb[2 * q + i];
-        x3_put(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), x);
-        stage(q >> 1, x);
+        uint32_t h0, h1, l0, l1;
+        x3_put(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), x, h0, h1, l0, l1);
+        stage_split(q >> 1, h0, h1, l0, l1);
       }
     };
     // g_y = g_h [h > 0]; with_sigma: g_h8 also gets the sigma head's term  sigma.weight[f] g_sigma  (nerf.py:136)
@@ -207,8 +213,9 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
           if (SIG) x[i] = __builtin_fmaf(lds_aux[snl::BB_AUX_SIGT + h * 128 + 16 * t + 2 * q + i], gsig, x[i]);
         }
         float v[4];
-        x3_put_signed(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), x, word, q + 8 * (t & 1), v);
-        stage(q >> 1, v);
+        uint32_t h0, h1, l0, l1;
+        x3_put_signed(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), x, word, q + 8 * (t & 1), v, h0, h1, l0, l1);
+        stage_split(q >> 1, h0, h1, l0, l1);
       }
     };
     auto mask_tile = [&](auto wset, int t, const f32x16& ra, const f32x16& rb, int blk) __attribute__((always_inline)) {

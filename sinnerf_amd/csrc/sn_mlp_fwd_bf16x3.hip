@@ -82,6 +82,7 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
   // training forward: per-wave staging tile of the activation stores (sn_mlp_pipe.h XPOSE_*)
   const char* const xp = smem + X3_LDS_BYTES + wave * XPOSE_WAVE_BYTES;
   const unsigned xp_w_lds = (unsigned)(X3_LDS_BYTES + wave * XPOSE_WAVE_BYTES) + (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
+  const unsigned xp_s_lds = xp_w_lds - 8u * (unsigned)h;           // ... of the split-state tiles: 8 B of hi parts per lane, lo parts 16 B on
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;    // row lane>>3, 16-byte chunk lane&7
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
 
@@ -127,8 +128,12 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     int cur_slot = 0;
     // training forward: the four fp32 values of accumulator registers 4qq..4qq+3 go to the wave's staging tile; store_rows(i) writes
     // row group i (8 points x 128 B) of the staged 32-point x 32-feature tile to acts[slot][point][32t..32t+31], non-temporal
-    auto stage = [&](int qq, const float (&v)[4]) __attribute__((always_inline)) {
+    auto stage = [&](int qq, const float (&v)[4]) __attribute__((always_inline)) {           // fp32 tile (slot 9)
       if (STORE) x3_lds_write_b128(xp_w_lds, 32 * qq, v);
+    };
+    // slots 0..8: the (hi, lo) pairs the epilogue has just built for the next layer ARE the stored state (sn_layout.h "x3 state")
+    auto stage_split = [&](int qq, uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1) __attribute__((always_inline)) {
+      if (STORE) x3_lds_write_split(xp_s_lds, 32 * qq, h0, h1, l0, l1);
     };
     f32x4 rowbuf[1];                                         // row groups between their ds_read and their store (x3_store_step)
     auto rows_read = [&](int i) __attribute__((always_inline)) {
@@ -178,9 +183,9 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
-        uint32_t h0, h1;
-        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1);
-        stage(q >> 1, v);
+        uint32_t h0, h1, l0, l1;
+        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1, l0, l1);
+        stage_split(q >> 1, h0, h1, l0, l1);
         sign_pair(t, q, h0, h1);
       }
       if (blk == 3) sign_tile_done(t);
@@ -194,14 +199,14 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
-        uint32_t h0, h1;
-        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1);
+        uint32_t h0, h1, l0, l1;
+        x3_epi<true>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1, l0, l1);
         sign_pair(t, q, h0, h1);
         sg = __builtin_fmaf(w[0], v[0], sg);                 // sigma head on the fp32 ReLU outputs (nerf.py:136)
         sg = __builtin_fmaf(w[1], v[1], sg);
         sg = __builtin_fmaf(w[2], v[2], sg);
         sg = __builtin_fmaf(w[3], v[3], sg);
-        stage(q >> 1, v);
+        stage_split(q >> 1, h0, h1, l0, l1);
       }
       if (blk == 3) sign_tile_done(t);
     };
@@ -212,8 +217,9 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
         const float a[4] = {ra[2 * q], ra[2 * q + 1], ra[2 * q + 2], ra[2 * q + 3]};
         const float b[4] = {rb[2 * q], rb[2 * q + 1], rb[2 * q + 2], rb[2 * q + 3]};
         float v[4];
-        x3_epi<false>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v);
-        stage(q >> 1, v);
+        uint32_t h0, h1, l0, l1;
+        x3_epi<false>(x3_reg(W, 0, 2 * t + (q >> 2)) + (q & 3), x3_reg(W, 1, 2 * t + (q >> 2)) + (q & 3), a, b, v, h0, h1, l0, l1);
+        stage_split(q >> 1, h0, h1, l0, l1);
       }
     };
 #define SNX_LW_CUR (ring.slot(cslot) + lane * 16)

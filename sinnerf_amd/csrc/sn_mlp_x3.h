@@ -58,8 +58,8 @@ SN_DEV void x3_split8(const float* f, u32x4& hi, u32x4& lo) {
 // Epilogue block: accumulator registers 4i..4i+3 of both chains -> v = act(A + B) (RELU: max with 0), its hi / lo pairs into
 // a[rh], a[rh+1] / a[rl], a[rl+1].  One volatile asm: program order relative to the MFMA asm is what keeps the hazard distances.
 template <bool RELU>
-SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], float (&v)[4], uint32_t& h0, uint32_t& h1) {
-  uint32_t l0, l1;
+SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], float (&v)[4], uint32_t& h0, uint32_t& h1, uint32_t& l0,
+                   uint32_t& l1) {
   float r0, r1, r2, r3;
   if (RELU)
     asm volatile("v_add_f32 %0, %12, %16\n\tv_add_f32 %1, %13, %17\n\tv_add_f32 %2, %14, %18\n\tv_add_f32 %3, %15, %19\n\t"
@@ -90,8 +90,8 @@ SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], flo
 
 template <bool RELU>
 SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], float (&v)[4]) {
-  uint32_t h0, h1;
-  x3_epi<RELU>(rh, rl, a, b, v, h0, h1);
+  uint32_t h0, h1, l0, l1;
+  x3_epi<RELU>(rh, rl, a, b, v, h0, h1, l0, l1);
 }
 // ReLU sign bits of a packed pair of post-ReLU bf16 values (>= 0: "positive" is "bits != 0") into a per-lane word: bit k <- the low
 // value, bit 16 + k <- the high value.  c01 = 0x00010001 in a register (VOP3P takes no literal).  The training forward leaves one word
@@ -102,8 +102,8 @@ SN_DEV void x3_sign_bits(uint32_t& word, uint32_t pk, int k, uint32_t c01) {
   asm("v_pk_min_u16 %0, %2, %3\n\tv_lshl_or_b32 %1, %0, %4, %1" : "=&v"(m), "+v"(word) : "v"(pk), "v"(c01), "n"(k));
 }
 // ... and the chain's use of them: v = (bit ? x : 0) for the four values of a block (pairs d, d + 1 of tile parity par), then as x3_put
-SN_DEV void x3_put_signed(int rh, int rl, const float (&x)[4], uint32_t word, int k, float (&v)[4]) {
-  uint32_t h0, h1, l0, l1;
+SN_DEV void x3_put_signed(int rh, int rl, const float (&x)[4], uint32_t word, int k, float (&v)[4], uint32_t& h0, uint32_t& h1,
+                          uint32_t& l0, uint32_t& l1) {
   float r0, r1, r2, r3;
   asm volatile("v_bfe_i32 %4, %16, %17, 1\n\tv_bfe_i32 %5, %16, %18, 1\n\tv_bfe_i32 %6, %16, %19, 1\n\tv_bfe_i32 %7, %16, %20, 1\n\t"
                "v_and_b32 %8, %4, %12\n\tv_and_b32 %9, %5, %13\n\tv_and_b32 %10, %6, %14\n\tv_and_b32 %11, %7, %15\n\t"
@@ -230,9 +230,16 @@ SN_DEV void x3_lds_write_b128(unsigned lds, int off, const float (&v)[4]) {
 }
 
 
+// ... of the (hi, lo) pairs of four consecutive features of one point in the SPLIT state layout (sn_layout.h "x3 state": per 8 features
+// 16 B of hi parts, then 16 B of lo parts): lds = the lane's staging address  row + 8 (lane >> 5), off = 32 x block
+SN_DEV void x3_lds_write_split(unsigned lds, int off, uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1) {
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const u32x2_ hh = {h0, h1}, ll = {l0, l1};
+  asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4" :: "v"(lds), "v"(hh), "v"(ll), "n"(off), "n"(off + 16) : "memory");
+}
+
 // four fp32 values -> their (hi, lo) bf16 pairs in a[rh], a[rh+1] / a[rl], a[rl+1] (no activation: values computed on the VALU)
-SN_DEV void x3_put(int rh, int rl, const float (&x)[4]) {
-  uint32_t h0, h1, l0, l1;
+SN_DEV void x3_put(int rh, int rl, const float (&x)[4], uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
   float r0, r1, r2, r3;
   asm volatile("v_cvt_pk_bf16_f32 %0, %8, %9\n\tv_cvt_pk_bf16_f32 %1, %10, %11\n\t"
                "v_lshlrev_b32 %4, 16, %0\n\tv_and_b32 %5, 0xffff0000, %0\n\tv_lshlrev_b32 %6, 16, %1\n\tv_and_b32 %7, 0xffff0000, %1\n\t"
@@ -242,6 +249,10 @@ SN_DEV void x3_put(int rh, int rl, const float (&x)[4]) {
                "v_accvgpr_write_b32 a[%14], %2\n\tv_accvgpr_write_b32 a[%15], %3"
                : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
                : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
+}
+SN_DEV void x3_put(int rh, int rl, const float (&x)[4]) {
+  uint32_t h0, h1, l0, l1;
+  x3_put(rh, rl, x, h0, h1, l0, l1);
 }
 // ... masked by the forward activations (backward of ReLU, nerf.py:73): v = a > 0 ? x : 0, then as x3_put
 SN_DEV void x3_put_masked(int rh, int rl, const float (&x)[4], const f32x4& a, float (&v)[4]) {

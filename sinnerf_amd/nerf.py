@@ -19,7 +19,7 @@ from . import _lib
 _DTYPES = {"fp32": _lib.SN_DTYPE_F32, "float32": _lib.SN_DTYPE_F32, torch.float32: _lib.SN_DTYPE_F32,
            "bf16": _lib.SN_DTYPE_BF16, "bfloat16": _lib.SN_DTYPE_BF16, torch.bfloat16: _lib.SN_DTYPE_BF16,
            # fp32-level accuracy on the bf16 matrix cores (3-term hi/lo split, csrc/sn_mlp_{fwd,bwd}_bf16x3.hip): inference, and
-           # under autograd the forward and the backward chain over the FP32 training state (weight gradients: the fp32 contractions)
+           # under autograd the forward, the backward chain and the weight gradients (training state: (hi, lo) bf16 pairs in fp32-sized buffers)
            "bf16x3": _lib.SN_DTYPE_BF16X3}
 
 

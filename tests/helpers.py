@@ -153,3 +153,32 @@ def dw_tasks(acts, emb, G, bf16=False):
                          (bpart.data_ptr() + j * M * 4) if want_b else 0,
                          j * per, min(P, (j + 1) * per), lda | (ldb << 32), N | ((var | flags) << 32)))
     return rows, outs
+
+
+# ---- bf16x3 training state (include/sinnerf_hip.h SN_DTYPE_BF16X3, csrc/sn_layout.h "x3 state") --------------------------------
+# Slots 0..8 of `acts` / `G` hold every value as the (hi, lo) bf16 pair the kernels compute with: per 8 features 16 B of hi parts, then
+# 16 B of lo parts (a row of 256 features is 1 KB like an fp32 row).  Slot 9 stays fp32.
+def x3_state_decode(a):
+    """(..., 256) float32 array holding split rows -> the fp32 values hi + lo"""
+    u = np.ascontiguousarray(a).view(np.uint16).reshape(a.shape[:-1] + (32, 2, 8)).astype(np.uint32) << 16
+    f = u.view(np.float32)
+    return (f[..., 0, :] + f[..., 1, :]).reshape(a.shape)
+
+
+def x3_state_encode(x):
+    """fp32 values (..., 256) -> split rows (as float32 bit patterns): hi = RNE bf16(x), lo = RNE bf16(x - hi)"""
+    def bf16_bits(v):
+        b = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        return (((b + 0x7FFF + ((b >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi = bf16_bits(x)
+    lo = bf16_bits(x - (hi.astype(np.uint32) << 16).view(np.float32))
+    out = np.stack([hi.reshape(x.shape[:-1] + (32, 8)), lo.reshape(x.shape[:-1] + (32, 8))], axis=-2)
+    return np.ascontiguousarray(out).reshape(x.shape[:-1] + (512,)).view(np.float32)
+
+
+def x3_state_to_fp32(state):
+    """(10, rows, 256) bf16x3 state -> the fp32 state an SN_DTYPE_F32 kernel reads (slots 0..8 decoded, slot 9 as is)"""
+    out = np.array(state, copy=True)
+    out[:9] = x3_state_decode(state[:9])
+    return out

@@ -9,7 +9,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from oracle import oracle_np as O                                                                     # noqa: E402
-from tests.helpers import GOLDEN, RENDER_CASES, check_render, load_case                               # noqa: E402
+from tests.helpers import GOLDEN, RENDER_CASES, check_render, load_case, x3_state_to_fp32                               # noqa: E402
 from tests.test_parity_gpu import dev, embeddings, injected_rng, make_model, rng_order, to_np         # noqa: E402
 
 DT = "bf16x3"
@@ -135,8 +135,9 @@ def test_bf16x3_classic_heads():
 @pytest.mark.parametrize("n_rays,S", [(60, 37), (512, 128)])
 def test_bf16x3_training_forward_writes_the_fp32_state(n_rays, S):
     """sn_mlp_forward_train(SN_DTYPE_BF16X3) through the C ABI against sn_mlp_forward_train(SN_DTYPE_F32): output, all ten
-    activation slots and the embedded inputs agree at fp32 rounding level (the state the fp32 backward consumes); the training
-    forward equals the inference forward of the same arithmetic bit for bit.  2220 points = a ragged last tile."""
+    activation slots -- slots 0..8 stored as the (hi, lo) pairs the kernel computes with (tests/helpers.py x3_state_decode), slot 9
+    fp32 -- and the embedded inputs agree at fp32 rounding level; the training forward equals the inference forward of the same
+    arithmetic bit for bit.  2220 points = a ragged last tile."""
     from sinnerf_amd import _lib, rendering
     rays = O.lego_rays(400, 400, seed=0)[:: max(1, 160000 // n_rays)][:n_rays]
     z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n_rays, S)).astype(np.float32))
@@ -159,6 +160,7 @@ def test_bf16x3_training_forward_writes_the_fp32_state(n_rays, S):
         state[dt] = (out.cpu().numpy(), acts.cpu().numpy(), emb.cpu().numpy())
     o32, a32, e32 = state["fp32"]
     o3, a3, e3 = state[DT]
+    a3 = x3_state_to_fp32(a3)
     assert np.array_equal(e3[:, :63], e32[:, :63]) and np.array_equal(e3[:, 64:91], e32[:, 64:91])      # the same exact embedding
     for slot in range(10):
         w = 128 if slot == 9 else 256
@@ -175,8 +177,9 @@ def test_bf16x3_training_forward_writes_the_fp32_state(n_rays, S):
 @pytest.mark.parametrize("n_rays,S", [(60, 37), (512, 128)])
 def test_bf16x3_backward_chain_writes_the_fp32_gradient_state(n_rays, S):
     """sn_mlp_backward_chain(SN_DTYPE_BF16X3) against sn_mlp_backward_chain(SN_DTYPE_F32) on the SAME training state -- the one the
-    bf16x3 forward wrote: fp32 activations (the fp32 chain's masks) AND the ReLU sign words in the unused half of slot 9 (the bf16x3
-    chain's masks), so both chains see the same masks: every G slot and the head block agree at fp32 rounding level, g_out bit for bit"""
+    bf16x3 forward wrote, decoded to fp32 for the fp32 chain (its masks: activations > 0); the bf16x3 chain's masks are the ReLU sign
+    words in the unused half of slot 9, checked here against those activations bit by bit, so both chains see the same masks: every G
+    slot (slots 0..8 decoded from their (hi, lo) pairs) and the head block agree at fp32 rounding level, g_out bit for bit"""
     from sinnerf_amd import _lib
     rays = O.lego_rays(400, 400, seed=0)[:: max(1, 160000 // n_rays)][:n_rays]
     z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n_rays, S)).astype(np.float32))
@@ -191,7 +194,8 @@ def test_bf16x3_backward_chain_writes_the_fp32_gradient_state(n_rays, S):
     _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m3.packed()), m3.kernel_dtype(_lib.SN_DTYPE_BF16X3), _lib.ptr(rays_t), _lib.ptr(z_t),
                                              n_rays, S, _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()), "fwd")
     # the sign words are what the activations say: bit (pair d, tile parity) of lane (j, h) <-> [h_l[point j][32 t + feature] > 0]
-    a = acts.cpu().numpy()
+    a = x3_state_to_fp32(acts.cpu().numpy())
+    acts32 = torch.from_numpy(a).to(dev())                                  # the same state as an SN_DTYPE_F32 kernel reads it
     words = a[9].view(np.uint32)[:, 128:192]                               # (rows, 64): per wave 32 rows = 8 layers x 4 rows x 16 lanes x 4 words
     for wave0 in (0, 32 * ((P - 1) // 32)):                                 # first and last (ragged) wave tile
         for l in (0, 3, 7):
@@ -211,12 +215,13 @@ def test_bf16x3_backward_chain_writes_the_fp32_gradient_state(n_rays, S):
         G = torch.full((10, rows, 256), float("nan"), device=dev())
         G[:, P:].zero_()
         g_o = torch.zeros((P, 4), device=dev())
-        _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(dt)), model.kernel_dtype(code), _lib.ptr(acts), _lib.ptr(out),
-                                                  _lib.ptr(g_raw), P, rows, _lib.ptr(G), _lib.ptr(g_o), _lib.stream_ptr()), "chain " + dt)
+        _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(model.packed_bwd(dt)), model.kernel_dtype(code), _lib.ptr(acts32 if dt == "fp32" else acts),
+                                                  _lib.ptr(out), _lib.ptr(g_raw), P, rows, _lib.ptr(G), _lib.ptr(g_o), _lib.stream_ptr()), "chain " + dt)
         torch.cuda.synchronize()
         res[dt] = (G.cpu().numpy(), g_o.cpu().numpy())
     G32, o32 = res["fp32"]
     G3, o3 = res[DT]
+    G3 = x3_state_to_fp32(G3)
     assert np.array_equal(o3, o32)
     worst = 0.0
     for slot in range(10):
@@ -231,8 +236,10 @@ def test_bf16x3_backward_chain_writes_the_fp32_gradient_state(n_rays, S):
 
 
 def test_bf16x3_weight_gradients_equal_the_fp32_contractions():
-    """sn_weight_grads(SN_DTYPE_BF16X3) against sn_weight_grads(SN_DTYPE_F32) on the SAME fp32 training state (acts, emb, G): all 24
-    parameter gradients within 2e-5 norm-wise (dW = G^T X over all points as Gh.Xh + Gl.Xh + Gh.Xl on the bf16 MFMA, fp32 column sums)"""
+    """sn_weight_grads(SN_DTYPE_BF16X3) against sn_weight_grads(SN_DTYPE_F32) on the SAME training state (acts, emb, G: written by the
+    bf16x3 forward and chain, decoded to fp32 for the fp32 kernels): all 24 parameter gradients within 2e-5 norm-wise (dW = G^T X over
+    all points as Gh.Xh + Gl.Xh + Gh.Xl on the bf16 MFMA -- slots 0..8 arrive as the (hi, lo) pairs, slot 9 and emb are split in
+    registers -- with fp32 column sums)"""
     import ctypes
     from sinnerf_amd import _lib
     n_rays, S = 700, 64
@@ -253,11 +260,15 @@ def test_bf16x3_weight_gradients_equal_the_fp32_contractions():
     _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m3.packed_bwd(DT)), m3.kernel_dtype(_lib.SN_DTYPE_BF16X3), _lib.ptr(acts), _lib.ptr(out),
                                               _lib.ptr(g_raw), P, rows, _lib.ptr(G), _lib.ptr(g_o), _lib.stream_ptr()), "chain")
     grads = {}
+    acts32 = torch.from_numpy(x3_state_to_fp32(acts.cpu().numpy())).to(dev())
+    G32 = torch.from_numpy(x3_state_to_fp32(G.cpu().numpy())).to(dev())
     for code in (_lib.SN_DTYPE_F32, _lib.SN_DTYPE_BF16X3):
         ws = torch.empty(int(_lib.lib.sn_weight_grads_workspace_bytes(rows, code)), dtype=torch.uint8, device=dev())
         outs = [torch.full_like(t, float("nan")) for t in m3.raw_tensors()]
         arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[o.data_ptr() for o in outs])
-        _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(emb), _lib.ptr(G), rows, code, _lib.ptr(ws), arr, 0, _lib.stream_ptr()), "dw")
+        f32 = code == _lib.SN_DTYPE_F32
+        _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts32 if f32 else acts), _lib.ptr(emb), _lib.ptr(G32 if f32 else G), rows, code, _lib.ptr(ws), arr, 0,
+                                            _lib.stream_ptr()), "dw")
         torch.cuda.synchronize()
         grads[code] = [o.double().cpu().numpy() for o in outs]
     worst = 0.0

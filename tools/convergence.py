@@ -9,7 +9,7 @@ metrics.py:14-15, as validation_step does: sinnerf.py:556-577).  Three paths fro
 the same device-RNG seed (all three consume the generator in the reference's order):
 
   bf16   sinnerf_amd, mixed precision (bf16-operand forward / chain / weight gradients over a bf16 training state)
-  bf16x3 sinnerf_amd, fp32-level accuracy on the bf16 MFMA (3-term hi/lo splits) over the fp32 training state
+  bf16x3 sinnerf_amd, fp32-level accuracy on the bf16 MFMA (3-term hi/lo splits), training state stored as the (hi, lo) pairs
   fp32   sinnerf_amd, fp32 MFMA kernels
   ref    the UNMODIFIED reference render_rays + NeRF modules (oracle/_ref) as PyTorch-ROCm eager ops on the same GPU
 

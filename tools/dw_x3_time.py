@@ -1,4 +1,5 @@
-"""per-variant cost of the bf16x3 weight-gradient contractions (run_task MODE 4 of dw_kernel, flags 0x100 | 0x400) through the raw
+"""per-variant cost of the bf16x3 weight-gradient contractions (run_task modes 4..7 of dw_kernel, flags 0x100 | 0x400; random bits
+stand in for the (hi, lo) state -- timing only) through the raw
 sn_dw_gemm entry: each variant's tasks alone -> cycles-equivalent cost per point and workgroup, normalised to variant 0 = 512
 (the K-split table COST_X3 of csrc/sn_dw.hip)."""
 import sys, numpy as np, torch

@@ -99,7 +99,7 @@ ms_chain_b, _ = timed(lambda: _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr
 ms_dw_b, _ = timed(lambda: A._weight_grads(mb[1], acts_b, emb_b, G_b, [True] * 24))
 out["bf16_training"] = {"ms_per_step": dtb * 1e3, "train_rays_per_s": N / dtb, "fine_fwd_train_ms": ms_fwd_b,
                         "fine_bwd_chain_ms": ms_chain_b, "fine_dW_ms": ms_dw_b}
-# fp32-level accuracy on the bf16 MFMA: compute_dtype="bf16x3" (3-term split forward, chain and weight gradients over the fp32 state)
+# fp32-level accuracy on the bf16 MFMA: compute_dtype="bf16x3" (3-term split forward, chain and weight gradients; the state as (hi, lo) pairs)
 mx = []
 for seed in (0, 1):
     mm = sinnerf_amd.NeRF(use_new_activation=True, compute_dtype="bf16x3")
