@@ -223,9 +223,9 @@ class TrainTrunkRun(TrunkRun):
             wave.v[35] = (w * 64 + LANE) * 16 + 3 * 4096
             wave.v[36] = 0
             wave.v[37] = 0
-            wave.v[38] = sb + LJ * 32 + 16 * (LH ^ ((LJ >> 3) & 1))
-            wave.v[39] = sb + b3 * 2304 + e * 1152 + g * 32 + 16 * hh
-            wave.v[40] = sb + b3 * 2304 + e * 1152 + g * 32 + 16 * (hh ^ 1)
+            wave.v[38] = sb + LJ * 32 + 16 * (LH ^ ((LJ >> 2) & 1))
+            wave.v[39] = sb + b3 * 2304 + e * 1152 + g * 32 + 16 * (hh ^ ((g >> 2) & 1))
+            wave.v[40] = wave.v[39]
             wave.v[41] = g * 512 + 16 * k
             wave.v[42] = LANE * 4
             wave.s[4], wave.s[5] = BLOB_BASE & 0xFFFFFFFF, BLOB_BASE >> 32
@@ -317,8 +317,8 @@ class ChainRun:
             wave.v[35] = (w * 64 + LANE) * 16 + sum(chain_slab_bytes(s) for s in range(3))
             for pt, reg in ((0, 36), (1, 37)):
                 wave.v[reg] = np.asarray(g_sigma[64 * w + 32 * pt + LJ], np.float32).view(np.uint32)
-            wave.v[38] = sb + LJ * 32 + 16 * (LH ^ ((LJ >> 3) & 1))
-            wave.v[39] = sb + b3 * 2304 + e * 1152 + g * 32 + 16 * hh
+            wave.v[38] = sb + LJ * 32 + 16 * (LH ^ ((LJ >> 2) & 1))
+            wave.v[39] = sb + b3 * 2304 + e * 1152 + g * 32 + 16 * (hh ^ ((g >> 2) & 1))
             wave.v[41] = g * 512 + 16 * k
             wave.s[4], wave.s[5] = BLOB_BASE & 0xFFFFFFFF, BLOB_BASE >> 32
             wave.s[6] = w * 1024

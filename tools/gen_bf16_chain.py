@@ -277,7 +277,7 @@ def gen(knobs):
     for dst, src in ((SGPR_G, "gplo"), (SGPR_G + 1, "gphi"), (SGPR_SIGN, "sglo"), (SGPR_SIGN + 1, "sghi")):
         g.emit("s_mov_b32 s%d, %%[%s]" % (dst, src))
         g.last_salu_write[dst] = g.n_states - 1
-    g.emit("v_xor_b32 v%d, 16, %%[str0]" % STR1)
+    g.emit("v_mov_b32 v%d, %%[str0]" % STR1)
     g.emit("v_lshrrev_b32 v%d, 2, %%[va0]" % VSG)
     if K["abl_mask"]:
         g.nop(4)                                                                  # SALU write of the sign pointer -> VMEM address

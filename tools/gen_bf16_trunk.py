@@ -54,8 +54,10 @@ KNOBS = dict(prefetch=4,        # A-fragment prefetch distance in k-steps (ring 
              dma_early=0,       # 1: a slab's DMA pieces in consecutive gaps right behind the sync point (in FRONT of the slab's row stores)
              spread=1,          # store mode: row stores dealt into the next tile's epilogue (0: burst behind the odd tile)
              abl_sign4=0,       # timing experiment (WRONG results): one dwordx4 sign store per FOUR tiles instead of a dword per tile
-             abl_vstore=1, abl_stage=1, abl_sign=1)   # store mode timing ablations (0 = leave out: WRONG results): the global stores, the
+             abl_vstore=1, abl_stage=1, abl_sign=1,   # store mode timing ablations (0 = leave out: WRONG results): the global stores, the
                                 # staging round trip (swaps + LDS writes / reads + stores), the sign-word arithmetic
+             abl_stw=1, abl_str=1)    # ... the staging ds_write_b128s alone / the staging ds_read_b128s alone (which of the two owns the
+                                # LDS bank conflicts the counters see: VERDICT r3 item 8)
 
 STORE_KNOBS = dict(store=1, cap=6.0)            # the build of sn_mlp_fwd_bf16_t.hip (csrc/Makefile passes the same)
 V_FIRST = 128                                  # first physical VGPR the statement owns (clobbers v[V_FIRST:255])
@@ -90,11 +92,14 @@ SLOTS_PER_BASE = 3                             # ds_read offsets are 16 bit: one
 # the sigma head), v232 the ReLU sign word, v233..v235 derived lane addresses; s[84:85] running pointer into acts[layer]
 # (+ slot_rows * 512 B per layer), s[86:87] pointer to the sign-word rows.
 # Staging tile of a wave (LDS, 9216 B): [point tile: 4608][b3 = tile parity: 2304][e = which of the lane's two chunks: 1152]
-# [point row j: 32 B][16 * (h ^ ((j >> 3) & 1))] -- the 16-byte chunk m = 4 b3 + 2 h + e of the 128-byte row of a tile PAIR.
-#   write (ds_write_b128, lane = point row): 16 lanes of a group hit 16 distinct 16-byte bank groups (rows j and j + 8 of a
-#   group differ in (j >> 3) & 1);  read (ds_read_b128, lane = (g, k): row 8 i + g, chunk k): (8 e + 2 g + (h ^ (i & 1))) mod 16
-#   is a bijection on every 16-lane group.  Both conflict-free (tools/gcn_sim.py counts them).  One lane-address VGPR for the
-#   writes, two for the reads (i even / odd), supplied by the kernel.
+# [point row j: 32 B][16 * (h ^ ((j >> 2) & 1))] -- the 16-byte chunk m = 4 b3 + 2 h + e of the 128-byte row of a tile PAIR.
+#   write (ds_write_b128, lane = point row): served EIGHT contiguous lanes at a time over 32 banks (128 B) -- rows j .. j+3 take the
+#   four 32-byte steps of the window, rows j+4 .. j+7 the same steps with the halves swapped: 8 distinct 16-byte slots;  read
+#   (ds_read_b128, lane = (g, k): row 8 i + g, chunk k; 16 lanes over 64 banks): (8 e + 2 g + (h ^ ((g >> 2) & 1))) mod 16 is a
+#   bijection on every lane group.  Both conflict-free in the guide's bank model (tools/gcn_sim.py counts them; the first layout
+#   swapped the halves on (j >> 3) & 1 -- conflict-free for 16-lane groups, two-way for the 8-lane groups the stores really use:
+#   profiles/r04_bf16_t_bank_conflict_by_class.txt, tools/ubench/lds_b128_banks.hip).  One lane-address VGPR for the writes, one for
+#   the reads (a second register still carries a copy for the odd row groups), supplied by the kernel.
 ST_RO, ST_T0, ST_SB = 240, 238, 232
 ST_VS, ST_STR1, ST_VSG = 233, 234, 235      # derived inside the statement: sigma-weight address, odd-row read address, sign-store offset
 ST_PT, ST_B3, ST_E = 4608, 2304, 1152
@@ -416,7 +421,8 @@ def gen(knobs):
                 fin.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (x, y), (x, y), None, "acc", (x, y)))
             for e in range(2):
                 off = pt * ST_PT + (t & 1) * ST_B3 + e * ST_E
-                fin.append(("ds_write", "ds_write_b128 %%[stw], v[%d:%d] offset:%d" % (PKR(pt, 4 * e), PKR(pt, 4 * e) + 3, off), (), None, "acc"))
+                if K["abl_stw"]:
+                    fin.append(("ds_write", "ds_write_b128 %%[stw], v[%d:%d] offset:%d" % (PKR(pt, 4 * e), PKR(pt, 4 * e) + 3, off), (), None, "acc"))
         if sigma:                                            # q outermost, both point tiles share a quad's sigma weights
             sig_load(0); sig_load(1)
             for i in range(4):
@@ -446,14 +452,16 @@ def gen(knobs):
                 pt, i = rows[n]
                 ro = ST_RO + 4 * (n % 2)
                 src = "v%d" % ST_STR1 if (i & 1) else "%[str0]"
-                items.append(("ds_read", "ds_read_b128 v[%d:%d], %s offset:%d" % (ro, ro + 3, src, pt * ST_PT + 256 * i), (), ("ro", s, n), "post"))
+                if K["abl_str"]:
+                    items.append(("ds_read", "ds_read_b128 v[%d:%d], %s offset:%d" % (ro, ro + 3, src, pt * ST_PT + 256 * i), (), ("ro", s, n), "post"))
             def stw(n):
                 ro = ST_RO + 4 * (n % 2)
+                rokey = ("ro", s, n) if K["abl_str"] else None
                 if K["abl_vstore"]:
                     items.append(("vstore", "global_store_dwordx4 %%[vo], v[%d:%d], s[%d:%d] offset:%d%s" % (ro, ro + 3, ST_SGPR_ACTS, ST_SGPR_ACTS + 1, 128 * tp, " nt" if K["nt"] else ""),
-                                  (), ("ro", s, n), "post", (ST_SGPR_ACTS, ST_SGPR_ACTS + 1)))
+                                  (), rokey, "post", (ST_SGPR_ACTS, ST_SGPR_ACTS + 1)))
                 else:                                        # timing ablation: the staged row is still waited for, nothing leaves
-                    items.append(("valu", "s_nop 0", (), ("ro", s, n), "post"))
+                    items.append(("valu", "s_nop 0", (), rokey, "post"))
                 if n < 7:
                     items.append(("valu", "v_add_u32 %[vo], 4096, %[vo]", ("vo",), None, "post"))
                 else:
@@ -633,9 +641,9 @@ def gen(knobs):
             g.emit("s_mov_b32 s%d, %%[%s]" % (dst, src))
             g.last_salu_write[dst] = g.n_states - 1
         # lane addresses derived from the kernel's: vb = TAIL + 64 h -> sigma weights at TAIL + 4 (BIAS_FLOATS + 128 h) = 8 vb - 7 TAIL
-        # + 4 BIAS_FLOATS (%[vsk] = that constant); the odd-row staging read address = str0 ^ 16; the sign-store offset = lane * 4
+        # + 4 BIAS_FLOATS (%[vsk] = that constant); the odd-row staging read address = a copy of str0; the sign-store offset = lane * 4
         g.emit("v_lshl_add_u32 v%d, %%[vb], 3, %%[vsk]" % ST_VS)
-        g.emit("v_xor_b32 v%d, 16, %%[str0]" % ST_STR1)
+        g.emit("v_mov_b32 v%d, %%[str0]" % ST_STR1)
         g.emit("v_lshrrev_b32 v%d, 2, %%[va0]" % ST_VSG)
     for q in range(4):
         g.emit("ds_read_b128 v[%d:%d], %%[vb] offset:%d" % (BIAS + 4 * q, BIAS + 4 * q + 3, q * 16)); g.lgkm.append(("bias", 0))
