@@ -24,14 +24,6 @@ SN_DEV void x3_mma_v(f32x16& acc, const u32x4& a, const u32x4& b) {
   else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-// the three MFMAs of a k-step (c0 += Ah.Bh ; c1 += Al.Bh ; c0 += Ah.Bl) as ONE asm: hipcc pads an `s_nop 0` in front of the third
-// (it depends on the first) when they are separate statements -- one issue slot per k-step of a kernel that is issue-bound
-SN_DEV void x3_mma3_a(f32x16& c0, f32x16& c1, const u32x4& ah, const u32x4& al, int rh, int rl) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, a[%4:%5], %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, a[%4:%5], %1\n\t"
-               "v_mfma_f32_32x32x16_bf16 %0, %2, a[%6:%7], %0"
-               : "+v"(c0), "+v"(c1) : "v"(ah), "v"(al), "n"(rh), "n"(rh + 3), "n"(rl), "n"(rl + 3));
-}
-
 // MFMA (8 passes) -> VALU read of its result at a layer end: the wait states the compiler would insert for a builtin MFMA.  The two
 // chains are operands: plain C++ arithmetic on them (A + B) could otherwise be scheduled above the wait (tools/check_agpr.py).
 SN_DEV void x3_result_fence(f32x16& a, f32x16& b) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b)); }
@@ -86,6 +78,27 @@ SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], flo
                    "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
                    "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
+}
+
+// ... one HALF of such a block: accumulator registers 2 i, 2 i + 1 -> v0, v1 = act(A + B), their packed hi pair into a[rh], lo pair into
+// a[rl] (12 VALU: the size that fits the shadow of one MFMA; slab_x3 issues a half behind the second and the third MFMA of a k-step)
+template <bool RELU>
+SN_DEV void x3_epi_half(int rh, int rl, float a0, float a1, float b0, float b1, float& v0, float& v1, uint32_t& hp, uint32_t& lp) {
+  float r0, r1;
+  if (RELU)
+    asm volatile("v_add_f32 %0, %6, %8\n\tv_add_f32 %1, %7, %9\n\tv_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\t"
+                 "v_cvt_pk_bf16_f32 %2, %0, %1\n\tv_lshlrev_b32 %4, 16, %2\n\tv_and_b32 %5, 0xffff0000, %2\n\t"
+                 "v_accvgpr_write_b32 a[%10], %2\n\tv_sub_f32 %4, %0, %4\n\tv_sub_f32 %5, %1, %5\n\t"
+                 "v_cvt_pk_bf16_f32 %3, %4, %5\n\tv_accvgpr_write_b32 a[%11], %3"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(hp), "=&v"(lp), "=&v"(r0), "=&v"(r1)
+                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "n"(rh), "n"(rl));
+  else
+    asm volatile("v_add_f32 %0, %6, %8\n\tv_add_f32 %1, %7, %9\n\t"
+                 "v_cvt_pk_bf16_f32 %2, %0, %1\n\tv_lshlrev_b32 %4, 16, %2\n\tv_and_b32 %5, 0xffff0000, %2\n\t"
+                 "v_accvgpr_write_b32 a[%10], %2\n\tv_sub_f32 %4, %0, %4\n\tv_sub_f32 %5, %1, %5\n\t"
+                 "v_cvt_pk_bf16_f32 %3, %4, %5\n\tv_accvgpr_write_b32 a[%11], %3"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(hp), "=&v"(lp), "=&v"(r0), "=&v"(r1)
+                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "n"(rh), "n"(rl));
 }
 
 template <bool RELU>
@@ -162,8 +175,27 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW + ISSUED) : "memory");
       __builtin_amdgcn_s_barrier();
     }
+    const u32x4 a_hi = af[(PHASE + ks) & 3][0], a_lo = af[(PHASE + ks) & 3][1];
+    // even k-steps: A += Wh.xh ; B += Wl.xh ; A += Wh.xl        odd: B += Wh.xh ; A += Wl.xh ; B += Wh.xl
+    const bool even = (ks & 1) == 0;
+    f32x16& c0 = even ? accA : accB;
+    f32x16& c1 = even ? accB : accA;
+    const bool seg0 = ks < NK0;
+    const int kk = seg0 ? ks : ks - NK0;
+    const int set = seg0 ? SET0 : SET1;
+    // Everything else of a k-step sits in the shadows of its three MFMAs (in-order issue: what is issued behind the third MFMA runs
+    // with the pipe empty as soon as that one retires):
+    //     MFMA 1 | fragment prefetch (k-step + 3), DMA pieces, row-store / mask-load steps | MFMA 2 | an epilogue block (k-steps 0..3)
+    //     or the next slab's bias (k-step 4) | MFMA 3
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks == 0) {
+      if (set < 0) x3_mma_v<true, false>(c0, a_hi, bh[kk]); else x3_mma_a<true, false>(c0, a_hi, x3_reg(set, 0, kk));
+    } else {
+      if (set < 0) x3_mma_v<false, false>(c0, a_hi, bh[kk]); else x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 0, kk));
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const bool dma = ks >= GB && (ks - GB) * PPK < NP;       // this k-step carries DMA pieces; the first one's m0 write goes in FRONT of
-    if (dma) ring.piece_m0();                           // the fragment reads (they are the wait state between it and the load)
+    if (dma) ring.piece_m0();                                // the fragment reads (they are the wait state between it and the load)
     {
       const int kn = ks + 3;
       const char* src = (kn < NK) ? lw + kn * 2048 : lw_next + (kn - NK) * 2048;
@@ -179,40 +211,23 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
       post(ks, NK, GB, false);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const u32x4 a_hi = af[(PHASE + ks) & 3][0], a_lo = af[(PHASE + ks) & 3][1];
-    // even k-steps: A += Wh.xh ; B += Wl.xh ; A += Wh.xl        odd: B += Wh.xh ; A += Wl.xh ; B += Wh.xl
-    const bool even = (ks & 1) == 0;
-    f32x16& c0 = even ? accA : accB;
-    f32x16& c1 = even ? accB : accA;
-    const bool seg0 = ks < NK0;
-    const int kk = seg0 ? ks : ks - NK0;
-    const int set = seg0 ? SET0 : SET1;
     if (ks == 0) {
-      if (set < 0) {
-        x3_mma_v<true, false>(c0, a_hi, bh[kk]);
-        x3_mma_v<false, true>(c1, a_lo, bh[kk]);
-        x3_mma_v<false, false>(c0, a_hi, bl[kk]);
-      } else {
-        x3_mma_a<true, false>(c0, a_hi, x3_reg(set, 0, kk));
-        x3_mma_a<false, true>(c1, a_lo, x3_reg(set, 0, kk));
-        x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
-      }
-    } else if (set < 0) {                                    // (as three statements: bundled, the kernels with pre-embedded inputs run
-      x3_mma_v<false, false>(c0, a_hi, bh[kk]);              //  out of VGPRs and hipcc spills into the hand-managed AGPR file)
-      x3_mma_v<false, false>(c1, a_lo, bh[kk]);
-      x3_mma_v<false, false>(c0, a_hi, bl[kk]);
+      if (set < 0) x3_mma_v<false, true>(c1, a_lo, bh[kk]); else x3_mma_a<false, true>(c1, a_lo, x3_reg(set, 0, kk));
     } else {
-      x3_mma3_a(c0, c1, a_hi, a_lo, x3_reg(set, 0, kk), x3_reg(set, 1, kk));
+      if (set < 0) x3_mma_v<false, false>(c1, a_lo, bh[kk]); else x3_mma_a<false, false>(c1, a_lo, x3_reg(set, 0, kk));
     }
     __builtin_amdgcn_sched_barrier(0);
-    // the previous tile's deferred epilogue, one block of four accumulator registers (~25 VALU) behind each of the first four
-    // k-steps -- as ONE block behind k-step 0 (~100 VALU against 3 MFMAs in flight) it left the MFMA pipe idle for a third of every slab
-    // (45 % busy, profiles/r04_x3_train_kernels.txt); the 4-k-step slabs keep it whole.  The next slab's bias goes into
-    // the vacated chain A right behind the last block.
+    // the previous tile's deferred epilogue: one block of four accumulator registers in each of the first four k-steps (the 4-k-step
+    // slabs keep all four blocks behind k-step 0: their row stores start at k-step 1).  The next slab's bias goes into the vacated
+    // chain A behind the last block.
     if (NK >= 8) {
       if (ks < 4) pending(ks);
       if (ks == 4) nA = load_bias(lds_bias, s_next, h);
-    } else {                                                 // (4-k-step slabs: the row stores of the tile start at k-step 1)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (set < 0) x3_mma_v<false, false>(c0, a_hi, bl[kk]); else x3_mma_a<false, false>(c0, a_hi, x3_reg(set, 1, kk));
+    __builtin_amdgcn_sched_barrier(0);
+    if (NK < 8) {
       if (ks == 0) { pending(0); pending(1); pending(2); pending(3); }
       if (ks == 1) nA = load_bias(lds_bias, s_next, h);
     }
@@ -236,6 +251,11 @@ SN_DEV void x3_lds_write_split(unsigned lds, int off, uint32_t h0, uint32_t h1, 
   typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
   const u32x2_ hh = {h0, h1}, ll = {l0, l1};
   asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4" :: "v"(lds), "v"(hh), "v"(ll), "n"(off), "n"(off + 16) : "memory");
+}
+
+// ... of ONE pair (two consecutive features): 4 B of hi parts at off, 4 B of lo parts 16 B further
+SN_DEV void x3_lds_write_split_pair(unsigned lds, int off, uint32_t hp, uint32_t lp) {
+  asm volatile("ds_write_b32 %0, %1 offset:%3\n\tds_write_b32 %0, %2 offset:%4" :: "v"(lds), "v"(hp), "v"(lp), "n"(off), "n"(off + 16) : "memory");
 }
 
 // four fp32 values -> their (hi, lo) bf16 pairs in a[rh], a[rh+1] / a[rl], a[rl+1] (no activation: values computed on the VALU)
