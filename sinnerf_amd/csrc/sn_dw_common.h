@@ -20,7 +20,10 @@ struct Task {                                   // 64 bytes, built on the host (
                                                 // 6 / 7 = 1 / 3 with the embedded inputs stored as bf16 (sn_dw_narrow_bf16.hip only);
                                                 // | 0x100: bf16 operands (mixed-precision training), fp32 accumulate;
                                                 // | 0x200: G and the 256-wide activations are stored as bf16 (the embedded
-                                                //   inputs of variants 1 / 3 stay fp32); lda / ldb stay in ELEMENTS
+                                                //   inputs of variants 1 / 3 stay fp32); lda / ldb stay in ELEMENTS;
+                                                // | 0x400 (with 0x100): bf16x3 -- 3-term (hi, lo) split, fp32-level; the 256-wide operands of
+                                                //   variants 0 (a, b), 1 (a), 2 (b), 4 (b) are rows of the SPLIT state (sn_layout.h "x3 state"),
+                                                //   everything else fp32 and split in registers
 };
 
 typedef __attribute__((address_space(3))) void lds_void;

@@ -238,14 +238,14 @@ mlp_bwd_chain_bf16x3_kernel(const char* __restrict__ bblob, const float* __restr
       slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a0, b0, a1, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
           [&](int blk) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNY_W(W_), (T_) - 1, a1, b1, blk); },   \
-          [&](int ks, int nk, int gb, bool before) __attribute__((always_inline)) {                                         \
-            if (!before && (T_) > 0) x3_store_step(ks, nk, gb, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(out_slot, (T_) - 1, i); }); }); \
+          [&](int ks, int nk, int st0, bool before) __attribute__((always_inline)) {                                         \
+            if (!before && (T_) > 0) x3_store_step(ks, nk, st0, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(out_slot, (T_) - 1, i); }); }); \
     else                                                                                                           \
       slab_x3<NK_, 0, SET_, SET_, 2, 0, NB_, VW_>(a1, b1, a0, af, SNY_LW_CUR, static_cast<const u32x4*>(nullptr), static_cast<const u32x4*>(nullptr), \
           SNY_LW_NEXT, lds_zero, SNY_SNEXT, h, ring,                                                               \
           [&](int blk) __attribute__((always_inline)) { EPI_(SNY_W(W_), (T_) - 1, a0, b0, blk); },                 \
-          [&](int ks, int nk, int gb, bool before) __attribute__((always_inline)) {                                         \
-            if (!before) x3_store_step(ks, nk, gb, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(out_slot, (T_) - 1, i); }); }); \
+          [&](int ks, int nk, int st0, bool before) __attribute__((always_inline)) {                                         \
+            if (!before) x3_store_step(ks, nk, st0, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(out_slot, (T_) - 1, i); }); }); \
     ++s; cslot = (cslot == 2) ? 0 : cslot + 1;                                                                     \
   } while (0)
     // the 8 output tiles of a transposed layer; tiles 6, 7 stage the NEXT layer's slabs (NBB_); the last tile's epilogue is not deferred

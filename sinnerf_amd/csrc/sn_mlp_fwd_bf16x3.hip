@@ -236,13 +236,13 @@ mlp_fwd_bf16x3_kernel(const char* __restrict__ blob, const float* __restrict__ i
     if (((T_) & 1) == 0)                                                                                                   \
       slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a0, b0, a1, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
                                                    [&](int blk) __attribute__((always_inline)) { if ((T_) > 0) EPI_(SNX_W(W_), (T_) - 1, a1, b1, blk); }, \
-                                                   [&](int ks, int nk, int gb, bool before) __attribute__((always_inline)) {                    \
-                                                     if ((T_) > 0 && !before) x3_store_step(ks, nk, gb, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(cur_slot, (T_) - 1, i); }); }); \
+                                                   [&](int ks, int nk, int st0, bool before) __attribute__((always_inline)) {                    \
+                                                     if ((T_) > 0 && !before) x3_store_step(ks, nk, st0, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(cur_slot, (T_) - 1, i); }); }); \
     else                                                                                                                   \
       slab_x3<NK0_, NK1_, S0_, S1_, GB_, PH_, NB_, VW_>(a1, b1, a0, af, SNX_LW_CUR, BH_, BL_, SNX_LW_NEXT, lds_bias, SNX_SNEXT, h, ring, \
                                                    [&](int blk) __attribute__((always_inline)) { EPI_(SNX_W(W_), (T_) - 1, a0, b0, blk); }, \
-                                                   [&](int ks, int nk, int gb, bool before) __attribute__((always_inline)) {                    \
-                                                     if (!before) x3_store_step(ks, nk, gb, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(cur_slot, (T_) - 1, i); }); }); \
+                                                   [&](int ks, int nk, int st0, bool before) __attribute__((always_inline)) {                    \
+                                                     if (!before) x3_store_step(ks, nk, st0, rows_read, [&](int i) __attribute__((always_inline)) { rows_write(cur_slot, (T_) - 1, i); }); }); \
     SNX_ADVANCE();                                                                                                         \
   } while (0)
 #define SNX_LAYER(NK0_, NK1_, S0_, S1_, GB_, NBA_, NBB_, EPI_, W_)              \

@@ -142,9 +142,9 @@ SN_DEV void x3_put_signed(int rh, int rl, const float (&x)[4], uint32_t word, in
 //   NBYTES     size of the slab staged at this slab's sync point (the slab two ahead), a multiple of 4 KB for every K
 //   VMW        counted wait at the sync point (training kernels): the youngest VMW vector-memory operations of the wave at the START of
 //              the slab are row stores issued BEHIND the previous slab's DMA pieces and may stay in flight; barriers are raw s_barriers
-//   post(ks, NK, GB, before)  memory operations of the caller, once per k-step behind the sync point: with
+//   post(ks, NK, ST0, before)  memory operations of the caller, once per k-step behind the sync point (ST0: first k-step for row stores): with
 //              before = true in FRONT of the k-step's DMA pieces (the chain's mask loads), with false BEHIND them (row stores:
-//              x3_store_step maps the LAST four steps to the four row-group stores of the previous tile)
+//              x3_store_step deals the four row-group stores of the previous tile over k-steps ST0 .. NK - 1)
 template <int NK0, int NK1, int SET0, int SET1, int GB, int PHASE, int NBYTES, int VMW = 0, class RingX, class Pending, class Post>
 SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], const char* lw, const u32x4* bh, const u32x4* bl,
                     const char* lw_next, const float* lds_bias, int s_next, int h, RingX& ring, Pending&& pending, Post&& post) {
@@ -161,6 +161,9 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
   constexpr int GB2 = (NK >= 8) ? NK - 4 : GB;
   constexpr int ISSUED = ((GB2 - GB) * PPK < NP) ? (GB2 - GB) * PPK : NP;      // pieces of slab s+2 issued before B2
   static_assert(GB2 >= GB && GB2 + 3 <= NK, "B2 in front of the first prefetch of the next slab's fragments");
+  // first k-step that may carry row stores of the caller: behind the slab's last DMA piece (x3_store_step), not before NK - 4 / the sync point
+  constexpr int LASTP = NP > 0 ? GB + NPS - 1 : GB;
+  constexpr int ST0 = (LASTP > NK - 4 ? LASTP : NK - 4) > GB ? (LASTP > NK - 4 ? LASTP : NK - 4) : GB;
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
     if (ks == GB) {
@@ -203,12 +206,12 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
       af[(PHASE + kn) & 3][1] = *reinterpret_cast<const u32x4*>(src + 1024);
     }
     if (ks >= GB) {
-      post(ks, NK, GB, true);
+      post(ks, NK, ST0, true);
       if (dma) ring.piece_load();
 #pragma unroll
       for (int i = 1; i < PPK; ++i)
         if ((ks - GB) * PPK + i < NP) ring.piece_static();
-      post(ks, NK, GB, false);
+      post(ks, NK, ST0, false);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (ks == 0) {
@@ -295,25 +298,25 @@ SN_DEV void x3_put_masked(int rh, int rl, const float (&x)[4], const f32x4& a, f
                : "vcc");
 }
 
-// the four row-group stores of a finished tile over the memory steps of the next slab.  A row group leaves the staging tile with a
-// ds_read_b128 and goes out with a global_store one step LATER (rd(i) then, a k-step on, wr(i)): read + store in one step parks the wave
-// for the LDS latency with nothing but the previous k-step's MFMAs in flight -- four times per slab (measured: the training forward lost
-// a third of its rate to it).  The LAST five steps carry rd(0) | wr(0) rd(1) | wr(1) rd(2) | wr(2) rd(3) | wr(3); a 4-k-step slab has
-// three steps behind its sync point and keeps read + store together (1 + 1 + 2), as do the 8-k-step slabs (last four steps).  The stores stay the youngest four vector-memory
-// operations of the slab (VMW of slab_x3).
+// the four row-group stores of a finished tile over the memory steps of the next slab.  THE RULE the counted waits rest on (VMW of
+// slab_x3): a slab issues its row stores BEHIND ITS LAST DMA PIECE -- in k-steps st0 = max(k-step of the last piece, NK - 4) .. NK - 1,
+// behind that k-step's pieces -- so that at the next slab's sync point exactly these four stores are younger than the pieces the wait is
+// for.  (Until round 4 the 4- and 8-k-step slabs dealt their stores 1 + 1 + 2 / 1 + 1 + 1 + 1 from the sync point on, BETWEEN their
+// pieces: vmcnt(4) then let the last two or three pieces of the next slab's weights stay in flight across the barrier -- a race that
+// showed as run-to-run differences of a few 1e-5 in a training render, tools/x3_determinism.py.)
+// Where the slab is long enough a row group leaves the staging tile one k-step AHEAD of its store (rd(i) then, a k-step on, wr(i)):
+// read + store in one step waits for the LDS latency in front of the store.  rd(0) never before k-step 4: pending(0..3) fill the tile
+// behind k-steps 0..3.
 template <class R, class W>
-SN_DEV void x3_store_step(int ks, int nk, int gb, R&& rd, W&& wr) {
-  if (nk >= 9) {                                 // rd(0) not before k-step 4: pending(0..3) fill the staging tile behind k-steps 0..3
-    const int j = ks - (nk - 5);
+SN_DEV void x3_store_step(int ks, int nk, int st0, R&& rd, W&& wr) {
+  const int m = nk - st0;                        // k-steps that carry stores (1..4)
+  if (m == 4 && st0 >= 5) {                      // rd(0) | wr(0) rd(1) | wr(1) rd(2) | wr(2) rd(3) | wr(3)
+    const int j = ks - (st0 - 1);
     if (j >= 1) wr(j - 1);
     if (j >= 0 && j < 4) rd(j);
-  } else if (nk - gb >= 4) {
-    const int j = ks - (nk - 4);
-    if (j >= 0) { rd(j); wr(j); }
-  } else if (ks - gb < 2) {
-    rd(ks - gb); wr(ks - gb);
-  } else {
-    rd(2); wr(2); rd(3); wr(3);                 // (one row buffer)
+  } else if (ks >= st0) {
+    const int per = (4 + m - 1) / m, j = ks - st0;
+    for (int i = j * per; i < (j + 1) * per && i < 4; ++i) { rd(i); wr(i); }      // (one row buffer: read, store, read, store)
   }
 }
 
