@@ -387,8 +387,9 @@ def test_bf16x3_training_render_gradients_on_llff_patch_shape():
     print("bf16x3 llff-patch gradients vs fp32 oracle: worst norm-wise %.2e, min cosine %.7f" % (worst, wcos))
 
 
-def test_bf16x3_training_render_is_run_to_run_identical():
-    """Two training renders of the llff patch (5 292 rays: 2 646 + 5 292 point tiles, ten rounds of the persistent workgroups) with freed
+@pytest.mark.parametrize("dt", [DT, "bf16", "fp32"])
+def test_training_render_is_run_to_run_identical(dt):
+    """(every arithmetic; written for bf16x3)  Two training renders of the llff patch (5 292 rays: 2 646 + 5 292 point tiles, ten rounds of the persistent workgroups) with freed
     memory poisoned in between give the SAME bits -- outputs and all 48 parameter gradients.  Regression test of a race the counted
     vmcnt waits had until round 4 (row stores issued between a short slab's DMA pieces: csrc/sn_mlp_x3.h x3_store_step) -- it moved a
     few hundred rays by ~1e-5 from run to run, inside every parity bar."""
@@ -402,8 +403,8 @@ def test_bf16x3_training_render_is_run_to_run_identical():
             for k, sh in (("rgb_coarse", (n, 3)), ("rgb_fine", (n, 3)), ("depth_coarse", (n,)), ("depth_fine", (n,)))}
 
     def run():
-        mc, _ = make_model(0, True, dtype=DT)
-        mf, _ = make_model(1, True, dtype=DT)
+        mc, _ = make_model(0, True, dtype=dt)
+        mf, _ = make_model(1, True, dtype=dt)
         mc.train(); mf.train()
         with injected_rng(order) as left:
             res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays).to(dev()), S, False, 1.0, 1.0, NI, 32768, False)
