@@ -421,3 +421,23 @@ def test_training_render_is_run_to_run_identical(dt):
         for k in out_a:
             assert torch.equal(out_a[k], out_b[k]), k
         assert all(torch.equal(x, y) for x, y in zip(g_a, g_b))
+
+
+@pytest.mark.parametrize("dt", [DT, "bf16", "fp32"])
+def test_inference_render_is_run_to_run_identical(dt):
+    """the same for the inference kernels: an eval render of 8 192 lego rays (64 + 128 samples: 4 096 + 12 288 point tiles) twice"""
+    import sinnerf_amd
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::19][:8192]).to(dev())
+    outs = []
+    for rep in range(3):
+        mc, _ = make_model(0, True, dtype=dt)
+        mf, _ = make_model(1, True, dtype=dt)
+        with torch.no_grad():
+            res = sinnerf_amd.render_rays([mc.eval(), mf.eval()], embeddings(), rays, 64, False, 0, 0, 128, 32768, True)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in res.items()})
+        junk = torch.full((128, 1024, 1024), float("nan"), device=dev())
+        del junk
+    for o in outs[1:]:
+        for k in o:
+            assert torch.equal(o[k], outs[0][k]), k
