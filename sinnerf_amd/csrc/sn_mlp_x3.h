@@ -80,27 +80,6 @@ SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], flo
                    "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1));
 }
 
-// ... one HALF of such a block: accumulator registers 2 i, 2 i + 1 -> v0, v1 = act(A + B), their packed hi pair into a[rh], lo pair into
-// a[rl] (12 VALU: the size that fits the shadow of one MFMA; slab_x3 issues a half behind the second and the third MFMA of a k-step)
-template <bool RELU>
-SN_DEV void x3_epi_half(int rh, int rl, float a0, float a1, float b0, float b1, float& v0, float& v1, uint32_t& hp, uint32_t& lp) {
-  float r0, r1;
-  if (RELU)
-    asm volatile("v_add_f32 %0, %6, %8\n\tv_add_f32 %1, %7, %9\n\tv_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\t"
-                 "v_cvt_pk_bf16_f32 %2, %0, %1\n\tv_lshlrev_b32 %4, 16, %2\n\tv_and_b32 %5, 0xffff0000, %2\n\t"
-                 "v_accvgpr_write_b32 a[%10], %2\n\tv_sub_f32 %4, %0, %4\n\tv_sub_f32 %5, %1, %5\n\t"
-                 "v_cvt_pk_bf16_f32 %3, %4, %5\n\tv_accvgpr_write_b32 a[%11], %3"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(hp), "=&v"(lp), "=&v"(r0), "=&v"(r1)
-                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "n"(rh), "n"(rl));
-  else
-    asm volatile("v_add_f32 %0, %6, %8\n\tv_add_f32 %1, %7, %9\n\t"
-                 "v_cvt_pk_bf16_f32 %2, %0, %1\n\tv_lshlrev_b32 %4, 16, %2\n\tv_and_b32 %5, 0xffff0000, %2\n\t"
-                 "v_accvgpr_write_b32 a[%10], %2\n\tv_sub_f32 %4, %0, %4\n\tv_sub_f32 %5, %1, %5\n\t"
-                 "v_cvt_pk_bf16_f32 %3, %4, %5\n\tv_accvgpr_write_b32 a[%11], %3"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(hp), "=&v"(lp), "=&v"(r0), "=&v"(r1)
-                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "n"(rh), "n"(rl));
-}
-
 template <bool RELU>
 SN_DEV void x3_epi(int rh, int rl, const float (&a)[4], const float (&b)[4], float (&v)[4]) {
   uint32_t h0, h1, l0, l1;
@@ -256,11 +235,6 @@ SN_DEV void x3_lds_write_split(unsigned lds, int off, uint32_t h0, uint32_t h1, 
   asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4" :: "v"(lds), "v"(hh), "v"(ll), "n"(off), "n"(off + 16) : "memory");
 }
 
-// ... of ONE pair (two consecutive features): 4 B of hi parts at off, 4 B of lo parts 16 B further
-SN_DEV void x3_lds_write_split_pair(unsigned lds, int off, uint32_t hp, uint32_t lp) {
-  asm volatile("ds_write_b32 %0, %1 offset:%3\n\tds_write_b32 %0, %2 offset:%4" :: "v"(lds), "v"(hp), "v"(lp), "n"(off), "n"(off + 16) : "memory");
-}
-
 // four fp32 values -> their (hi, lo) bf16 pairs in a[rh], a[rh+1] / a[rl], a[rl+1] (no activation: values computed on the VALU)
 SN_DEV void x3_put(int rh, int rl, const float (&x)[4], uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
   float r0, r1, r2, r3;
@@ -277,27 +251,6 @@ SN_DEV void x3_put(int rh, int rl, const float (&x)[4]) {
   uint32_t h0, h1, l0, l1;
   x3_put(rh, rl, x, h0, h1, l0, l1);
 }
-// ... masked by the forward activations (backward of ReLU, nerf.py:73): v = a > 0 ? x : 0, then as x3_put
-SN_DEV void x3_put_masked(int rh, int rl, const float (&x)[4], const f32x4& a, float (&v)[4]) {
-  uint32_t h0, h1, l0, l1;
-  float r0, r1, r2, r3;
-  asm volatile("v_cmp_lt_f32 vcc, 0, %16\n\tv_cndmask_b32 %8, 0, %12, vcc\n\t"
-               "v_cmp_lt_f32 vcc, 0, %17\n\tv_cndmask_b32 %9, 0, %13, vcc\n\t"
-               "v_cmp_lt_f32 vcc, 0, %18\n\tv_cndmask_b32 %10, 0, %14, vcc\n\t"
-               "v_cmp_lt_f32 vcc, 0, %19\n\tv_cndmask_b32 %11, 0, %15, vcc\n\t"
-               "v_cvt_pk_bf16_f32 %0, %8, %9\n\tv_cvt_pk_bf16_f32 %1, %10, %11\n\t"
-               "v_lshlrev_b32 %4, 16, %0\n\tv_and_b32 %5, 0xffff0000, %0\n\tv_lshlrev_b32 %6, 16, %1\n\tv_and_b32 %7, 0xffff0000, %1\n\t"
-               "v_accvgpr_write_b32 a[%20], %0\n\tv_accvgpr_write_b32 a[%21], %1\n\t"
-               "v_sub_f32 %4, %8, %4\n\tv_sub_f32 %5, %9, %5\n\tv_sub_f32 %6, %10, %6\n\tv_sub_f32 %7, %11, %7\n\t"
-               "v_cvt_pk_bf16_f32 %2, %4, %5\n\tv_cvt_pk_bf16_f32 %3, %6, %7\n\t"
-               "v_accvgpr_write_b32 a[%22], %2\n\tv_accvgpr_write_b32 a[%23], %3"
-               : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3),
-                 "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]),
-                 "n"(rh), "n"(rh + 1), "n"(rl), "n"(rl + 1)
-               : "vcc");
-}
-
 // the four row-group stores of a finished tile over the memory steps of the next slab.  THE RULE the counted waits rest on (VMW of
 // slab_x3): a slab issues its row stores BEHIND ITS LAST DMA PIECE -- in k-steps st0 = max(k-step of the last piece, NK - 4) .. NK - 1,
 // behind that k-step's pieces -- so that at the next slab's sync point exactly these four stores are younger than the pieces the wait is
