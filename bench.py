@@ -709,14 +709,14 @@ def main():
             ref_models, ref_emb = stage_ref.build_reference_models(params)
             kind = "reference"
 
-            def cpu_render(r):
-                return ref_rendering.render_rays(ref_models, ref_emb, r, NS, False, 0, 0, NI, 1024 * 32, True)
+            def cpu_render(r, white_back=True):
+                return ref_rendering.render_rays(ref_models, ref_emb, r, NS, False, 0, 0, NI, 1024 * 32, white_back)
         else:
             tp = [{k: torch.from_numpy(v) for k, v in p.items()} for p in params]
             kind = "port"
 
-            def cpu_render(r):
-                return T.render(tp, r, NS, NI, True)
+            def cpu_render(r, white_back=True):
+                return T.render(tp, r, NS, NI, white_back)
         # thread count: torch's intra-op pool with ALL cores of a 256-core host is 10x SLOWER than with a few dozen on this
         # op sequence (measured: 26 rays/s at 256 threads) -- so the count is calibrated on a 256-ray probe and the best one
         # is used and reported as `cores`
@@ -746,6 +746,15 @@ def main():
                                              "stock torch CPU ops (oracle/torch_ref.py = the reference's op sequence; oracle/_ref "
                                              "not staged on this box)", nthreads, cdt),
                                "thread_calibration_rays_per_s": {str(k): v for k, v in cal.items()}}
+        try:                                       # BASELINE configs[0] as named: ONE 1024-ray chunk of a 504x378 llff-shaped frame, 64+64, CPU
+            lr = torch.from_numpy(O.llff_like_rays(1024, seed=0))
+            with torch.no_grad():
+                cpu_render(lr[:256], False)
+                t0 = time.perf_counter()
+                cpu_render(lr, False)
+            res["cpu_baseline"]["config1_llff_1024_rays_per_s"] = 1024 / (time.perf_counter() - t0)
+        except Exception as e:                      # noqa: BLE001
+            res["cpu_baseline"]["config1_llff_1024_rays_per_s"] = repr(e)
         if kind == "reference":                                                          # the port beside it, same sample
             try:
                 tp = [{k: torch.from_numpy(v) for k, v in p.items()} for p in params]
