@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Run-to-run comparison of a training render (llff patch, 5 292 rays, perturb = noise_std = 1, injected draws) per arithmetic, with freed
+memory poisoned in between: bit-identical outputs and gradients or not, and where they differ.  This is what found the store-order race of
+the bf16x3 training kernels (csrc/sn_mlp_x3.h x3_store_step); tests/test_bf16x3_gpu.py::test_training_render_is_run_to_run_identical is the
+regression test.  usage (repo root = $R): R=$PWD python tools/x3_determinism.py     (SINNERF_HIP_LIB=... for another build)"""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.environ["R"])
+sys.path.insert(0, os.environ.get("R", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle_np as O
 import sinnerf_amd
 from tests.test_parity_gpu import make_model, embeddings, injected_rng, dev
