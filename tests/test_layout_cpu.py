@@ -279,3 +279,23 @@ def test_bf16_emb_positions_invert_the_layout_slot_maps():
     # the positions no column maps to are exactly the pad slots of the layout
     assert {32 * h + e for h in (0, 1) for e in range(32) if L.lib.sn_layout_xyz_slot_col(h, e) < 0} == set(range(64)) - {xyz_pos(c) for c in range(63)}
     assert {16 * h + e for h in (0, 1) for e in range(16) if L.lib.sn_layout_dir_slot_col(h, e) < 0} == set(range(32)) - {dir_pos(c) for c in range(27)}
+
+
+def test_x3_state_layout_helpers_round_trip():
+    """tests/helpers.py x3_state_encode / _decode restate the bf16x3 training-state layout (csrc/sn_layout.h "x3 state",
+    include/sinnerf_hip.h sn_mlp_forward_train): per 8 consecutive features 16 B of hi parts (RNE bf16 of x), then 16 B of lo parts
+    (RNE bf16 of x - hi); hi + lo = x to 2^-16 relative; a row keeps its 1 KB."""
+    from tests.helpers import x3_state_decode, x3_state_encode
+    x = np.random.RandomState(0).standard_normal((3, 7, 256)).astype(np.float32)
+    x[0, 0, :8] = [0.0, -0.0, 1.0, -1.0, 3.0e-39, 65504.0, 1.0 + 2.0 ** -9, 1.0 - 2.0 ** -10]      # zeros, a subnormal, ties of the hi rounding
+    e = x3_state_encode(x)
+    assert e.shape == x.shape and e.dtype == np.float32
+    u = e.view(np.uint16).reshape(3, 7, 32, 2, 8)
+    hi = (u[..., 0, :].astype(np.uint32) << 16).view(np.float32).reshape(3, 7, 256)
+    lo = (u[..., 1, :].astype(np.uint32) << 16).view(np.float32).reshape(3, 7, 256)
+    assert np.array_equal(hi, O.bf16_round(x))                                      # the oracle's RNE bf16
+    assert np.array_equal(lo, O.bf16_round(x - hi))
+    d = x3_state_decode(e)
+    assert np.array_equal(d, hi + lo)
+    nz = np.abs(x) > 1e-30
+    assert (np.abs(d - x)[nz] / np.abs(x)[nz]).max() <= 2.0 ** -16
