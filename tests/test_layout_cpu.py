@@ -299,3 +299,37 @@ def test_x3_state_layout_helpers_round_trip():
     assert np.array_equal(d, hi + lo)
     nz = np.abs(x) > 1e-30
     assert (np.abs(d - x)[nz] / np.abs(x)[nz]).max() <= 2.0 ** -16
+
+
+def test_x3_split_tile_swizzle_is_consistent_and_bank_conflict_free():
+    """The staged image of a SPLIT tile in the bf16x3 weight-gradient kernel (csrc/sn_dw.hip RowStager<.., SPLIT>), restated: LDS piece
+    (row, lp) receives the global 16-byte piece lp ^ swz(row), swz(row) = (row & 1) | ((row & 2) << 2); lane (q, G) of a transpose read
+    addresses the 8-byte group of features f .. f+3 of row 8 (G >> 1) + (q >> 2) (+ 4 for the second read), hi part, lo part at ^ 16.
+    (a) every lane's address holds exactly the global bytes it wants; (b) the 32 lanes a ds_read_b64_tr_b16 serves together
+    (MI355X_MICROARCH.md LDS table: 2 x 32 lanes, bank = (a / 4) mod 64) cover 64 distinct banks -- for hi and lo, every tile column
+    block, both reads, every tile width."""
+    swz = lambda row: (row & 1) | ((row & 2) << 2)
+    for W in (64, 128, 256):                                               # features per row of the tile (row = W * 4 bytes)
+        per_row = W // 4                                                   # 16-byte pieces per row
+        lds = {}                                                           # LDS byte address of a piece -> (row, global piece)
+        for row in range(16):
+            for lp in range(per_row):
+                lds[row * W * 4 + lp * 16] = (row, lp ^ swz(row))
+        assert len(lds) == 16 * per_row
+        for f0 in range(0, W, 32):                                         # accumulator tile column block
+            for second in (0, 1):
+                for part in (0, 1):
+                    addrs = []
+                    for lane in range(64):
+                        q, G = lane & 15, lane >> 4
+                        row = 8 * (G >> 1) + (q >> 2) + 4 * second
+                        f = f0 + 16 * (G & 1) + 4 * (q & 3)
+                        off = row * W * 4 + ((2 * (f >> 3)) ^ swz(row)) * 16 + 8 * ((f >> 2) & 1)
+                        off ^= 16 * part
+                        r, gp = lds[off & ~15]
+                        assert r == row and gp == 2 * (f >> 3) + part, (W, lane, part)      # (a) hi piece 2 (f / 8), lo piece + 1
+                        assert (off & 15) == 8 * ((f >> 2) & 1)
+                        addrs.append(off)
+                    for half in (addrs[:32], addrs[32:]):                  # (b)
+                        banks = [(a // 4 + d) % 64 for a in half for d in (0, 1)]
+                        assert len(set(banks)) == 64, (W, f0, second, part)
