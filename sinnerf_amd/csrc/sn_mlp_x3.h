@@ -143,6 +143,7 @@ SN_DEV void slab_x3(f32x16& accA, f32x16& accB, f32x16& nA, u32x4 (&af)[4][2], c
   // first k-step that may carry row stores of the caller: behind the slab's last DMA piece (x3_store_step), not before NK - 4 / the sync point
   constexpr int LASTP = NP > 0 ? GB + NPS - 1 : GB;
   constexpr int ST0 = (LASTP > NK - 4 ? LASTP : NK - 4) > GB ? (LASTP > NK - 4 ? LASTP : NK - 4) : GB;
+  static_assert(ST0 >= LASTP && ST0 >= GB && ST0 < NK, "row stores behind the slab's last DMA piece: what VMW = 4 at the next sync point counts on");
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
     if (ks == GB) {
