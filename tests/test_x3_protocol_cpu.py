@@ -175,3 +175,30 @@ def test_row_groups_are_read_after_the_epilogue_filled_the_tile():
     for nk, gb, nb in ((4, 1, B_L0), (4, 1, B_H), (8, 2, B_D), (8, 2, B_H)):
         c = schedule(nk, gb, nb)
         assert c["st0"] >= c["lastp"] and c["st0"] >= gb and c["st0"] < nk
+
+
+def test_weight_gradient_loop_computes_every_chunk_once():
+    """The bf16x3 chunk loop of csrc/sn_dw.hip (run_task, X3 branch) restated: the gathers of chunk c go out in front of the MFMAs of chunk
+    c-1 (two register sets, unrolled by two, an odd step count evened out by one peeled step whose set is copied): every chunk 0 .. n-1 is
+    multiplied exactly once, from the set that holds it, for every chunk count."""
+    h = src("sn_dw.hip")
+    for line in ("step(1, ra1, rb1, ra0, rb0);", "step(c, ra1, rb1, ra0, rb0);", "step(c + 1, ra0, rb0, ra1, rb1);", "for (; c < n_chunks; c += 2) {",
+                 "if (n_chunks & 1) {", "gather_a(smem, ra0);"):
+        assert line in h, line
+    for n in range(1, 40):
+        sets, done = {0: 0, 1: None}, []                      # register set -> chunk it holds (after the prologue: chunk 0 in set 0)
+
+        def step(c, g, k):
+            sets[g] = c                                       # gather(chunk c) -- chunk n is the staged clamp copy nobody multiplies
+            done.append(sets[k])                              # compute(chunk c - 1)
+            assert sets[k] == c - 1, (n, c)
+        c = 1
+        if n & 1:
+            step(1, 1, 0)
+            sets[0] = sets[1]
+            c = 2
+        while c < n:
+            step(c, 1, 0)
+            step(c + 1, 0, 1)
+            c += 2
+        assert done == list(range(n)), (n, done)
