@@ -92,26 +92,27 @@ class NeRF(nn.Module):
     """``NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False)``.
 
     Reference ``models/nerf.py:46-148``.  The HIP kernels implement the layer configuration both reference call sites
-    construct (``sinnerf.py:137,140``, ``eval.py:136-137``): D=8, W=256, 63/27 inputs, skips=[4] (``self.fused``).  Any other
-    configuration the reference's constructor accepts is built too and runs the same op sequence as stock PyTorch-ROCm ops on
-    the device (``sinnerf_amd/generic.py``: eager speed, differentiable, fp32).  Both head variants of ``nerf.py:77-100`` are
-    built: ``use_new_activation=True`` (ShiftedSoftplus / WidenedSigmoid, what SinNeRF uses) and the constructor's default
-    ``False`` (ReLU / Sigmoid).
+    construct (``sinnerf.py:137,140``, ``eval.py:136-137``): D=8, W=256, 63/27 inputs, skips=[4].  Any other configuration
+    the reference's constructor accepts raises ``NotImplementedError`` here, at construction: there is no torch-op second
+    backend in this package.  Both head variants of ``nerf.py:77-100`` are built: ``use_new_activation=True``
+    (ShiftedSoftplus / WidenedSigmoid, what SinNeRF uses) and the constructor's default ``False`` (ReLU / Sigmoid).
     """
 
     def __init__(self, D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4], use_new_activation=False,
                  compute_dtype="fp32"):
         super().__init__()
-        self.fused = (D, W, in_channels_xyz, in_channels_dir, list(skips)) == (8, 256, 63, 27, [4])
+        if (D, W, in_channels_xyz, in_channels_dir, list(skips)) != (8, 256, 63, 27, [4]):
+            raise NotImplementedError(
+                "sinnerf_amd.NeRF: the HIP kernels exist for NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4]) "
+                "(models/sinnerf.py:137,140, eval.py:136-137); got D=%r, W=%r, in_channels_xyz=%r, in_channels_dir=%r, skips=%r.  "
+                "There is no torch-op fallback for other layer configurations."
+                % (D, W, in_channels_xyz, in_channels_dir, list(skips)))
+        dtype_code(compute_dtype)                                    # unknown arithmetic: ValueError here, not at the first render
         self.use_new_activation = bool(use_new_activation)
         self.D, self.W = D, W
         self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
         self.skips = skips
         self.compute_dtype = compute_dtype
-        if not self.fused and dtype_code(compute_dtype) != _lib.SN_DTYPE_F32:
-            import warnings
-            warnings.warn("sinnerf_amd.NeRF: compute_dtype=%r only exists for the fused configuration (D=8, W=256, 63/27, skips=[4]); "
-                          "this network runs the reference's fp32 op sequence (sinnerf_amd.generic)" % (compute_dtype,), stacklevel=2)
         for i in range(D):                                           # nerf.py:66-75
             if i == 0:
                 layer = nn.Linear(in_channels_xyz, W)
@@ -136,14 +137,8 @@ class NeRF(nn.Module):
         return code if self.use_new_activation else code | _lib.SN_DTYPE_CLASSIC_HEADS
 
     # ---- packed weights -------------------------------------------------------------------------------
-    def _need_fused(self):
-        if not self.fused:
-            raise NotImplementedError("the packed-weight kernels exist for NeRF(D=8, W=256, 63, 27, skips=[4]) only; this "
-                                      "configuration runs through sinnerf_amd.generic")
-
     def raw_tensors(self):
         """The 24 parameter tensors in the order of ``include/sinnerf_hip.h`` (= state_dict order)."""
-        self._need_fused()
         out = []
         for i in range(self.D):
             lin = getattr(self, f"xyz_encoding_{i+1}")[0]
@@ -162,8 +157,6 @@ class NeRF(nn.Module):
         through ``data_ptr``; a write THROUGH ``p.data`` (``dist.broadcast(p.data)``, ``p.data.copy_()``, EMA / clipping code,
         a fused optimiser writing a flat buffer the parameters are views of) bumps neither -- call this after such a write.
         ``parallel.broadcast_parameters`` and ``optim.FlatAdam`` do.  The blob tensors are kept and re-filled in place."""
-        if not getattr(self, "fused", True):           # nothing is packed for the general configurations (generic.py)
-            return
         self._pack_generation += 1
 
     def packed(self, dtype=None):
@@ -256,9 +249,6 @@ class NeRF(nn.Module):
         need = self.in_channels_xyz if sigma_only else self.in_channels_xyz + self.in_channels_dir
         if x.dim() != 2 or x.shape[1] != need:
             raise RuntimeError(f"expected input of shape (B, {need}), got {tuple(x.shape)}")
-        if not self.fused:
-            from .generic import mlp_generic
-            return mlp_generic(self, x.float(), sigma_only)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import mlp_embedded_autograd
             return mlp_embedded_autograd(self, x, sigma_only)

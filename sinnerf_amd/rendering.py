@@ -29,30 +29,43 @@ PROFILE = None
 MAX_FUSED_SAMPLES = 1024       # samples per ray the per-ray kernels (compositor, sampler) hold in one wave
 
 
-def _is_pow2_bands(e, n_freqs):
-    """the reference's Embedding keeps no `logscale` attribute (nerf.py:8-22): the frequency bands themselves decide"""
+def _is_pow2_bands(e, in_channels, n_freqs):
+    """the reference's Embedding keeps no `logscale` attribute (nerf.py:8-22): the frequency bands themselves decide.  The verdict
+    is cached on the object, keyed on the band tensor's identity and version: a render call is launch-latency sensitive and must
+    not convert 14 band values to Python floats every time (nor sync a device on them if the bands were moved there)."""
     fb = getattr(e, "freq_bands", None)
-    if fb is None or len(fb) != n_freqs:
-        return False
-    return [float(f) for f in fb] == [float(2 ** k) for k in range(n_freqs)]
+    key = (id(fb), getattr(fb, "_version", None), in_channels, n_freqs)
+    hit = getattr(e, "_sn_pow2_verdict", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    ok = (fb is not None and getattr(e, "in_channels", None) == in_channels and getattr(e, "N_freqs", None) == n_freqs
+          and len(fb) == n_freqs)
+    if ok:
+        host = torch.as_tensor(fb).detach().to("cpu", torch.float64)
+        ok = bool(torch.equal(host, 2.0 ** torch.arange(n_freqs, dtype=torch.float64)))
+    try:
+        e._sn_pow2_verdict = (key, ok)
+    except Exception:                  # an object that refuses attributes is simply re-checked every call
+        pass
+    return ok
 
 
 def _fused_embeddings(embeddings):
     """the kernels fuse Embedding(3, 10) / Embedding(3, 4) with the logscale bands 2^k into the MLP (sinnerf.py:133-134,
-    eval.py:134-135); anything else -- including a reference-style Embedding(..., logscale=False) -- goes to generic.py"""
+    eval.py:134-135); anything else -- including a reference-style Embedding(..., logscale=False) -- is refused"""
     ex, ed = embeddings[0], embeddings[1]
-    return (getattr(ex, "in_channels", None) == 3 and getattr(ex, "N_freqs", None) == 10 and
-            getattr(ed, "in_channels", None) == 3 and getattr(ed, "N_freqs", None) == 4 and
-            _is_pow2_bands(ex, 10) and _is_pow2_bands(ed, 4))
+    return _is_pow2_bands(ex, 3, 10) and _is_pow2_bands(ed, 3, 4)
+
+
+SUPPORTED = ("NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=27, skips=[4]) with Embedding(3, 10) / Embedding(3, 4) "
+             "(logscale bands 2^k) and at most %d samples per ray" % MAX_FUSED_SAMPLES)
 
 
 def _check_embeddings(embeddings):
     if not _fused_embeddings(embeddings):
-        raise NotImplementedError("this entry point takes Embedding(3,10) / Embedding(3,4) (logscale); render_rays routes other "
-                                  "embeddings through sinnerf_amd.generic")
-
-# developer switch / tests: run render_rays through the general torch-op path (sinnerf_amd/generic.py) even for the fused configuration
-FORCE_GENERIC = False
+        raise NotImplementedError("sinnerf_amd: the HIP kernels fuse the embedding into the MLP and exist for one configuration -- "
+                                  + SUPPORTED + " (what models/sinnerf.py:133-141 and eval.py:134-137 build); got other embeddings. "
+                                  "There is no torch-op fallback.")
 
 
 def _mlp(model, rays, z_vals, sigma_only, flags=0):
@@ -161,8 +174,9 @@ def render_rays(models,
     """Render rays -- drop-in for reference ``models/rendering.py:126-335`` (same arguments, same dict).
 
     ``chunk`` only bounds temporary memory in the reference (its results are chunk-invariant); the fused kernels
-    need no point chunking and ignore it, the general path (``sinnerf_amd/generic.py``: other layer shapes / embeddings /
-    more than 1024 samples per ray) honours it as the reference does.  ``noisy_coarse`` is unused in the reference as well.
+    need no point chunking and ignore it.  ``noisy_coarse`` is unused in the reference as well.  Configurations the kernels
+    do not implement (other embeddings, more than 1024 samples per ray; other layer shapes are refused by the ``NeRF``
+    constructor) raise ``NotImplementedError``: there is no torch-op second backend.
     """
     if not isinstance(rays, torch.Tensor) or not rays.is_cuda:
         raise RuntimeError("sinnerf_amd.render_rays: rays must be a CUDA/ROCm tensor (there is no CPU fallback)")
@@ -175,14 +189,12 @@ def render_rays(models,
     if N_importance > 0 and len(models) < 2:
         raise IndexError("list index out of range")          # models[1], rendering.py:321
     rays = rays.contiguous().float()
-    # the reference's general configurations (other layer shapes / embeddings, more samples than the per-ray kernels hold):
-    # same op sequence as stock PyTorch-ROCm ops on the device -- sinnerf_amd/generic.py
-    if (FORCE_GENERIC or not all(m.fused for m in models) or not _fused_embeddings(embeddings)
-            or N_samples + N_importance > MAX_FUSED_SAMPLES):
-        from .generic import render_generic
-        with torch.cuda.device(rays.device):
-            return render_generic(models, embeddings, rays, N_samples, use_disp, perturb, noise_std, N_importance, chunk, white_back,
-                                  test_time, detach_coarse)
+    # one configuration exists in HIP (the one both reference call sites build); everything else is refused, loudly
+    _check_embeddings(embeddings)
+    if N_samples + N_importance > MAX_FUSED_SAMPLES:
+        raise NotImplementedError("sinnerf_amd.render_rays: %d + %d samples per ray; the per-ray kernels (compositor, importance "
+                                  "sampler, merge) hold at most %d in one wave.  Supported: %s"
+                                  % (N_samples, N_importance, MAX_FUSED_SAMPLES, SUPPORTED))
     needs_grad = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
     with torch.cuda.device(rays.device):
         if needs_grad and rays.shape[0] > 0:

@@ -32,6 +32,26 @@ DEFAULT_HPARAMS = dict(N_samples=64, N_importance=64, use_disp=False, perturb=1.
 
 
 
+def rebuild_scheduler(sch, new_opt):
+    """The same learning-rate schedule, at the same epoch, on another optimiser.
+
+    A ``MultiStepLR`` is constructed fresh (its constructor takes one initial step: ``last_epoch`` 0, the group's current lr kept)
+    and then given the old one's ``state_dict`` -- epoch counter, step count, ``_last_lr``, milestones.  Passing
+    ``last_epoch=sch.last_epoch`` to the constructor instead would resume one epoch AHEAD (the initial step increments it), so every
+    milestone of ``utils/__init__.py:34-36`` would fire one step early.  Other scheduler types are re-pointed in place."""
+    if isinstance(sch, torch.optim.lr_scheduler.MultiStepLR):
+        lrs = [g["lr"] for g in new_opt.param_groups]
+        ns = torch.optim.lr_scheduler.MultiStepLR(new_opt, milestones=sorted(sch.milestones.elements()), gamma=sch.gamma)
+        ns.load_state_dict(sch.state_dict())
+        for g, lr in zip(new_opt.param_groups, lrs):
+            g["lr"] = lr
+        assert ns.last_epoch == sch.last_epoch
+        sch.optimizer = new_opt       # a caller still holding the old object at least drives the live optimiser's lr
+        return ns
+    sch.optimizer = new_opt
+    return sch
+
+
 class SinNeRFSystem(nn.Module):
     def __init__(self, hparams=None, **kw):
         super().__init__()
@@ -189,16 +209,7 @@ class SinNeRFSystem(nn.Module):
         # the wrapper around optimizer.step, `_opt_called` -- bound to the discarded torch.optim.Adam): same milestones / gamma,
         # resumed at the epoch the old one had reached.  Lists configure_optimizers() returned earlier still hold the old pair:
         # re-read `self.optimizer` / `self._schedulers` (or call configure_optimizers() again) after .to(device)
-        rebuilt = []
-        for sch in getattr(self, "_schedulers", []):
-            if isinstance(sch, torch.optim.lr_scheduler.MultiStepLR):
-                ns = torch.optim.lr_scheduler.MultiStepLR(new, milestones=sorted(sch.milestones.elements()), gamma=sch.gamma,
-                                                          last_epoch=sch.last_epoch)
-                sch.optimizer = new       # a caller still holding the old object at least drives the live optimiser's lr
-            else:
-                sch.optimizer = new
-                ns = sch
-            rebuilt.append(ns)
+        rebuilt = [rebuild_scheduler(sch, new) for sch in getattr(self, "_schedulers", [])]
         if rebuilt:
             self._schedulers = rebuilt
         self.optimizer, self._flat = new, new.grads

@@ -1,0 +1,112 @@
+"""Host-side logic that needs no GPU: configuration refusals (there is no torch-op second backend), the learning-rate schedule
+surviving the optimiser upgrade of ``SinNeRFSystem._ensure_flat_optimizer``, the checkpoint key filter."""
+import os
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def test_other_layer_configurations_are_refused_at_construction():
+    """models/nerf.py:47-50 accepts any D / W / skips / input widths; only the one both call sites build exists in HIP."""
+    import sinnerf_amd
+    sinnerf_amd.NeRF()                                                       # the defaults ARE the supported configuration
+    sinnerf_amd.NeRF(8, 256, 63, 27, [4], True)
+    for kw in (dict(D=4), dict(W=128), dict(skips=[2]), dict(skips=[]), dict(in_channels_xyz=39), dict(in_channels_dir=15)):
+        with pytest.raises(NotImplementedError, match="D=8, W=256"):
+            sinnerf_amd.NeRF(**kw)
+    with pytest.raises(ValueError, match="compute dtype"):
+        sinnerf_amd.NeRF(compute_dtype="fp16")
+
+
+def test_no_torch_op_backend_in_the_package():
+    """the product package holds no transcription of the reference's op sequence: `sinnerf_amd.generic` is gone, and neither the
+    renderer nor the network imports torch.nn.functional / calls a torch op sequence for the MLP"""
+    import sinnerf_amd
+    import importlib
+    with pytest.raises(ImportError):
+        importlib.import_module("sinnerf_amd.generic")
+    pkg = os.path.dirname(sinnerf_amd.__file__)
+    for name in ("rendering.py", "nerf.py", "autograd.py"):
+        src = open(os.path.join(pkg, name)).read()
+        for needle in ("torch.nn.functional", "F.linear", "torch.cumprod", "torch.searchsorted", "FORCE_GENERIC", "from oracle", "import oracle"):
+            assert needle not in src, (name, needle)
+
+
+def test_embedding_verdict_is_cached_and_follows_the_bands():
+    import sinnerf_amd
+    from sinnerf_amd import rendering
+    e = [sinnerf_amd.Embedding(3, 10), sinnerf_amd.Embedding(3, 4)]
+    assert rendering._fused_embeddings(e)
+    key0 = e[0]._sn_pow2_verdict[0]
+    assert rendering._fused_embeddings(e) and e[0]._sn_pow2_verdict[0] == key0          # second call: the cached verdict
+    assert not rendering._fused_embeddings([sinnerf_amd.Embedding(3, 10, logscale=False), e[1]])
+    assert not rendering._fused_embeddings([sinnerf_amd.Embedding(3, 4), e[1]])          # right bands, wrong count
+    assert not rendering._fused_embeddings([e[1], e[0]])
+    e[0].freq_bands.mul_(2.0)                                                             # in place: _version moves, verdict re-taken
+    assert not rendering._fused_embeddings(e)
+    with pytest.raises(NotImplementedError, match="Embedding"):
+        rendering._check_embeddings(e)
+
+
+def _lr_trace(sched, opt, n):
+    out = []
+    for _ in range(n):
+        opt.step()
+        sched.step()
+        out.append((sched.last_epoch, opt.param_groups[0]["lr"]))
+    return out
+
+
+@pytest.mark.parametrize("advance", [0, 1, 2, 3, 4])
+def test_rebuilt_scheduler_continues_the_same_schedule(advance):
+    """MultiStepLR(new, ..., last_epoch=old.last_epoch) resumed one epoch ahead -- every milestone of the
+    reference schedule (utils/__init__.py:34-36) fired a step early.  The rebuilt scheduler must sit at the old epoch with the
+    old lr and then produce the very trajectory an un-rebuilt one does."""
+    from sinnerf_amd.system import rebuild_scheduler
+    def make():
+        p = [torch.nn.Parameter(torch.zeros(3))]
+        p[0].grad = torch.zeros(3)
+        opt = torch.optim.Adam(p, lr=5e-4)
+        return opt, torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[3, 5], gamma=0.1)
+    opt_a, sch_a = make()                          # never rebuilt
+    opt_b, sch_b = make()                          # rebuilt after `advance` epochs
+    _lr_trace(sch_a, opt_a, advance)
+    _lr_trace(sch_b, opt_b, advance)
+    p2 = [torch.nn.Parameter(torch.zeros(3))]
+    p2[0].grad = torch.zeros(3)
+    g = opt_b.param_groups[0]
+    new = torch.optim.Adam(p2, lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"])
+    new.param_groups[0]["initial_lr"] = g["initial_lr"]
+    ns = rebuild_scheduler(sch_b, new)
+    assert ns is not sch_b and ns.optimizer is new
+    assert ns.last_epoch == sch_a.last_epoch == advance
+    assert new.param_groups[0]["lr"] == opt_a.param_groups[0]["lr"]
+    assert ns.get_last_lr() == sch_a.get_last_lr()
+    assert _lr_trace(ns, new, 7) == _lr_trace(sch_a, opt_a, 7)
+
+
+def test_checkpoint_key_filter(tmp_path):
+    """utils/__init__.py:60-83: select one sub-module's entries, strip '<name>.', drop ignored prefixes; accepts a Lightning
+    checkpoint, a bare state dict, or a path to either."""
+    from sinnerf_amd.ckpt import extract_model_state_dict, load_ckpt
+    t = lambda v: torch.full((2,), float(v))
+    sd = {"nerf_coarse.sigma.weight": t(1), "nerf_coarse.rgb.0.bias": t(2), "nerf_fine.sigma.weight": t(3), "discriminator.conv.weight": t(4)}
+    for ck in (sd, {"state_dict": sd, "epoch": 3}):
+        got = extract_model_state_dict(ck, "nerf_coarse")
+        assert set(got) == {"sigma.weight", "rgb.0.bias"} and got["sigma.weight"][0] == 1
+        assert set(extract_model_state_dict(ck, "nerf_coarse", prefixes_to_ignore=["rgb"])) == {"sigma.weight"}
+        assert set(extract_model_state_dict(ck, "nerf_fine")) == {"sigma.weight"}
+        assert extract_model_state_dict(ck, "model") == {}
+    path = os.path.join(tmp_path, "x.ckpt")
+    torch.save({"state_dict": sd}, path)
+    assert set(extract_model_state_dict(path, "nerf_fine")) == {"sigma.weight"}
+    lin = torch.nn.Linear(2, 1)
+    load_ckpt(lin, {"m.bias": torch.tensor([7.0])}, model_name="m")             # missing entries keep their values
+    assert lin.bias.item() == 7.0
+    with pytest.raises(RuntimeError):
+        load_ckpt(lin, {"m.nope": torch.tensor([7.0])}, model_name="m")          # unknown entries fail in load_state_dict

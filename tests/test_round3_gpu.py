@@ -353,55 +353,33 @@ def test_hand_scheduled_training_kernels_fuzz_and_determinism():
         assert sig == first and torch.equal(new[1], ref[0]) and torch.equal(new[2], ref[1]), rep
 
 
-def test_general_configurations_run_on_the_device_and_match_the_oracle():
-    """The reference's constructors are more general than the fused configuration (models/nerf.py:47-50, :8-22): another layer
-    shape, other embeddings and more than 1024 samples per ray go through sinnerf_amd/generic.py (stock PyTorch-ROCm ops on the
-    device) -- same results as the oracle, differentiable, state_dict keys of the reference."""
+def test_unsupported_configurations_are_refused_loudly():
+    """One configuration exists in HIP -- NeRF(8, 256, 63, 27, [4]) with Embedding(3, 10) / Embedding(3, 4), <= 1024 samples per ray
+    (models/sinnerf.py:133-141, eval.py:134-137).  Everything else the reference's constructors accept (models/nerf.py:47-50, :8-22)
+    raises NotImplementedError naming that configuration; nothing falls back to torch ops."""
     import sinnerf_amd
-    from sinnerf_amd import rendering
     d = dev()
-    # (1) NeRF(D=4, W=128, skips=[2]) stand-alone against the oracle's nerf_forward with the same layer configuration
-    torch.manual_seed(0)
-    m = sinnerf_amd.NeRF(D=4, W=128, skips=[2], use_new_activation=True).to(d)
-    assert not m.fused and "xyz_encoding_3.0.weight" in m.state_dict() and m.state_dict()["xyz_encoding_3.0.weight"].shape == (128, 128 + 63)
-    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
-    x = np.random.RandomState(0).standard_normal((300, 90)).astype(np.float32)
-    got = m(torch.from_numpy(x).to(d))
-    ref = O.nerf_forward(params, x, D=4, W=128, skips=(2,))
-    assert got.shape == (300, 4) and np.abs(got.detach().cpu().numpy() - ref).max() <= 2e-5
-    got.square().mean().backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
-    with pytest.raises(NotImplementedError):
-        m.packed()
-    # (2) the general render on the FUSED configuration equals the oracle too (perturb, noise, disparity sampling, injected draws)
-    mc, pc = make_model(0, True)
-    mf, pf = make_model(1, True)
-    rays = O.lego_rays(400, 400, seed=0)[::2503][:48]
-    n = rays.shape[0]
-    r = np.random.RandomState(5)
-    rng = {"perturb": r.uniform(0, 1, (n, 24)).astype(np.float32), "noise_coarse": r.standard_normal((n, 24)).astype(np.float32),
-           "u": r.uniform(0, 1, (n, 40)).astype(np.float32), "noise_fine": r.standard_normal((n, 64)).astype(np.float32)}
-    order = [("rand", rng["perturb"]), ("randn", rng["noise_coarse"]), ("rand", rng["u"]), ("randn", rng["noise_fine"])]
-    rendering.FORCE_GENERIC = True
-    try:
-        with injected_rng(order) as left, torch.no_grad():
-            res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays).to(d), 24, True, 1.0, 0.5, 40, 4096, True)
-            assert not left
-    finally:
-        rendering.FORCE_GENERIC = False
-    ref = O.render_rays([pc, pf], rays, 24, True, 1.0, 0.5, 40, 1 << 19, True, False, rng=rng)
-    from tests.helpers import check_render
-    check_render({k: v.cpu().numpy() for k, v in res.items()}, ref, tag="generic", opa=5e-3, rel=5e-3)
-    # (3) other embeddings and 1100 samples per ray: runs, finite, right shapes, gradients flow
-    emb = [sinnerf_amd.Embedding(3, 6), sinnerf_amd.Embedding(3, 2)]
-    g = [sinnerf_amd.NeRF(D=4, W=64, in_channels_xyz=39, in_channels_dir=15, skips=[2], use_new_activation=False).to(d) for _ in range(2)]
-    out = sinnerf_amd.render_rays(g, emb, torch.from_numpy(rays).to(d), 16, False, 1.0, 1.0, 8, 4096, False)
-    assert out["rgb_fine"].shape == (n, 3) and out["opacity_fine"].shape == (n, 24)
-    (out["rgb_fine"].mean() + out["depth_coarse"].mean()).backward()
-    assert all(p.grad is not None for p in g[1].parameters())
-    with torch.no_grad():
-        big = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays[:4]).to(d), 1100, False, 0, 0, 0, 32768, True)
-    assert big["opacity_coarse"].shape == (4, 1100) and torch.isfinite(big["rgb_coarse"]).all()
+    mc, _ = make_model(0, True)
+    mf, _ = make_model(1, True)
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=0)[::2503][:8]).to(d)
+    with pytest.raises(NotImplementedError, match="D=8, W=256"):
+        sinnerf_amd.NeRF(D=4, W=128, skips=[2])
+    for emb in ([sinnerf_amd.Embedding(3, 6), sinnerf_amd.Embedding(3, 4)],
+                [sinnerf_amd.Embedding(3, 10), sinnerf_amd.Embedding(3, 2)],
+                [sinnerf_amd.Embedding(3, 10, logscale=False), sinnerf_amd.Embedding(3, 4)]):
+        with pytest.raises(NotImplementedError, match="Embedding"):
+            sinnerf_amd.render_rays([mc, mf], emb, rays, 16, False, 0, 0, 8, 4096, True)
+    with pytest.raises(NotImplementedError, match="samples per ray"):
+        sinnerf_amd.render_rays([mc, mf], embeddings(), rays, 1100, False, 0, 0, 0, 32768, True)
+    with torch.no_grad():                                  # ... and the boundary case still renders
+        big = sinnerf_amd.render_rays([mc, mf], embeddings(), rays[:4], 1024, False, 0, 0, 0, 32768, True)
+    assert big["opacity_coarse"].shape == (4, 1024) and torch.isfinite(big["rgb_coarse"]).all()
+    # the embedding verdict is cached per object (no per-call host conversions), and follows the bands when they change
+    e = embeddings()
+    from sinnerf_amd import rendering
+    assert rendering._fused_embeddings(e) and e[0]._sn_pow2_verdict[1] is True
+    e[0].freq_bands = e[0].freq_bands * 1.5
+    assert not rendering._fused_embeddings(e)
 
 
 # ---- SN_DTYPE_EMB_BF16: the embedded inputs stored as the bf16 operands, in the kernel's K-slot order ---------------------------------
