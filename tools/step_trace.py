@@ -1,5 +1,5 @@
 """five bf16 training steps of the 4096-ray lego patch through SinNeRFSystem.train_step (eager or graph=True via argv[1] == 'graph');
-run under `rocprofv3 --kernel-trace` to see what one step is made of (tools/r3_run13.sh summarises the last step)"""
+run under `rocprofv3 --kernel-trace` to see what one step is made of (tools/summarize_prof.py summarises the trace)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle_np as O
