@@ -97,17 +97,84 @@ def roofline_record(dtype, n_rays, NS, NI, ms_fine, ms_coarse, ms_step, traffic=
             "mlp_share_of_step": (ms_fine + ms_coarse) / ms_step}
 
 
-def pmc_traffic(n_points, dtype):
-    """HBM bytes of the fine-pass launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, tools/summarize_prof.py); PMC cannot be sampled from inside the process."""
+def kernel_sources_sha():
+    """sha256 over the kernel sources and their generators (what a committed PMC profile was measured ON): a profile stamped with a
+    different hash describes other kernels and is refused.  (The GPU box has no .git: a commit id cannot be checked there.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(REPO, "sinnerf_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "sinnerf_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(REPO, "tools", "gen_*.py")) + [os.path.join(REPO, "sinnerf_amd", "csrc", "Makefile")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def live_pmc_traffic(args, n_points, timeout=240):
+    """HBM bytes of the fine-pass launch, measured BY THIS RUN: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate passes,
+    they do not fit one; --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a child `bench.py --steps 1 --no-extra` of the
+    same workload; the longest mlp_fwd dispatch of each pass is the fine pass.  FETCH_SIZE is doubled (gfx950 tallies wide coalesced
+    reads at half size), both are KiB.  Returns (bytes, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="sn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("WORLD_SIZE", None)
+    try:
+        for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", cnt, "--pmc", cnt, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-extra", "--no-cpu-baseline", "--no-pmc", "--dtype", args.dtype,
+                   "--hw", str(args.hw[0]), str(args.hw[1]), "--n-importance", str(args.n_importance), "--full-json", os.path.join(tmp, "child.json")]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            best = (-1.0, None)
+            for f in glob.glob(os.path.join(tmp, "**", cnt + "_counter_collection.csv"), recursive=True):
+                per = {}
+                for r in csv.DictReader(open(f)):
+                    if "mlp_fwd" not in r["Kernel_Name"] or r["Counter_Name"] != cnt:
+                        continue
+                    d = per.setdefault(r["Dispatch_Id"], [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), 0.0])
+                    d[1] += float(r["Counter_Value"])
+                for dur, val in per.values():
+                    if dur > best[0]:
+                        best = (dur, val)
+            if best[1] is None:
+                return None, "no mlp_fwd dispatch in the %s pass" % cnt
+            out[cnt] = best[1] * 1024.0
+        total = 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]
+        return total, ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes over a 1-step child of this "
+                       "command), fine-pass dispatch: 2 x %.0f B fetched (gfx950 correction) + %.0f B written; algorithmic %d B"
+                       % (out["FETCH_SIZE"], out["WRITE_SIZE"], n_points * 20))
+    except Exception as e:                  # noqa: BLE001
+        return None, "live PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_traffic(n_points, dtype, args=None):
+    """`roofline.traffic`: HBM bytes of the fine-pass launch.  Measured live (live_pmc_traffic) unless --no-pmc; otherwise / on failure
+    the committed profile is used ONLY IF it was measured on these kernel sources (kernel_sources_sha) -- a stale profile yields null."""
+    why = "--no-pmc"
+    if args is not None and not args.no_pmc:
+        got, why = live_pmc_traffic(args, n_points)
+        if got is not None:
+            return got, why
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
         if tj.get("points") == n_points and dtype == "fp32":
-            return tj["hbm_bytes"], "bytes/launch from %s measured at git %s, NOT by this run (algorithmic %d)" % (
-                tj["source"], tj.get("git_head", "unstamped"), tj["algorithmic_bytes"])
+            if tj.get("kernel_sources_sha") == kernel_sources_sha():
+                return tj["hbm_bytes"], "bytes/launch from %s (git %s, kernel sources %s = this tree's), NOT by this run [%s] (algorithmic %d)" % (
+                    tj["source"], tj.get("git_head", "unstamped"), tj["kernel_sources_sha"], why, tj["algorithmic_bytes"])
+            return None, "no traffic: %s; the committed profile %s was measured on other kernel sources (%s, this tree: %s)" % (
+                why, tj.get("source"), tj.get("kernel_sources_sha", "unstamped"), kernel_sources_sha())
     except Exception:                       # noqa: BLE001
         pass
-    return None, None
+    return None, "no traffic: %s; no committed profile for this workload" % why
 
 
 def train_step_record(O, dev, dtype, rays, NS, NI, reps=10):
@@ -163,9 +230,13 @@ def train_hbm_roofline(ms_per_step, n_points):
         pj = json.load(open(path))
         k = pj["kernels"]
         per_pt = sum(v["bytes_per_point"] for name, v in k.items() if v.get("step", "bf16" if "bf16" in name else "fp32") == "bf16")
-        traffic = per_pt * n_points
-        note = "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/%s, measured at git %s, NOT by this run)" % (
-            os.path.basename(path), pj.get("git_head", "unstamped"))
+        if pj.get("kernel_sources_sha") == kernel_sources_sha():
+            traffic = per_pt * n_points
+            note = "PMC bytes/point of the bf16 forward, chain and weight-gradient launches x points (profiles/%s, git %s, kernel sources %s = this tree's; NOT by this run)" % (
+                os.path.basename(path), pj.get("git_head", "unstamped"), pj["kernel_sources_sha"])
+        else:
+            note = "no traffic: profiles/%s was measured on other kernel sources (%s, this tree: %s)" % (
+                os.path.basename(path), pj.get("kernel_sources_sha", "unstamped"), kernel_sources_sha())
     except Exception:                               # noqa: BLE001
         pass
     alg = TRAIN_BF16_BYTES_PER_POINT * n_points
@@ -249,6 +320,96 @@ def train_cfg_record(O, dev, dtype, cfg, steps=3, warmup=2):
     return rec
 
 
+class SetupFailed(RuntimeError):
+    """a multi-rank record's collective-free setup failed on SOME rank: every rank skips the record (agreed by all-reduce)"""
+
+
+def setup_agreed(setup, dev, world):
+    """Run the collective-FREE part of a multi-rank record (models, batches: what can run out of memory) and let all ranks agree on
+    whether it worked before any of them enters a collective: a rank that failed alone would otherwise leave the others blocked in
+    the record's first all-reduce until the driver's timeout.  Exceptions BEHIND this point propagate: a failure inside
+    the collective-bearing part is fatal for the whole job, with a traceback, instead of a hang."""
+    obj, err = None, None
+    try:
+        obj = setup()
+    except AssertionError:
+        raise
+    except Exception as e:                          # noqa: BLE001
+        err = repr(e)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([0 if err else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if not bool(t.item()) and err is None:
+            err = "setup failed on another rank"
+    if err:
+        raise SetupFailed(err)
+    return obj
+
+
+def train_cfg3_full_record(O, dev, dtype="bf16", steps=8, warmup=3):
+    """BASELINE configs[2] AS NAMED -- "llff/room 504x378 patch 63x84 sW/sH=4 full SinNeRF losses, bf16" -- on what is runnable offline:
+    the llff four-render step with the ADVERSARIAL term through the reference's UNMODIFIED models/discriminator.py (staged into
+    oracle/_ref by build(); sinnerf.py:143-145 with --patch_size unset as in the README's LLFF commands, hinge loss, dis_weight 0.01 =
+    README "Step 2") and BOTH optimiser passes per batch (pytorch-lightning 0.10 calls training_step once per optimiser, sinnerf.py:271):
+    pass 0 = four renders with gradients + -mean(D(side patch)) + flat all-reduce + Adam; pass 1 = one no-grad side render, hinge D loss,
+    D backward, opt_d.  The discriminator stays on stock PyTorch-ROCm (north_star); the DINO-ViT term (sinnerf.py:332-339) needs weights
+    from the network and is not runnable offline.  Reports the whole step and the share of it spent on the HIP path (the same step with
+    the MSE stand-in for the side loss + the no-grad side render, both timed here)."""
+    from oracle import stage_ref
+    from sinnerf_amd.system import SinNeRFSystem
+    if not stage_ref.discriminator_available():
+        return {"error": "oracle/_ref/models/discriminator.py not staged on this box (build() stages it where /root/reference exists)"}
+    dmod = stage_ref.load_discriminator()
+    what, white_back = TRAIN_CFGS["train_cfg3"]
+    psx, psy = 63, 84
+
+    def make(with_d):
+        torch.manual_seed(7)
+        sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=white_back, depth_weight=1.0,
+                             dis_weight=0.01 if with_d else 0.0)
+        if with_d:
+            sysm.attach_discriminator(dmod.Discriminator(conditional=False, policy="color,cutout", imsize=-1), patch_hw=(psx, psy))
+        sysm = sysm.to(dev)
+        sysm.configure_optimizers()
+        return sysm
+    batch = train_cfg_batch(O, dev, "train_cfg3")
+    batch["real_patch"] = torch.rand((1, 3, psx, psy), device=dev)
+    n_rays = sum(batch[k].shape[0] for k in ("rays", "rays_full", "rays_side", "rays_proj"))
+
+    def timed(fn, n, w):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, out
+    np.random.seed(0)
+    full = make(True)
+    t_full, (out_g, out_d) = timed(lambda: full.train_step_adversarial(batch), steps, warmup)
+    assert torch.isfinite(out_g["loss"]).item() and torch.isfinite(out_d["loss"]).item()
+    side = batch["rays_side"].reshape(-1, 8)
+
+    def side_render():
+        with torch.no_grad():
+            return full(side)
+    t_side, _ = timed(side_render, steps, 2)
+    plain = make(False)
+    t_plain, _ = timed(lambda: plain.train_step(batch), steps, warmup)
+    d_params = sum(p.numel() for p in full.D.parameters())
+    pts = n_rays * 192
+    return {"workload": what + " + hinge GAN through the reference Discriminator (imsize=-1: %d parameters, logits (1,1,12,18)), both optimiser passes" % d_params,
+            "dtype": dtype, "rays_per_step": n_rays, "ms_per_step": t_full * 1e3, "train_rays_per_s": n_rays / t_full,
+            "hip_path_ms": (t_plain + t_side) * 1e3, "hip_path_share": (t_plain + t_side) / t_full,
+            "generator_pass_standin_ms": t_plain * 1e3, "side_render_nograd_ms": t_side * 1e3,
+            "discriminator_and_glue_ms": (t_full - t_plain - t_side) * 1e3,
+            "losses": "pass 0: MSE(rays) + MSE(full patch) + SL1 depth(rays, proj) + 0.01 x hinge G loss; pass 1: hinge D loss on real patch / detached side render",
+            "vit": "not runnable offline (DINO weights)", "loss_g": float(out_g["loss"].detach()), "loss_d": float(out_d["loss"].detach()),
+            "roofline": train_hbm_roofline(t_plain * 1e3, pts) if dtype == "bf16" else None}
+
+
 def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2, graph=False):
     """The multi-GPU training path of SURVEY §8e: replicas (broadcast at start), every rank draws its OWN 4096-ray patch,
     fwd + loss + bwd, ONE all-reduce (mean) of the flat 1 191 688-float gradient buffer over RCCL, fused Adam on the flat
@@ -256,11 +417,13 @@ def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2, graph=False):
     events around the collective, and asserts the replicas are still bit-identical afterwards."""
     import torch.distributed as dist
     from sinnerf_amd.system import SinNeRFSystem
-    torch.manual_seed(1234 + rank)                               # replicas start DIFFERENT; setup_distributed() fixes that
-    sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=True).to(dev)
+    def setup():
+        torch.manual_seed(1234 + rank)                           # replicas start DIFFERENT; setup_distributed() fixes that
+        sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=True).to(dev)
+        rays = torch.from_numpy(O.lego_rays(400, 400, seed=100 + rank)[::39][:4096]).to(dev)      # this rank's patch
+        return sysm, rays, {"rays": rays, "rgbs": torch.rand((rays.shape[0], 3), device=dev)}
+    sysm, rays, batch = setup_agreed(setup, dev, world)
     flat = sysm.setup_distributed()
-    rays = torch.from_numpy(O.lego_rays(400, 400, seed=100 + rank)[::39][:4096]).to(dev)      # this rank's patch
-    batch = {"rays": rays, "rgbs": torch.rand((rays.shape[0], 3), device=dev)}
     for _ in range(warmup):
         sysm.train_step(batch, graph=graph)
     flat.profile = []
@@ -302,7 +465,7 @@ def train_dp_leg(O, dev, dtype, rank, world, steps, warmup=2, graph=False):
 
 # ---- the ONE JSON line: the driver keeps the last 8 KB of stdout, so the line stays well below that -----------------------------
 LINE_BUDGET = 7000
-_KEEP_STR = {"unit", "dtype", "bound", "kind", "error", "scaling", "data", "metric", "all_reduce_backend", "rccl_version"}
+_KEEP_STR = {"unit", "dtype", "bound", "kind", "error", "scaling", "data", "metric", "all_reduce_backend", "rccl_version", "vit"}
 
 
 def _sig(x, n=5):
@@ -313,18 +476,25 @@ def _sig(x, n=5):
     return float("%.*g" % (n, x))
 
 
-def _slim(v, top=False):
+_ROOFLINE_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_tflops", "frac_of_achievable", "avg_launch_ms")
+_DROP_IN_RECORDS = {"thread_calibration_rays_per_s", "flop_per_launch", "algorithmic_bytes_per_step", "replicas_identical_after",
+                    "all_reduce_bytes", "optimizer", "launch", "losses", "peak_tflops", "host_cores", "roofline_rays_per_s_per_gpu",
+                    "renders_per_step", "points_per_step", "per_rank_tflops", "rays_per_rank_per_step", "loss", "peak_tflops",
+                    "frac_of_fp32_mfma_peak", "bound", "steps", "gathered_rows_on_rank0", "rccl_version"}
+
+
+def _slim(v, top=False, key=None):
     """numbers to 5 significant digits; inside secondary records prose strings go (the full record is in --full-json)"""
     if isinstance(v, dict):
         out = {}
+        if key == "roofline" and not top:
+            v = {k: x for k, x in v.items() if k in _ROOFLINE_KEEP and x is not None}
         for k, x in v.items():
             if isinstance(x, str) and not top and k not in _KEEP_STR:
                 continue
-            if k in ("thread_calibration_rays_per_s", "flop_per_launch", "algorithmic_bytes_per_step", "replicas_identical_after",
-                     "all_reduce_bytes", "optimizer", "launch", "losses", "peak_tflops", "host_cores", "roofline_rays_per_s_per_gpu"):
-                if not top:
-                    continue
-            out[k] = _slim(x)
+            if k in _DROP_IN_RECORDS and not top and key != "roofline":
+                continue
+            out[k] = _slim(x, key=k)
         return out
     if isinstance(v, (list, tuple)):
         return [_slim(x) for x in v]
@@ -346,11 +516,17 @@ def compact_line(res):
         cb = {k: v for k, v in res["cpu_baseline"].items() if k != "thread_calibration_rays_per_s"}
         head["cpu_baseline"] = {k: (_sig(v) if not isinstance(v, str) else v[:200]) for k, v in cb.items()}
     rec = dict(res.get("records", {}))
-    order = ["bf16", "fp32", "bf16x3", "config5_bf16", "config5_sharded", "train_cfg4_dp", "config5_bf16x3", "config5_fp32",
-             "train_cfg2_bf16", "train_cfg2_fp32", "train_cfg2_bf16x3"]
+    # priority: the other arithmetics of the headline frame, then every NAMED BASELINE config (configs[2..4]: the training step shapes in
+    # bf16 -- config 3 also with the discriminator -- and the 800x800 frame), the GPU-side baseline, then the remaining precisions of the
+    # same shapes; the per-stage / data-parallel legs that repeat information go last (train_dp_fp32 is the first to be dropped)
+    order = ["bf16", "fp32", "bf16x3", "config5_bf16", "config5_sharded", "train_cfg4_dp",
+             "train_cfg2_fp32", "train_cfg3_bf16", "train_cfg3_full_bf16", "train_cfg4_bf16", "train_cfg2_bf16", "train_cfg2_bf16x3"]
+    late = ["train_cfg3_fp32", "train_cfg4_fp32", "config5_bf16x3", "config5_fp32"]
     prio = [("records", k) for k in order if k in rec]
-    prio += [(None, k) for k in ("train_dp", "train_dp_graph", "torch_eager_gpu_baseline", "train_step_bf16", "train_step", "train_step_bf16x3", "train_dp_fp32") if k in res]
-    prio += [("records", k) for k in rec if k not in order]
+    prio += [(None, k) for k in ("torch_eager_gpu_baseline", "train_dp", "train_step_bf16x3") if k in res]
+    prio += [("records", k) for k in late if k in rec]
+    prio += [("records", k) for k in rec if k not in order and k not in late]
+    prio += [(None, k) for k in ("train_step_bf16", "train_step", "train_dp_graph", "train_dp_fp32") if k in res]
     out, dropped = dict(head), []
     out["records"] = {}
     for where, k in prio:
@@ -377,11 +553,14 @@ def config5_sharded_record(O, dev, rank, world, barrier, dist, steps=2, warmup=1
     import sinnerf_amd
     from sinnerf_amd import parallel
     H, W = hw
-    frame = O.lego_rays(H, W, seed=0)
-    lo, hi = parallel.shard_bounds(frame.shape[0], rank, world)
-    mine = torch.from_numpy(np.ascontiguousarray(frame[lo:hi])).to(dev)
-    models, _ = build_models(O, dev, dtype)
-    emb = [sinnerf_amd.Embedding(3, 10), sinnerf_amd.Embedding(3, 4)]
+
+    def setup():
+        frame = O.lego_rays(H, W, seed=0)
+        lo, hi = parallel.shard_bounds(frame.shape[0], rank, world)
+        mine = torch.from_numpy(np.ascontiguousarray(frame[lo:hi])).to(dev)
+        models, _ = build_models(O, dev, dtype)
+        return frame, lo, hi, mine, models, [sinnerf_amd.Embedding(3, 10), sinnerf_amd.Embedding(3, 4)]
+    frame, lo, hi, mine, models, emb = setup_agreed(setup, dev, world)
     dt, ms_fine, ms_coarse = time_render(models, emb, mine, 64, 128, steps, warmup, barrier)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -404,17 +583,20 @@ def config5_sharded_record(O, dev, rank, world, barrier, dist, steps=2, warmup=1
     return rec
 
 
-def train_cfg_dp_record(O, dev, dtype, cfg, rank, world, dist, steps=8, warmup=3):
+def train_cfg_dp_record(O, dev, dtype, cfg, rank, world, dist, steps=20, warmup=3):
     """BASELINE configs[3] as named: the dtu four-render step on EVERY rank (its own patches), then the ONE flat all-reduce and the
     fused Adam (SinNeRFSystem.train_step); per-step time = max over ranks, `all_reduce_us` from HIP events around the
     collective, replicas asserted identical afterwards."""
     from sinnerf_amd.system import SinNeRFSystem
     what, white_back = TRAIN_CFGS[cfg]
-    torch.manual_seed(77 + rank)
-    sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=white_back,
-                         depth_weight=1.0).to(dev)
+
+    def setup():
+        torch.manual_seed(77 + rank)
+        sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=white_back,
+                             depth_weight=1.0).to(dev)
+        return sysm, train_cfg_batch(O, dev, cfg, seed=31 * rank)
+    sysm, batch = setup_agreed(setup, dev, world)
     flat = sysm.setup_distributed()
-    batch = train_cfg_batch(O, dev, cfg, seed=31 * rank)
     n_rays = sum(batch[k].shape[0] for k in ("rays", "rays_full", "rays_side", "rays_proj"))
     for _ in range(warmup):
         out = sysm.train_step(batch)
@@ -532,6 +714,8 @@ def main():
     ap.add_argument("--n-importance", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline number + roofline only (used by the rocprof passes)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the two rocprofv3 PMC passes that measure roofline.traffic live "
+                                                            "(used by those passes themselves and by profiling runs of this script)")
     ap.add_argument("--cpu-rays", type=int, default=16384)
     ap.add_argument("--dist-backend", default="nccl", help="developer option: 'gloo' lets N ranks share one GPU for testing")
     ap.add_argument("--selftest-launcher", action="store_true", help="rendezvous + all-reduce only, no GPU work (CPU test)")
@@ -555,15 +739,34 @@ def main():
     if args.selftest_launcher:
         return launcher_selftest(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    n_dev = torch.cuda.device_count()
     if args.dist_backend != "nccl":
-        local = local % torch.cuda.device_count()
+        local = local % n_dev
+    else:
+        # fail fast and legibly (torchrun path too): RCCL cannot put two ranks on one device, and a LOCAL_RANK beyond the visible
+        # devices would otherwise surface as an opaque HIP error inside the first collective
+        assert n_dev >= world and local < n_dev, (
+            "rank %d: --gpus %d with backend nccl (RCCL) needs %d visible devices, found %d (LOCAL_RANK=%d; HIP_VISIBLE_DEVICES=%r) -- "
+            "use --dist-backend gloo to exercise the N-rank path on fewer devices"
+            % (rank, world, world, n_dev, local, os.environ.get("HIP_VISIBLE_DEVICES")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.dist_backend)          # "nccl" = RCCL
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool: RCCL fails with hipIpcGetMemHandle otherwise
+        # who is here, BEFORE the first collective (stderr: stdout carries rank 0's one JSON line) -- if the rendezvous or the first
+        # all-reduce hangs, the log says which ranks arrived, on which device, with which RCCL
+        print("[bench rank %d/%d] pid %d device cuda:%d (%s) of %d visible, backend %s, rccl %s, master %s:%s"
+              % (rank, world, os.getpid(), local, torch.cuda.get_device_name(local), n_dev, args.dist_backend, rccl_version(),
+                 os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")), file=sys.stderr, flush=True)
+        dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(minutes=10))          # "nccl" = RCCL
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)                                     # the first collective: its own line in the log, not a record's
+        assert int(seen.item()) == world, "first all-reduce saw %d ranks, expected %d" % (int(seen.item()), world)
+        print("[bench rank %d/%d] first all-reduce ok: %d ranks" % (rank, world, int(seen.item())), file=sys.stderr, flush=True)
 
     import sinnerf_amd
     from oracle import oracle_np as O          # inputs generator + cpu_baseline leg only
@@ -591,7 +794,7 @@ def main():
     if rank == 0:
         total_rays = n_rays * world * args.steps
         value = total_rays / dt
-        traffic, traffic_note = pmc_traffic(n_rays * (NS + NI), args.dtype)
+        traffic, traffic_note = pmc_traffic(n_rays * (NS + NI), args.dtype, args if world == 1 else None)
         res = {
             "metric": "rendered rays/sec (64+%d samples), lego %dx%d" % (NI, W, H),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -609,14 +812,19 @@ def main():
     # ---- the data-parallel training leg (every rank takes part; it is the only place a collective runs) ----------------
     if not args.no_extra:
         try:
-            # (a 3.5 ms step: 5 warm-up + >= 20 timed steps -- a 2 + 5 run measures 7 % of ramp-up, tools/dp_leg_time.py)
+            # (a 3.5 ms step: 5 warm-up + >= 20 timed steps -- a 2 + 5 run measures 7 % of ramp-up, tools/dp_leg_time.py; the
+            # all-reduce time is the mean over those >= 20 steps)
             dp_steps = max(20, min(args.steps, 100))
             leg = train_dp_leg(O, dev, "bf16", rank, world, steps=dp_steps, warmup=5)
             leg_graph = train_dp_leg(O, dev, "bf16", rank, world, steps=dp_steps, warmup=5, graph=True) if world == 1 else None
             leg32 = train_dp_leg(O, dev, "fp32", rank, world, steps=3) if world == 1 else None
         except AssertionError:
             raise
+        except SetupFailed as e:                    # agreed by every rank before any collective of the leg
+            leg, leg_graph, leg32 = {"error": repr(e)}, None, None
         except Exception as e:                      # noqa: BLE001
+            if world > 1:                           # inside the collective-bearing part: the other ranks are blocked in it -- fail the job, loudly
+                raise
             leg, leg_graph, leg32 = {"error": repr(e)}, None, None
         if rank == 0:
             res["train_dp"] = leg
@@ -633,10 +841,8 @@ def main():
                         ("train_cfg4_dp", lambda: train_cfg_dp_record(O, dev, "bf16", "train_cfg4", rank, world, dist))):
             try:
                 recs[key] = fn()
-            except AssertionError:
-                raise
-            except Exception as e:                  # noqa: BLE001
-                recs[key] = {"error": repr(e)}
+            except SetupFailed as e:                # every rank agreed to skip this record; anything else (a failure between
+                recs[key] = {"error": repr(e)}      # collectives) propagates and ends the job with a traceback instead of a hang
         if rank == 0:
             res["records"] = recs
 
@@ -692,6 +898,11 @@ def main():
                 except Exception as e:              # noqa: BLE001
                     records[cfg + "_" + dt_name] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+        try:
+            records["train_cfg3_full_bf16"] = train_cfg3_full_record(O, dev, "bf16")
+        except Exception as e:                      # noqa: BLE001
+            records["train_cfg3_full_bf16"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the reference's op sequence (models/rendering.py:126-335 + models/nerf.py) as stock torch ops on
@@ -774,24 +985,54 @@ def main():
             res["cpu_baseline"]["numpy_oracle_rays_per_s"] = ns.shape[0] / ndt
         except Exception as e:                      # noqa: BLE001
             res["cpu_baseline"]["numpy_oracle_rays_per_s"] = repr(e)
-        # the same op sequence as stock PyTorch-ROCm eager ops on this GPU: the "reference on the MI355X" figure SURVEY §8d
-        # asks for beside the CPU baseline.  Reported, never the target.
+        # the reference ITSELF run eagerly on this GPU through PyTorch-ROCm: the "reference on the MI355X" figure SURVEY §8d asks for
+        # beside the CPU baseline, and the only measurable stand-in for north_star's "reference PyTorch-CUDA rays/sec".  The staged,
+        # unmodified render_rays + NeRF modules with eval.py's OWN chunking: batched_inference slices rays by chunk = 1024*32*16
+        # (eval.py:92 -- the whole 160 000-ray frame is one call) and render_rays chunks POINTS by the same value (rendering.py:196).
+        # Reported, never the target.  (oracle/torch_ref.py, the port, only when oracle/_ref is not staged.)
         try:
-            tg = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p in params]
-            er = rays[:: max(1, n_rays // 16384)][:16384].contiguous()
+            if stage_ref.available():
+                gm, gemb = stage_ref.build_reference_models(params)
+                gm = [m.to(dev) for m in gm]
+                gkind, gchunk = "reference", 1024 * 32 * 16
+
+                def gpu_render(r):
+                    outs = [ref_rendering.render_rays(gm, gemb, r[i:i + gchunk], NS, False, 0, 0, NI, gchunk, True, test_time=False)
+                            for i in range(0, r.shape[0], gchunk)]                 # eval.py:94-110 (test_time=False, eval.py:107)
+                    return outs[-1]["rgb_fine"]
+                er = rays
+            else:
+                tg = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p in params]
+                gkind, gchunk = "port", 4096
+
+                def gpu_render(r):
+                    for i in range(0, r.shape[0], gchunk):
+                        o = T.render(tg, r[i:i + gchunk], NS, NI, True)
+                    return o["rgb_fine"]
+                er = rays[:: max(1, n_rays // 16384)][:16384].contiguous()
             with torch.no_grad():
-                T.render(tg, er[:1024], NS, NI, True)
+                gpu_render(er[:4096])
+                gpu_render(er)                                                       # warm: allocator pools at the full size
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for i in range(0, er.shape[0], 4096):
-                    T.render(tg, er[i:i + 4096], NS, NI, True)
+                reps = 2
+                for _ in range(reps):
+                    last = gpu_render(er)
                 torch.cuda.synchronize()
-            edt = time.perf_counter() - t1
-            res["torch_eager_gpu_baseline"] = {"value": er.shape[0] / edt, "unit": "rays/s", "kind": "port",
-                                               "sample": "%d rays of the same frame in chunks of 4096, stock torch fp32 ops on the same MI355X" % er.shape[0],
-                                               "speedup_of_value": res["value"] / (er.shape[0] / edt)}
-            if "bf16" in res.get("records", {}):
-                res["torch_eager_gpu_baseline"]["speedup_of_bf16_record"] = res["records"]["bf16"]["value"] / (er.shape[0] / edt)
+            edt = (time.perf_counter() - t1) / reps
+            assert bool(torch.isfinite(last).all())
+            ev = er.shape[0] / edt
+            res["torch_eager_gpu_baseline"] = {
+                "value": ev, "unit": "rays/s", "kind": gkind,
+                "sample": ("the UNMODIFIED reference render_rays + NeRF (oracle/_ref) on this MI355X through stock PyTorch-ROCm fp32 ops, the whole %d-ray "
+                           "frame per call with eval.py's chunk = %d (eval.py:92, rendering.py:196), test_time=False (eval.py:107), %d timed frames" % (er.shape[0], gchunk, reps))
+                          if gkind == "reference" else "%d rays in chunks of 4096, oracle/torch_ref.py (port) on this MI355X" % er.shape[0],
+                "speedup_of_value": res["value"] / ev}
+            for k in ("bf16", "bf16x3", "fp32"):
+                if k in res.get("records", {}) and "value" in res["records"][k]:
+                    res["torch_eager_gpu_baseline"]["speedup_of_%s_record" % k] = res["records"][k]["value"] / ev
+            del last
+            torch.cuda.empty_cache()
         except Exception as e:                      # noqa: BLE001
             res["torch_eager_gpu_baseline"] = {"error": repr(e)}
     if rank == 0:

@@ -152,7 +152,13 @@ int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, l
  * dtype SN_DTYPE_BF16_STATE: acts / g_acts are bf16 arrays; the ReLU masks come from the sign words sn_mlp_forward_train
  * left in slot 9 (see there), gradients leave as whole 128-byte rows.
  * slot_rows as for sn_mlp_forward_train (>= n_points rounded up to 128, 256 for bf16; rows >= n_points of slots' 256
- * columns are written as zeros, the caller zero-fills the rest of the pad rows).  Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.   */
+ * columns are written as zeros, the caller zero-fills the rest of the pad rows).  Weight gradients are the contractions  dW_l = g_l^T X_l  over points of these matrices with acts / emb.
+ * PAIRING RULE (all three training entry points): the state arrays of the arithmetics have the same shapes and byte sizes but NOT the
+ * same contents -- `acts` written by sn_mlp_forward_train(dtype D) may only be read by sn_mlp_backward_chain(D) and sn_weight_grads(D),
+ * `g_acts` written by sn_mlp_backward_chain(D) only by sn_weight_grads(D), with D one of {SN_DTYPE_F32 (also read by SN_DTYPE_BF16),
+ * SN_DTYPE_BF16_STATE, SN_DTYPE_BF16X3}.  The library cannot tell the layouts apart from the pointers: a mismatch (e.g. an x3 state
+ * handed to the SN_DTYPE_F32 chain) yields wrong gradients, not an error code.  SN_DTYPE_BF16X3 additionally requires slot_rows % 128 == 0
+ * (checked: SN_E_BADSHAPE).                                                                                                            */
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,
                           long n_points, long slot_rows, float* g_acts, float* g_out, void* stream);
 
@@ -174,7 +180,8 @@ int sn_dw_gemm(const void* tasks, int n_tasks, void* stream);
  * becomes two column ranges of the same gradient).
  *   acts, emb: as written by sn_mlp_forward_train; g_acts: as written by sn_mlp_backward_chain (pad rows zero);
  *   slot_rows: a multiple of 16; dtype: SN_DTYPE_F32 (fp32 MFMAs), SN_DTYPE_BF16 (bf16 operands, fp32 state) or
- *   SN_DTYPE_BF16_STATE (acts / g_acts stored as bf16);
+ *   SN_DTYPE_BF16_STATE (acts / g_acts stored as bf16) or SN_DTYPE_BF16X3 (the x3 state; see the PAIRING RULE at sn_mlp_backward_chain:
+ *   acts / g_acts must have been written with the SAME dtype);
  *   workspace: sn_weight_grads_workspace_bytes(slot_rows, dtype) bytes of DEVICE scratch (the K-split partials);
  *   grads: HOST array of SN_N_RAW_TENSORS device pointers in the order of sn_pack_weights' `raw` (NULL = not wanted);
  *   accumulate != 0: grads[i] += result (autograd's accumulation into an existing .grad), else grads[i] = result.        */

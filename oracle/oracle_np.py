@@ -416,9 +416,29 @@ def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None,
     (SN_DTYPE_BF16_STATE) -- every contraction sees BOTH operands rounded (the pre-activation gradients g_y are rounded once,
     when they are packed for the next transposed layer / stored; activations and weights as in the forward), accumulation
     stays wide; the two narrow transposed heads (rgb.0^T, sigma^T) are fp32 VALU work on unrounded values; the softplus
-    derivative is taken from the STORED activation, sigmoid(y2-1) = 1 - exp(-d), as the kernel does."""
+    derivative is taken from the STORED activation, sigmoid(y2-1) = 1 - exp(-d), as the kernel does.
+
+    ``operand_round="bf16x3"``: emulate the 3-TERM SPLIT backward of csrc/sn_mlp_bwd_bf16x3.hip + sn_dw.hip modes 5-7
+    (SN_DTYPE_BF16X3): every operand of every contraction -- pre-activation gradients, transposed weights, activations, embedded
+    inputs -- enters as its (hi, lo) bf16 pair (``bf16_split`` of the fp32 value) and a product  A.B  is  Ah.Bh + Al.Bh + Ah.Bl
+    (the Al.Bl term is dropped, 2^-16 relative); bias gradients are the column sums of hi + lo; heads and the softplus derivative
+    as in the bf16 emulation.  ``gy_out`` then receives the pre-activation gradients as the kernel STORES them (hi + lo)."""
     f8 = np.float64
-    rd = (lambda a: operand_round(np.asarray(a, F)).astype(f8)) if operand_round is not None else (lambda a: np.asarray(a, f8))
+    x3 = isinstance(operand_round, str) and operand_round == "bf16x3"
+    if x3:
+        def pair(a):
+            hi, lo = bf16_split(np.asarray(a, f8).astype(F))
+            return hi.astype(f8), lo.astype(f8)
+        rd = lambda a: sum(pair(a))                                          # the value a stored (hi, lo) pair decodes to
+        def mm(a, b, ta=False):                                              # a (.T) @ b with split operands, wide accumulation
+            (ah, al), (bh, bl) = pair(a), pair(b)
+            if ta:
+                ah, al = ah.T, al.T
+            return ah @ bh + al @ bh + ah @ bl
+    else:
+        rd = (lambda a: operand_round(np.asarray(a, F)).astype(f8)) if operand_round is not None else (lambda a: np.asarray(a, f8))
+        mm = lambda a, b, ta=False: (rd(a).T if ta else rd(a)) @ rd(b)
+    lowp = operand_round is not None
     g = {}
     x = cache["x"].astype(f8)
     input_xyz, input_dir = x[:, :in_xyz], x[:, in_xyz:]
@@ -431,39 +451,39 @@ def nerf_backward(params, cache, g_out, in_xyz=63, D=8, skips=(4,), gy_out=None,
         sg = 1.0 / (1.0 + np.exp(-cache["y3"].astype(f8)))
         g_y3 = g_rgb * sg * (1.0 - sg)
     d = cache["d"].astype(f8)
-    g["rgb.0.weight"], g["rgb.0.bias"] = rd(g_y3).T @ rd(d), rd(g_y3).sum(0)
+    g["rgb.0.weight"], g["rgb.0.bias"] = mm(g_y3, d, ta=True), rd(g_y3).sum(0)
     if gy_out is not None:
         gy_out["rgb"], gy_out["sigma"] = g_y3, g_sigma
     g_d = g_y3 @ params["rgb.0.weight"].astype(f8)
     if not new_act:
         g_y2 = g_d * (d > 0)                                                 # ReLU(inplace): g * [out > 0]
-    elif operand_round is not None:
+    elif lowp:
         g_y2 = g_d * (1.0 - np.exp(-d))
     else:
         g_y2 = g_d / (1.0 + np.exp(-(cache["y2"].astype(f8) - 1.0)))
     d_in = np.concatenate([cache["final"].astype(f8), input_dir], -1)
-    g["dir_encoding.0.weight"], g["dir_encoding.0.bias"] = rd(g_y2).T @ rd(d_in), rd(g_y2).sum(0)
-    g_final = (rd(g_y2) @ rd(params["dir_encoding.0.weight"]))[:, :256]
+    g["dir_encoding.0.weight"], g["dir_encoding.0.bias"] = mm(g_y2, d_in, ta=True), rd(g_y2).sum(0)
+    g_final = mm(g_y2, params["dir_encoding.0.weight"])[:, :256]
     if gy_out is not None:
-        gy_out["dir"], gy_out["final"] = g_y2, g_final
+        gy_out["dir"], gy_out["final"] = (g_y2, rd(g_final)) if x3 else (g_y2, g_final)
     h8 = cache[f"h{D}"].astype(f8)
-    g["xyz_encoding_final.weight"], g["xyz_encoding_final.bias"] = rd(g_final).T @ rd(h8), rd(g_final).sum(0)
-    g["sigma.weight"], g["sigma.bias"] = rd(g_sigma).T @ rd(h8), rd(g_sigma).sum(0)
-    g_h = rd(g_final) @ rd(params["xyz_encoding_final.weight"]) + g_sigma @ params["sigma.weight"].astype(f8)
+    g["xyz_encoding_final.weight"], g["xyz_encoding_final.bias"] = mm(g_final, h8, ta=True), rd(g_final).sum(0)
+    g["sigma.weight"], g["sigma.bias"] = mm(g_sigma, h8, ta=True), rd(g_sigma).sum(0)
+    g_h = mm(g_final, params["xyz_encoding_final.weight"]) + g_sigma @ params["sigma.weight"].astype(f8)
     for i in reversed(range(D)):
         h_out = cache[f"h{i+1}"]
         g_y = g_h * (h_out > 0)
         if gy_out is not None:
-            gy_out[f"l{i+1}"] = g_y
+            gy_out[f"l{i+1}"] = rd(g_y) if x3 else g_y
         if i == 0:
             xin = input_xyz
         else:
             xin = cache[f"h{i}"].astype(f8)
             if i in skips:
                 xin = np.concatenate([input_xyz, xin], -1)
-        g[f"xyz_encoding_{i+1}.0.weight"], g[f"xyz_encoding_{i+1}.0.bias"] = rd(g_y).T @ rd(xin), rd(g_y).sum(0)
+        g[f"xyz_encoding_{i+1}.0.weight"], g[f"xyz_encoding_{i+1}.0.bias"] = mm(g_y, xin, ta=True), rd(g_y).sum(0)
         if i > 0:
-            g_x = rd(g_y) @ rd(params[f"xyz_encoding_{i+1}.0.weight"])
+            g_x = mm(g_y, params[f"xyz_encoding_{i+1}.0.weight"])
             g_h = g_x[:, in_xyz:] if i in skips else g_x
     return g
 

@@ -178,6 +178,26 @@ def load_callers(patch=None):
     return ev, sn
 
 
+def discriminator_available():
+    return available() and all(os.path.isfile(os.path.join(DEST, f)) for f in ("models/discriminator.py", "models/diff_aug.py"))
+
+
+def load_discriminator():
+    """The reference's UNMODIFIED ``models/discriminator.py`` (+ ``models/diff_aug.py``; both need torch / numpy only) from
+    oracle/_ref: returns the module (``.Discriminator``, ``.DiffAugment``).  The discriminator is NOT on the hot path -- north_star
+    keeps it on stock PyTorch -- it is the reference-side consumer of the rendered side patch (``models/sinnerf.py:143-145, 445-487``)
+    that BASELINE configs[2] "full SinNeRF losses" names; bench.py's ``train_cfg3_full`` leg and tests/test_full_losses_gpu.py plug it
+    into ``SinNeRFSystem.side_loss``."""
+    if not discriminator_available():
+        raise FileNotFoundError("oracle/_ref does not hold models/discriminator.py (run oracle/stage_ref.py where /root/reference exists)")
+    load()                                              # makes `models` resolve to the staged package
+    sys.path.insert(0, DEST)
+    try:
+        return importlib.import_module("models.discriminator")
+    finally:
+        sys.path.remove(DEST)
+
+
 def build_reference_models(params_list):
     """The reference's own ``NeRF`` / ``Embedding`` objects carrying the given state dicts (list of {name: ndarray})."""
     import torch

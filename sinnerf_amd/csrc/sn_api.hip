@@ -222,8 +222,13 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
   const bool hand = dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256;   // the hand-scheduled kernel
   if (emb16 && !hand) return SN_E_UNSUPPORTED;                               // (the only one that writes the bf16 form of emb)
-  if (dtype == SN_DTYPE_BF16X3)                  // fp32-level forward on the bf16 MFMA, fp32 training state (as SN_DTYPE_F32 writes it)
+  // fp32-level forward on the bf16 MFMA.  Its training state is the "x3 state" of sn_layout.h -- slots 0..8 hold (hi, lo) bf16 PAIRS in
+  // the bytes of an fp32 row, slot 9 fp32 values + ReLU sign words -- NOT the array SN_DTYPE_F32 writes: only the SN_DTYPE_BF16X3 forms of
+  // sn_mlp_backward_chain / sn_weight_grads read it (include/sinnerf_hip.h "pairing rule")
+  if (dtype == SN_DTYPE_BF16X3) {
+    if (slot_rows % 128 != 0) return SN_E_BADSHAPE;           // whole 128-point tiles, as the header states
     return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows, (hipStream_t)stream);
+  }
   if (hand)
     return SN_HEADS(classic, sn_mlp_forward_bf16_t)(blob, rays, z_vals, n_points, n_samples, out, acts, emb, slot_rows, emb16, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32)
@@ -260,8 +265,12 @@ int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, co
   if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16_STATE && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
   const long tile = (dtype == SN_DTYPE_F32 || dtype == SN_DTYPE_BF16X3) ? 128 : 256;      // whole point tiles are written
   if (slot_rows < (n_points + tile - 1) / tile * tile) return SN_E_BADSHAPE;
-  if (dtype == SN_DTYPE_BF16X3)                  // fp32-level accuracy on the bf16 MFMA over the fp32 state (blob: *_bwd_bf16x3 table)
+  // fp32-level accuracy on the bf16 MFMA (blob: *_bwd_bf16x3 table).  acts MUST be the x3 state sn_mlp_forward_train(SN_DTYPE_BF16X3)
+  // wrote (masks from its sign words); g_acts leaves in the same layout ((hi, lo) pairs in slots 0..8) for sn_weight_grads(SN_DTYPE_BF16X3)
+  if (dtype == SN_DTYPE_BF16X3) {
+    if (slot_rows % 128 != 0) return SN_E_BADSHAPE;
     return SN_HEADS(classic, sn_mlp_backward_chain_bf16x3)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out, (hipStream_t)stream);
+  }
   if (dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256)         // the hand-scheduled kernel
     return SN_HEADS(classic, sn_mlp_backward_chain_bf16_t)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32)

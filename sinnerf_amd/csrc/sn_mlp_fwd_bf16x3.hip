@@ -17,10 +17,13 @@
 //   depend on each other; chain A starts from the bias, chain B from the inline constant 0, the epilogue adds them;
 // * the epilogue splits each fp32 result into its (hi, lo) bf16 pair for the next layer's B operands; the embeddings are the
 //   EXACT ones of the fp32 kernel (no angle doubling) split the same way; heads in fp32 on the VALU as everywhere.
-// STORE (training forward, SN_DTYPE_BF16X3 of sn_mlp_forward_train): additionally writes the fp32 activations of every layer
-// (acts[10][slot_rows][256], the values the next layer consumed BEFORE their hi/lo split) and the fp32 embedded inputs (emb) --
-// the fp32 training state of sn_mlp_fwd.hip, value for value at fp32 rounding level -- for the fp32 backward chain and weight
-// gradients.  Row-coalesced stores through per-wave staging tiles, four 1 KB row-group stores per finished tile dealt one per
+// STORE (training forward, SN_DTYPE_BF16X3 of sn_mlp_forward_train): additionally writes the training state in the "x3 state" layout of
+// sn_layout.h -- NOT the array SN_DTYPE_F32 writes, although it has the same shape and size: slots 0..8 hold every activation as the
+// (hi, lo) bf16 PAIR the next layer consumed (per 8 features 16 B of hi parts, then 16 B of lo parts, in the 1 KB an fp32 row takes),
+// slot 9 the fp32 dir_encoding outputs in columns [0, 128) and the ReLU SIGN WORDS of layers 1..8 in its unused half, emb the fp32
+// embedded inputs.  Only the SN_DTYPE_BF16X3 forms of sn_mlp_backward_chain / sn_weight_grads read it; handing it to an SN_DTYPE_F32
+// entry point (or an fp32 state to these) gives wrong gradients without an error (include/sinnerf_hip.h "pairing rule").
+// Row-coalesced stores through per-wave staging tiles, four 1 KB row-group stores per finished tile dealt one per
 // k-step behind the slab's DMA pieces; the sync points wait with a COUNTED vmcnt (the four youngest operations of a wave are those
 // stores) at a fence-less barrier, and the staging writes are inline asm -- the three measures sn_mlp_bf16.h documents for the
 // bf16-state kernels; at this kernel's slab time (48 MFMAs x 32 cycles) a store drain per slab would cost more than the slab.

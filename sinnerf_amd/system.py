@@ -27,7 +27,11 @@ from .rendering import render_rays
 
 DEFAULT_HPARAMS = dict(N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=1.0, chunk=32 * 1024,
                        lr=5e-4, weight_decay=0.0, decay_step=[20], decay_gamma=0.1, depth_weight=0.0, white_back=True,
-                       compute_dtype="fp32")
+                       compute_dtype="fp32",
+                       # the adversarial term of the reference's second training stage (opt.py:98,107; README "Step 2": 0.01).  It only
+                       # takes effect once a discriminator module is attached (attach_discriminator): the discriminator itself stays on
+                       # stock PyTorch (north_star) and is not part of this package
+                       dis_weight=0.0, dloss="hinge", patch_hw=None)
 
 
 
@@ -69,6 +73,52 @@ class SinNeRFSystem(nn.Module):
             self.models.append(self.nerf_fine)
         self.white_back = hp["white_back"]       # dataset property in the reference (blender/dtu True, llff False)
         self._flat = None
+        self.D = None                            # sinnerf.py:143-145: built by the reference when dis_weight > 0; here: attach_discriminator()
+
+    # ---- sinnerf.py:143-145, 207-208, 445-471 (dloss == 'hinge'): the hooks the discriminator plugs into --------------------------------
+    def attach_discriminator(self, D, dis_weight=None, patch_hw=None):
+        """Plug a discriminator (any ``nn.Module`` mapping a ``(1, 3, psx, psy)`` patch to logits -- the reference's
+        ``models/discriminator.py::Discriminator`` unchanged) into the patch step, as ``sinnerf.py:143-145`` does when
+        ``dis_weight > 0``.  ``patch_hw`` = (psx, psy) of the side patch (``real_patch.shape[-2:]``, sinnerf.py:281) when the batch
+        carries no ``real_patch``.  Call before ``configure_optimizers``: it then also returns ``opt_d`` (sinnerf.py:207-208)."""
+        self.D = D
+        if dis_weight is not None:
+            self.hparams.dis_weight = dis_weight
+        if patch_hw is not None:
+            self.hparams.patch_hw = tuple(patch_hw)
+        if self.hparams.dloss != "hinge":
+            raise NotImplementedError("dloss=%r: only the reference's default 'hinge' (opt.py:98) is mirrored" % (self.hparams.dloss,))
+        return self
+
+    def _side_patch(self, results_side, batch):
+        """``rearrange(results_side['rgb_fine'], '(b p q) c -> b c p q')`` of sinnerf.py:327-330 for b = 1"""
+        hw = tuple(batch["real_patch"].shape[-2:]) if "real_patch" in batch else self.hparams.patch_hw
+        if hw is None:
+            raise RuntimeError("the discriminator needs the patch shape: pass patch_hw=(psx, psy) or a batch with 'real_patch'")
+        rgb = results_side["rgb_fine"]
+        return rgb.reshape(1, hw[0], hw[1], 3).permute(0, 3, 1, 2)
+
+    def _generator_adv_loss(self, results_side, batch):
+        """optimizer_idx == 0, hinge: ``loss_d = -mean(D(results_side['rgb_fine']))`` (sinnerf.py:446-450), weighted by
+        ``dis_weight`` where the total is formed (sinnerf.py:499)"""
+        return -torch.mean(self.D(self._side_patch(results_side, batch))) * self.hparams.dis_weight
+
+    def discriminator_step(self, batch):
+        """optimizer_idx == 1 of ``training_step`` (sinnerf.py:462-471, hinge): the discriminator sees the real patch and the
+        DETACHED side render, so the only work on the accelerated path is ONE no-grad render of ``rays_side`` (PL 0.10 calls
+        ``training_step`` once per optimiser: the reference re-runs all four renders here and back-propagates through them for
+        gradients the discriminator's optimiser never uses).  Returns ``{'loss': loss_d}`` for ``opt_d``."""
+        if self.D is None:
+            raise RuntimeError("no discriminator attached (attach_discriminator)")
+        with torch.no_grad():
+            results_side = self(batch["rays_side"].reshape(-1, 8))
+        fake = self._side_patch(results_side, batch).detach()
+        real = batch["real_patch"]
+        pred_real, pred_fake = self.D(real), self.D(fake)
+        loss_real = torch.relu(torch.ones_like(pred_real) - pred_real).mean()
+        loss_gen = torch.relu(torch.ones_like(pred_fake) + pred_fake).mean()
+        loss_d = (loss_real + loss_gen) / 2
+        return {"loss": loss_d, "log": {"train/loss_d": loss_d.detach()}}
 
     # ---- sinnerf.py:171-193 -------------------------------------------------------------------------------------
     def forward(self, rays):
@@ -99,7 +149,11 @@ class SinNeRFSystem(nn.Module):
         scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=hp.decay_step, gamma=hp.decay_gamma)
         self._schedulers = [scheduler]
         self.__dict__.pop("_step_graphs", None)      # captured steps bake in the old flat-buffer addresses
-        return [self.optimizer], [scheduler]
+        opts = [self.optimizer]
+        if self.D is not None and hp.dis_weight > 0:                             # sinnerf.py:207-208: get_optimizer(hparams, [self.D], rate=0.2)
+            self.opt_d = torch.optim.Adam(self.D.parameters(), lr=hp.lr * 0.2, eps=1e-8, weight_decay=hp.weight_decay)
+            opts.append(self.opt_d)
+        return opts, [scheduler]
 
     # ---- losses.py:12-22 (MSE coarse + fine) + SL1Loss of depth_fine and depth_coarse (sinnerf.py:32-42, 310-319):
     #      value, gradients and PSNR from the fused sn_render_loss kernel pair (sinnerf_amd/losses.py)
@@ -122,6 +176,8 @@ class SinNeRFSystem(nn.Module):
           warped patch of ``sinnerf.py:300-302``) keeps the render and its backward on the step so that the timed work
           is the reference's.
         """
+        if optimizer_idx == 1:
+            return self.discriminator_step(batch)
         if "rays_full" in batch:
             return self._training_step_patches(batch)
         rays, rgbs = batch["rays"], batch["rgbs"]
@@ -132,8 +188,12 @@ class SinNeRFSystem(nn.Module):
         return {"loss": loss, "progress_bar": {"train_psnr": p}, "log": {"train/loss": loss.detach(), "train/psnr": p}}
 
     def side_loss(self, results_side, batch):
-        """Stand-in for the unseen-view losses that stay on PyTorch (DINO-ViT ``sinnerf.py:332-339``, discriminator): MSE of
-        the side render against the warped patch.  Replace by assignment (``system.side_loss = fn``)."""
+        """The unseen-view terms, which stay on PyTorch.  With a discriminator attached and ``dis_weight > 0``: the generator's
+        adversarial loss of ``sinnerf.py:446-450``.  Otherwise a stand-in (MSE of the side render against the warped patch) that keeps
+        the render and its backward on the step.  The DINO-ViT feature loss (``sinnerf.py:332-339``) needs weights from the network
+        and is not runnable offline: assign your own callable (``system.side_loss = fn``) to add it."""
+        if self.D is not None and self.hparams.dis_weight > 0:
+            return self._generator_adv_loss(results_side, batch)
         tgt = batch.get("side_rgb")
         if tgt is None:
             return None
@@ -259,6 +319,28 @@ class SinNeRFSystem(nn.Module):
             out = self._zero_forward_backward(batch)
         self.optimizer.step()                    # the one exchange step (RCCL all-reduce, mean) + sn_adam_step
         return out
+
+    def train_step_adversarial(self, batch):
+        """Both optimiser passes of one batch, as pytorch-lightning 0.10 drives ``training_step`` with two optimisers
+        (``sinnerf.py:202-210, 271``): pass 0 -- the four renders with gradients, the generator's hinge term through the attached
+        discriminator (its parameters frozen, as PL toggles ``requires_grad`` per optimiser), flat all-reduce + Adam on the NeRFs;
+        pass 1 -- ``discriminator_step`` (one no-grad side render), backward through the discriminator only, ``opt_d.step()``.
+        Returns (generator dict, discriminator dict)."""
+        if self.D is None or not hasattr(self, "opt_d"):
+            raise RuntimeError("train_step_adversarial: attach_discriminator() and configure_optimizers() first")
+        d_params = list(self.D.parameters())
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            out_g = self.train_step(batch)
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        self.opt_d.zero_grad(set_to_none=True)
+        out_d = self.discriminator_step(batch)
+        out_d["loss"].backward()
+        self.opt_d.step()
+        return out_g, out_d
 
     def _graphed_step(self, batch):
         tensors = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}

@@ -280,6 +280,134 @@ def test_bf16x3_weight_gradients_equal_the_fp32_contractions():
     print("bf16x3 weight gradients vs fp32 contractions: worst norm-wise difference %.2e" % worst)
 
 
+# ---- stage-level bars against the ORACLE's emulation of this arithmetic ------------------------------
+# The three tests above compare HIP with HIP (x3 kernel vs fp32 kernel on the same state): regression, not parity.  Below, every
+# stage output is held to oracle_np under bf16x3_operands() / nerf_backward(operand_round="bf16x3") -- the same (hi, lo) operand pairs
+# and dropped lo.lo term restated in numpy with wide accumulation -- at 1e-5 of each slot's / tensor's range.
+
+def _x3_stages_through_the_abi(n_rays, S, seed=3):
+    """sn_mlp_forward_train -> sn_mlp_backward_chain -> sn_weight_grads, all SN_DTYPE_BF16X3, through the C ABI.  Returns device
+    tensors (state in the kernel's own layout) and the inputs."""
+    import ctypes
+    from sinnerf_amd import _lib
+    step = max(1, 160000 // n_rays)
+    rays = np.ascontiguousarray(O.lego_rays(400, 400, seed=0)[::step][:n_rays])
+    assert rays.shape[0] == n_rays
+    z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n_rays, S)).astype(np.float32))
+    rays_t, z_t = torch.from_numpy(rays).to(dev()), torch.from_numpy(z).to(dev())
+    P = n_rays * S
+    rows = -(-P // 128) * 128
+    m3, params = make_model(seed, True, dtype=DT)
+    code = _lib.SN_DTYPE_BF16X3
+    out = torch.zeros((n_rays, S, 4), device=dev())
+    acts = torch.zeros((10, rows, 256), device=dev())
+    emb = torch.zeros((rows, 128), device=dev())
+    _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m3.packed()), m3.kernel_dtype(code), _lib.ptr(rays_t), _lib.ptr(z_t), n_rays, S,
+                                             _lib.ptr(out), _lib.ptr(acts), _lib.ptr(emb), rows, _lib.stream_ptr()), "fwd")
+    g_raw = torch.from_numpy(np.random.RandomState(2).standard_normal((P, 4)).astype(np.float32)).to(dev())
+    G = torch.zeros((10, rows, 256), device=dev())
+    g_o = torch.zeros((P, 4), device=dev())
+    _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m3.packed_bwd(DT)), m3.kernel_dtype(code), _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_raw),
+                                              P, rows, _lib.ptr(G), _lib.ptr(g_o), _lib.stream_ptr()), "chain")
+    ws = torch.empty(int(_lib.lib.sn_weight_grads_workspace_bytes(rows, code)), dtype=torch.uint8, device=dev())
+    grads = [torch.full_like(t, float("nan")) for t in m3.raw_tensors()]
+    arr = (ctypes.c_void_p * _lib.N_RAW_TENSORS)(*[o.data_ptr() for o in grads])
+    _lib.check(_lib.lib.sn_weight_grads(_lib.ptr(acts), _lib.ptr(emb), _lib.ptr(G), rows, code, _lib.ptr(ws), arr, 0, _lib.stream_ptr()), "dw")
+    torch.cuda.synchronize()
+    names = [k for k, _ in m3.named_parameters()]
+    return dict(rays=rays, z=z, P=P, rows=rows, params=params, out=out, acts=acts, emb=emb, G=G, g_o=g_o, g_raw=g_raw,
+                grads={k: g.double().cpu().numpy() for k, g in zip(names, grads)})
+
+
+def _oracle_cache_from_state(st, r0, r1):
+    """the oracle's forward cache for points [r0, r1) taken from the training state the KERNEL stored (decoded): masks and
+    activations are then the ones the chain saw -- a pre-activation within rounding of zero cannot flip a gradient entry"""
+    a = x3_state_to_fp32(st["acts"][:, r0:r1].cpu().numpy())
+    e = st["emb"][r0:r1].cpu().numpy()
+    cache = {f"h{i+1}": a[i] for i in range(8)}
+    cache["final"], cache["d"] = a[8], a[9][:, :128]
+    cache["x"] = np.concatenate([e[:, :63], e[:, 64:91]], 1)
+    o = st["out"].reshape(-1, 4)[r0:r1].cpu().numpy().astype(np.float64)
+    # WidenedSigmoid' from the kernel's own output, as the chain takes it: y3 = 2 atanh((2 rgb - 1) / 1.002)
+    cache["y3"] = 2.0 * np.arctanh(np.clip((2.0 * o[:, :3] - 1.0) / 1.002, -0.999999, 0.999999))
+    cache["new_act"] = True
+    return cache
+
+
+def test_bf16x3_training_state_vs_the_split_emulated_oracle():
+    """sn_mlp_forward_train(SN_DTYPE_BF16X3): the DECODED state (slots 0..8 from their (hi, lo) pairs, slot 9 fp32) against the
+    oracle's forward cache under ``bf16x3_operands()`` -- not against the fp32 kernel -- at 1e-5 of each slot's range; the embedded
+    inputs against ``oracle_np.embedding`` (models/nerf.py:36-41)."""
+    st = _x3_stages_through_the_abi(60, 37)
+    P = st["P"]
+    xin = np.concatenate([O.embedding(O._points(st["rays"], st["z"]).reshape(-1, 3), 10),
+                          np.repeat(O.embedding(st["rays"][:, 3:6], 4), 37, 0)], 1)
+    cache = {}
+    with O.bf16x3_operands():
+        ref_out = O.nerf_forward(st["params"], xin, cache=cache)
+    a = x3_state_to_fp32(st["acts"].cpu().numpy())[:, :P]
+    e = st["emb"].cpu().numpy()[:P]
+    assert np.abs(e[:, :63] - xin[:, :63]).max() <= 2e-6 and np.abs(e[:, 64:91] - xin[:, 63:]).max() <= 2e-6
+    worst = 0.0
+    for slot, key in enumerate([f"h{i+1}" for i in range(8)] + ["final", "d"]):
+        ref = cache[key]
+        got = a[slot][:, :ref.shape[1]]
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        worst = max(worst, err)
+        assert err <= 1e-5, (key, err)
+        if slot < 8:
+            assert ((got > 0) != (ref > 0)).mean() <= 1e-4, key
+    o = st["out"].reshape(-1, 4).cpu().numpy()
+    assert np.abs(o - ref_out).max() <= 1e-5 * np.abs(ref_out).max()
+    print("bf16x3 training state vs split-emulated oracle: worst max|d| / slot range = %.2e" % worst)
+
+
+@pytest.mark.parametrize("n_rays,S", [(60, 37), (4096, 128)])
+def test_bf16x3_chain_and_weight_gradients_vs_the_split_emulated_oracle(n_rays, S):
+    """sn_mlp_backward_chain + sn_weight_grads (SN_DTYPE_BF16X3) against ``oracle_np.nerf_backward(operand_round="bf16x3")`` on the
+    state the kernels themselves stored: every G slot (decoded) and g_out at 1e-5 of the slot's range, all 24 parameter gradients at
+    1e-5 of the tensor's range (and norm-wise).  (60 x 37): 2 220 points, a ragged last tile; (4096 x 128): the fine pass of a training
+    step, 524 288 points -- the oracle walks it in chunks of 16 384 points, gradients summed in float64."""
+    st = _x3_stages_through_the_abi(n_rays, S)
+    P = st["P"]
+    CH = 16384
+    slot_keys = [f"l{i+1}" for i in range(8)] + ["final", "dir"]
+    g_sum, g_worst, o_worst = None, 0.0, 0.0
+    ranges, diffs = np.zeros(10), np.zeros(10)
+    o_rng, o_dif = 0.0, 0.0
+    for r0 in range(0, P, CH):
+        r1 = min(P, r0 + CH)
+        cache = _oracle_cache_from_state(st, r0, r1)
+        gy = {}
+        ref = O.nerf_backward(st["params"], cache, st["g_raw"][r0:r1].cpu().numpy(), gy_out=gy, operand_round="bf16x3")
+        g_sum = ref if g_sum is None else {k: g_sum[k] + v for k, v in ref.items()}
+        Gc = x3_state_to_fp32(st["G"][:, r0:r1].cpu().numpy())
+        for slot, key in enumerate(slot_keys):
+            want = gy[key]
+            got = Gc[slot][:, :want.shape[1]]
+            assert np.isfinite(got).all(), (slot, r0)
+            ranges[slot] = max(ranges[slot], np.abs(want).max())
+            diffs[slot] = max(diffs[slot], np.abs(got - want).max())
+        go = st["g_o"][r0:r1].cpu().numpy()
+        want = np.concatenate([gy["rgb"], gy["sigma"]], 1)
+        o_rng, o_dif = max(o_rng, np.abs(want).max()), max(o_dif, np.abs(go - want).max())
+    for slot in range(10):
+        assert diffs[slot] <= 1e-5 * ranges[slot], (slot_keys[slot], diffs[slot], ranges[slot])
+    assert o_dif <= 1e-5 * o_rng, (o_dif, o_rng)
+    if st["rows"] > P:                                                       # pad rows of the 256 columns: zeros
+        assert not st["G"][:9, P:].any() and not st["G"][9, P:, :128].any()
+    worst_rng, worst_nrm = 0.0, 0.0
+    for k, v in g_sum.items():
+        got = st["grads"][k].reshape(v.shape)
+        assert np.isfinite(got).all(), k
+        e_rng = np.abs(got - v).max() / max(np.abs(v).max(), 1e-30)
+        e_nrm = np.linalg.norm(got - v) / max(np.linalg.norm(v), 1e-30)
+        worst_rng, worst_nrm = max(worst_rng, e_rng), max(worst_nrm, e_nrm)
+        assert e_rng <= 1e-5 and e_nrm <= 1e-5, (k, e_rng, e_nrm)
+    print("bf16x3 chain / weight gradients vs split-emulated oracle (%d x %d): G worst %.2e of range, g_out %.2e, dW worst %.2e of range, %.2e norm-wise"
+          % (n_rays, S, (diffs / ranges).max(), o_dif / o_rng, worst_rng, worst_nrm))
+
+
 def test_bf16x3_render_gradients_golden():
     """compute_dtype='bf16x3' under autograd: forward, backward chain and weight gradients on the bf16 MFMA (3-term splits) over
     the fp32 training state.  Every stage equals its fp32 counterpart at fp32 rounding level when fed the SAME state (the three tests

@@ -58,6 +58,37 @@ def test_bf16x3_split_emulation_is_fp32_level():
     assert np.abs((hi + lo) - np.array([1.2345678, -3.3e-5, 0.0], np.float32)).max() <= 2.0 ** -16 * 1.3
 
 
+def test_bf16x3_backward_emulation_is_fp32_level_and_distinct():
+    """``nerf_backward(operand_round="bf16x3")``: the split backward of csrc/sn_mlp_bwd_bf16x3.hip + sn_dw.hip modes 5-7 restated
+    (every operand as its (hi, lo) pair, the lo.lo term dropped).  Same cache, same upstream: within 2e-5 norm-wise of the wide
+    backward on every tensor (one bf16 product: ~5e-3) and NOT identical to it; stored pre-activation gradients (gy_out) are the
+    decoded (hi + lo) values, 2^-16 relative from the wide ones; bias gradients are the column sums of those."""
+    p = O.init_params(0, True)
+    r = np.random.RandomState(1)
+    pts = r.uniform(-2, 2, (384, 3)).astype(np.float32)
+    x = np.concatenate([O.embedding(pts, 10), O.embedding(r.standard_normal((384, 3)).astype(np.float32), 4)], 1)
+    c = {}
+    O.nerf_forward(p, x, cache=c)
+    g = r.standard_normal((384, 4)).astype(np.float32)
+    gy8, gy3 = {}, {}
+    wide = O.nerf_backward(p, c, g, gy_out=gy8)
+    # the wide backward with the SAME softplus-derivative form (1 - exp(-d)) the low-precision paths use: isolates the split's error
+    x3 = O.nerf_backward(p, c, g, gy_out=gy3, operand_round="bf16x3")
+    b16 = O.nerf_backward(p, c, g, operand_round=O.bf16_round)
+    for k, v in wide.items():
+        e3 = np.linalg.norm(x3[k] - v) / np.linalg.norm(v)
+        e16 = np.linalg.norm(b16[k] - v) / np.linalg.norm(v)
+        assert 0 < e3 <= 2e-5, (k, e3)
+        assert e3 < 0.02 * e16, (k, e3, e16)
+    for k in ("l1", "l4", "l5", "l8", "final"):
+        a, b = gy3[k], gy8[k]
+        hi, lo = O.bf16_split(a.astype(np.float32))
+        assert np.array_equal((hi.astype(np.float64) + lo), a), k          # what is stored decodes to itself
+        assert np.abs(a - b).max() <= 3e-5 * np.abs(b).max(), k
+        assert np.array_equal(a == 0, b == 0), k                             # same ReLU masks: same cache
+    assert np.allclose(x3["xyz_encoding_3.0.bias"], gy3["l3"].sum(0), rtol=0, atol=1e-12)
+
+
 def test_patch_ray_generators_match_config_sizes():
     ll, dt = O.llff_patch_rays(0), O.dtu_patch_rays(0)
     assert ll.shape == (5292, 8) and dt.shape == (3920, 8)                # BASELINE configs 3, 4 (SURVEY §8a sizes)

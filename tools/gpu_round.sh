@@ -10,17 +10,17 @@ echo "== bench bf16"; timeout 600 python bench.py --steps 3 --warmup 1 --dtype b
 echo "== train bench"; timeout 600 python tools/train_bench.py > gpurun_out/train_bench.log 2>&1; echo "train exit $?"; tail -1 gpurun_out/train_bench.log
 cd /tmp
 P="rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof"
-echo "== rocprof stats"; timeout 600 $P --stats -o stats -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $R/gpurun_out/prof_stats.log 2>&1; echo "exit $?"
-echo "== rocprof stats bf16"; timeout 600 $P --stats -o stats_bf16 -- python $R/bench.py --steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --no-extra > $R/gpurun_out/prof_stats_bf16.log 2>&1; echo "exit $?"
+echo "== rocprof stats"; timeout 600 $P --stats -o stats -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-pmc > $R/gpurun_out/prof_stats.log 2>&1; echo "exit $?"
+echo "== rocprof stats bf16"; timeout 600 $P --stats -o stats_bf16 -- python $R/bench.py --steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --no-extra --no-pmc > $R/gpurun_out/prof_stats_bf16.log 2>&1; echo "exit $?"
 echo "== rocprof stats train"; timeout 600 $P --stats -o stats_train -- python $R/tools/train_bench.py > $R/gpurun_out/prof_stats_train.log 2>&1; echo "exit $?"
-echo "== pmc1"; timeout 600 $P --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -o pmc1 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $R/gpurun_out/prof_pmc1.log 2>&1; echo "exit $?"
-echo "== pmc2"; timeout 600 $P --pmc FETCH_SIZE -o pmc2 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $R/gpurun_out/prof_pmc2.log 2>&1; echo "exit $?"
-echo "== pmc3"; timeout 600 $P --pmc WRITE_SIZE -o pmc3 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $R/gpurun_out/prof_pmc3.log 2>&1; echo "exit $?"
+echo "== pmc1"; timeout 600 $P --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -o pmc1 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-pmc > $R/gpurun_out/prof_pmc1.log 2>&1; echo "exit $?"
+echo "== pmc2"; timeout 600 $P --pmc FETCH_SIZE -o pmc2 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-pmc > $R/gpurun_out/prof_pmc2.log 2>&1; echo "exit $?"
+echo "== pmc3"; timeout 600 $P --pmc WRITE_SIZE -o pmc3 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-pmc > $R/gpurun_out/prof_pmc3.log 2>&1; echo "exit $?"
 C="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_CVT SQ_BUSY_CYCLES"
 for dt in fp32 bf16; do
-  echo "== instruction mix $dt"; timeout 300 $P --pmc $C -o mix_$dt -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --dtype $dt > $R/gpurun_out/mix_$dt.log 2>&1; echo "exit $?"
+  echo "== instruction mix $dt"; timeout 300 $P --pmc $C -o mix_$dt -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-pmc --dtype $dt > $R/gpurun_out/mix_$dt.log 2>&1; echo "exit $?"
 done
-echo "== pmc bf16"; timeout 600 $P --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -o pmc1_bf16 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --dtype bf16 > $R/gpurun_out/prof_pmc1_bf16.log 2>&1; echo "exit $?"
+echo "== pmc bf16"; timeout 600 $P --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -o pmc1_bf16 -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-pmc --dtype bf16 > $R/gpurun_out/prof_pmc1_bf16.log 2>&1; echo "exit $?"
 cd $R
 cd /tmp
 echo "== pmc train (HBM bytes of the training kernels)"

@@ -87,5 +87,8 @@ json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 if "traffic" in out:
     import subprocess
     head = subprocess.run(["git", "describe", "--always", "--dirty"], capture_output=True, text=True).stdout.strip() or "unknown"
-    json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json", git_head=head), open("profiles/pmc_traffic.json", "w"), indent=1)
+    sys.path.insert(0, os.getcwd())
+    from bench import kernel_sources_sha           # the profile is only valid for the kernel sources it was measured on (bench.py pmc_traffic)
+    json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json", git_head=head, kernel_sources_sha=kernel_sources_sha()),
+              open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "dispatches"}, indent=1)[:5000])
