@@ -365,8 +365,8 @@ def test_bf16x3_training_state_vs_the_split_emulated_oracle():
 @pytest.mark.parametrize("n_rays,S", [(60, 37), (4096, 128)])
 def test_bf16x3_chain_and_weight_gradients_vs_the_split_emulated_oracle(n_rays, S):
     """sn_mlp_backward_chain + sn_weight_grads (SN_DTYPE_BF16X3) against ``oracle_np.nerf_backward(operand_round="bf16x3")`` on the
-    state the kernels themselves stored: every G slot (decoded) and g_out at 1e-5 of the slot's range, all 24 parameter gradients at
-    1e-5 of the tensor's range (and norm-wise).  (60 x 37): 2 220 points, a ragged last tile; (4096 x 128): the fine pass of a training
+    state the kernels themselves stored: every G slot (decoded; 2e-5 of the slot's range for the 16-bit (hi, lo) slots, 1e-5 for the
+    fp32 slot 9) and g_out at 1e-5, all 24 parameter gradients at 1e-5 of the tensor's range (and norm-wise).  (60 x 37): 2 220 points, a ragged last tile; (4096 x 128): the fine pass of a training
     step, 524 288 points -- the oracle walks it in chunks of 16 384 points, gradients summed in float64."""
     st = _x3_stages_through_the_abi(n_rays, S)
     P = st["P"]
@@ -391,8 +391,12 @@ def test_bf16x3_chain_and_weight_gradients_vs_the_split_emulated_oracle(n_rays, 
         go = st["g_o"][r0:r1].cpu().numpy()
         want = np.concatenate([gy["rgb"], gy["sigma"]], 1)
         o_rng, o_dif = max(o_rng, np.abs(want).max()), max(o_dif, np.abs(go - want).max())
+    # slots 0..8 are stored as (hi, lo) pairs: 16 mantissa bits.  Two independently rounded representations of values that agree to
+    # fp32 accumulation order differ by up to 2 x 2^-17 = 1.5e-5 of the value (measured at the slot's largest entries: 1.1e-5), so the
+    # bar for those slots is 2e-5 of the slot's range; slot 9 and g_out are fp32 and are held to 1e-5
+    print("G max|d| / range per slot:", " ".join("%.1e" % (d / r) for d, r in zip(diffs, ranges)), "| g_out %.1e" % (o_dif / o_rng))
     for slot in range(10):
-        assert diffs[slot] <= 1e-5 * ranges[slot], (slot_keys[slot], diffs[slot], ranges[slot])
+        assert diffs[slot] <= (2e-5 if slot < 9 else 1e-5) * ranges[slot], (slot_keys[slot], diffs[slot], ranges[slot])
     assert o_dif <= 1e-5 * o_rng, (o_dif, o_rng)
     if st["rows"] > P:                                                       # pad rows of the 256 columns: zeros
         assert not st["G"][:9, P:].any() and not st["G"][9, P:, :128].any()
