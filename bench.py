@@ -480,7 +480,7 @@ _ROOFLINE_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algor
 _DROP_IN_RECORDS = {"thread_calibration_rays_per_s", "flop_per_launch", "algorithmic_bytes_per_step", "replicas_identical_after",
                     "all_reduce_bytes", "optimizer", "launch", "losses", "peak_tflops", "host_cores", "roofline_rays_per_s_per_gpu",
                     "renders_per_step", "points_per_step", "per_rank_tflops", "rays_per_rank_per_step", "loss", "peak_tflops",
-                    "frac_of_fp32_mfma_peak", "bound", "steps", "gathered_rows_on_rank0", "rccl_version"}
+                    "frac_of_fp32_mfma_peak", "bound", "steps"}
 
 
 def _slim(v, top=False, key=None):

@@ -22,6 +22,10 @@ int sn_mlp_backward_chain_bf16_classic_launch(const void* bblob, const float* ac
                                       hipStream_t stream);
 int sn_mlp_backward_chain_bf16x3_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                         long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
+int sn_mlp_backward_chain_bf16x3_t_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                          long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
+int sn_mlp_backward_chain_bf16x3_t_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                                  long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_mlp_backward_chain_bf16x3_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                                 long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_dw_launch(const void* tasks, int n_tasks, hipStream_t stream);
@@ -48,6 +52,10 @@ int sn_mlp_forward_bf16x3_launch(const void* blob, const float* in0, const float
 int sn_mlp_forward_bf16x3_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                          int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
                                          hipStream_t stream);
+int sn_mlp_forward_bf16x3_t_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples, float* out,
+                                   float* acts, float* emb, long slot_rows, hipStream_t stream);
+int sn_mlp_forward_bf16x3_t_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples, float* out,
+                                           float* acts, float* emb, long slot_rows, hipStream_t stream);
 int sn_mlp_forward_bf16_v3_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
                                   float* out, hipStream_t stream);
 int sn_mlp_forward_bf16_v3_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
@@ -227,6 +235,8 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
   // sn_mlp_backward_chain / sn_weight_grads read it (include/sinnerf_hip.h "pairing rule")
   if (dtype == SN_DTYPE_BF16X3) {
     if (slot_rows % 128 != 0) return SN_E_BADSHAPE;           // whole 128-point tiles, as the header states
+    if (!compiler_scheduled && n_points < (1l << 31) - 256)  // the generated trunk (sn_mlp_fwd_bf16x3_t.hip): the same bits
+      return SN_HEADS(classic, sn_mlp_forward_bf16x3_t)(blob, rays, z_vals, n_points, n_samples, out, acts, emb, slot_rows, (hipStream_t)stream);
     return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows, (hipStream_t)stream);
   }
   if (hand)
@@ -269,6 +279,8 @@ int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, co
   // wrote (masks from its sign words); g_acts leaves in the same layout ((hi, lo) pairs in slots 0..8) for sn_weight_grads(SN_DTYPE_BF16X3)
   if (dtype == SN_DTYPE_BF16X3) {
     if (slot_rows % 128 != 0) return SN_E_BADSHAPE;
+    if (!compiler_scheduled && n_points < (1l << 31) - 256)  // the generated slab loop (sn_mlp_bwd_bf16x3_t.hip): the same bits
+      return SN_HEADS(classic, sn_mlp_backward_chain_bf16x3_t)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out, (hipStream_t)stream);
     return SN_HEADS(classic, sn_mlp_backward_chain_bf16x3)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out, (hipStream_t)stream);
   }
   if (dtype == SN_DTYPE_BF16_STATE && !compiler_scheduled && n_points < (1l << 31) - 256)         // the hand-scheduled kernel

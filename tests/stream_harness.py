@@ -48,8 +48,11 @@ def apply_table(table, raws, nbytes, weight_bytes):
     dst, src = table[:, 0].astype(np.int64), table[:, 1].astype(np.int64)
     val = np.zeros(len(dst), np.float32)
     ok = src >= 0
-    tid, off = (src[ok] >> 20) & 0x3FF, src[ok] & 0xFFFFF
+    tid, off = (src[ok] >> 20) & 0xFF, src[ok] & 0xFFFFF
     val[ok] = flat[starts[tid] + off]
+    is_lo = np.zeros(len(dst), bool)
+    is_lo[ok] = (src[ok] & (1 << 29)) != 0                      # DT_BF16X3: the lo part, RNE(w - float(RNE(w)))  (sn_layout.h SRC_LO_FLAG)
+    val[is_lo] = val[is_lo] - G.bf16_to_f32(G.bf16_rne(val[is_lo]))
     as_f32 = (src == -2) | (ok & ((src & (1 << 30)) != 0))
     if weight_bytes == 4:
         as_f32[:] = True
@@ -339,3 +342,216 @@ class ChainRun:
     def stored(self, slot):
         a = self.G.view(np.uint16).reshape(10, SLOT_ROWS, 256)[slot].astype(np.uint32)
         return G.bf16_to_f32(a)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16x3 TRAINING forward trunk (tools/gen_x3_trunk.py / csrc/sn_mlp_fwd_bf16x3_t.hip): one 32-point tile per wave, 3 ring slots
+# that ROTATE from tile to tile (operands), tail at LDS offset 0, "x3 state" ((hi, lo) pairs) in acts
+X3_TAIL_BYTES, X3_SLOT_BYTES = 12544, 40960
+X3_STAGE_OFF = X3_TAIL_BYTES + 3 * X3_SLOT_BYTES               # 135424
+X3_ROWS = 128
+
+
+def forward_blob_bf16x3(params):
+    from sinnerf_amd import _lib
+    lib = _lib.lib
+    raws = []
+    for k in ORDER:
+        raws += [params[k + ".weight"], params[k + ".bias"]]
+    n = lib.sn_pack_table_entries_dtype(3)
+    table = np.empty((n, 2), np.int32)
+    assert lib.sn_build_pack_table(3, ctypes.c_void_p(table.ctypes.data)) == 0
+    return apply_table(table, raws, lib.sn_packed_weights_bytes(3), 2)
+
+
+def split8(f):
+    """(64, 8) fp32 -> ((4, 64) packed hi pairs, (4, 64) packed lo pairs): csrc/sn_mlp_x3.h x3_split8"""
+    hi = G.bf16_rne(f)
+    lo = G.bf16_rne((f - G.bf16_to_f32(hi)).astype(np.float32))
+    pk = lambda b: np.stack([b[:, 2 * i] | (b[:, 2 * i + 1] << 16) for i in range(4)], 0).astype(np.uint32)
+    return pk(hi), pk(lo)
+
+
+class X3TrunkRun:
+    """one workgroup pass (4 waves x 32 points) of the generated bf16x3 training trunk, with the ring rotated by `rot` slots"""
+    BIND = dict(vaA="v32", vaB="v33", vaC="v34", vb="v35", vs="v36", stw0="v37", stw1="v38", stw2="v39", stw3="v40", str="v41", vsg="v42",
+                goff="v43", sg="v44", vo="v45", blob="s[4:5]", smA="s6", smB="s7", smC="s8", c01="s9",
+                aplo="s12", aphi="s13", sglo="s14", sghi="s15", srlo="s16", srhi="s17",
+                **{"xh%d" % i: "v[%d:%d]" % (4 * i, 4 * i + 3) for i in range(4)},
+                **{"xl%d" % i: "v[%d:%d]" % (16 + 4 * i, 16 + 4 * i + 3) for i in range(4)})
+
+    def __init__(self, params, xyz_points, rot=1):
+        from sinnerf_amd import _lib
+        self.params = params
+        self.blob = forward_blob_bf16x3(params)
+        self.x_emb = O.embedding(xyz_points.astype(np.float32), 10)              # (128, 63)
+        wg = G.Workgroup(4)
+        wg.mem.add("blob", BLOB_BASE, data=self.blob.tobytes(), writable=False)
+        self.acts = wg.mem.add("acts", ACTS_BASE, nbytes=10 * X3_ROWS * 1024)
+        self.acts[:] = 0xEE
+        x3_off = lambda s: sum(slab_k(i) * 128 for i in range(s))
+        slots = [(rot + k) % 3 for k in range(3)]
+        for s in range(2):                               # slabs 0, 1 staged by the previous tile's dir section / the prologue
+            o, n = x3_off(s), slab_k(s) * 128
+            wg.lds.b[X3_TAIL_BYTES + slots[s] * X3_SLOT_BYTES: X3_TAIL_BYTES + slots[s] * X3_SLOT_BYTES + n] = self.blob[o:o + n]
+        tail0 = x3_off(76)
+        wg.lds.b[0: TAIL_FLOATS * 4] = self.blob[tail0: tail0 + TAIL_FLOATS * 4]
+        g, k = LANE >> 3, LANE & 7
+        for w, wave in enumerate(wg.waves):
+            f = np.zeros((64, 32), np.float32)
+            for e in range(32):
+                for h in (0, 1):
+                    c = _lib.lib.sn_layout_xyz_slot_col(h, e)
+                    if c >= 0:
+                        f[LH == h, e] = self.x_emb[32 * w + LJ[LH == h], c]
+            for ks in range(4):
+                hi, lo = split8(f[:, 8 * ks: 8 * ks + 8])
+                wave.v[4 * ks: 4 * ks + 4] = hi
+                wave.v[16 + 4 * ks: 16 + 4 * ks + 4] = lo
+            sb = X3_STAGE_OFF + w * 4096
+            for i in range(3):
+                wave.v[32 + i] = X3_TAIL_BYTES + slots[i] * X3_SLOT_BYTES + LANE * 16
+                wave.s[6 + i] = X3_TAIL_BYTES + slots[i] * X3_SLOT_BYTES + w * 1024
+            wave.v[35] = LH * 64
+            wave.v[36] = 4 * (BIAS_FLOATS + AUX_SIGW + 128 * LH)
+            stw0 = sb + LJ * 128 + 16 * (LH ^ (LJ & 7))
+            for i in range(4):
+                wave.v[37 + i] = stw0 ^ (32 * i)
+            wave.v[41] = sb + g * 128 + 16 * (k ^ g)
+            wave.v[42] = (LANE >> 4) * 1024 + (LANE & 15) * 16
+            wave.v[43] = (w * 64 + LANE) * 16 + x3_off(2)
+            wave.v[44] = 0
+            wave.v[45] = g * 1024 + 16 * k
+            wave.s[4], wave.s[5] = BLOB_BASE & 0xFFFFFFFF, BLOB_BASE >> 32
+            wave.s[9] = 0x00010001
+            ap = ACTS_BASE + (32 * w) * 1024
+            sg = ACTS_BASE + ((9 * X3_ROWS + 32 * w) * 256 + 128) * 4
+            wave.s[12], wave.s[13] = ap & 0xFFFFFFFF, ap >> 32
+            wave.s[14], wave.s[15] = sg & 0xFFFFFFFF, sg >> 32
+            wave.s[16], wave.s[17] = (X3_ROWS * 1024) & 0xFFFFFFFF, (X3_ROWS * 1024) >> 32
+            wave.vm = [("store", None)] * 2              # the generator's entry assumption: at most the two pieces of slab 1 in flight
+        self.wg = wg
+        self.vo0 = [w_.v[45].copy() for w_ in wg.waves]
+
+    def run(self, lines):
+        self.wg.run(G.bind(lines, self.BIND))
+        return self
+
+    def state(self):
+        """(10, 128 rows, 256) float32 view of acts (slots 0..8 still as (hi, lo) pairs: decode with tests.helpers.x3_state_decode)"""
+        return self.acts.view(np.float32).reshape(10, X3_ROWS, 256)
+
+    def agpr_set(self, st):
+        """the activation held in AGPR set st as (128 points, 256 features) fp32 = hi + lo"""
+        out = np.zeros((2, 128, 256), np.float32)
+        for w, wave in enumerate(self.wg.waves):
+            for part in range(2):
+                for ks in range(16):
+                    base = st * 128 + part * 64 + ks * 4
+                    for i in range(4):
+                        word = wave.a[base + i]
+                        for e, bits in enumerate((word & 0xFFFF, word >> 16)):
+                            q = 8 * ks + 2 * i + e
+                            for h in (0, 1):
+                                sel = LH == h
+                                out[part, 32 * w + LJ[sel], hid_slot_feature(q, h)] = G.bf16_to_f32(bits[sel])
+        return out[0] + out[1]
+
+    def sigma(self):
+        tail0 = sum(slab_k(i) * 128 for i in range(76))
+        aux = self.blob[tail0 + BIAS_FLOATS * 4: tail0 + TAIL_FLOATS * 4].view(np.float32)
+        out = np.zeros(128, np.float32)
+        for w, wave in enumerate(self.wg.waves):
+            sg = wave.v[44].view(np.float32)
+            out[32 * w + np.arange(32)] = sg[:32] + sg[32:] + aux[640]
+        return out
+
+
+# ---- bf16x3 backward chain (tools/gen_x3_chain.py / csrc/sn_mlp_bwd_bf16x3_t.hip): 4 static slots of 32 KB, tail at LDS offset 0
+XC_SLOT, XC_RING_OFF = 32768, 11776
+XC_STAGE_OFF = XC_RING_OFF + 4 * XC_SLOT                          # 142848
+
+
+def backward_blob_bf16x3(params):
+    from sinnerf_amd import _lib
+    lib = _lib.lib
+    raws = []
+    for k in ORDER:
+        raws += [params[k + ".weight"], params[k + ".bias"]]
+    n = lib.sn_pack_table_entries_bwd_bf16x3()
+    table = np.empty((n, 2), np.int32)
+    assert lib.sn_build_pack_table_bwd_bf16x3(ctypes.c_void_p(table.ctypes.data)) == 0
+    return apply_table(table, raws, lib.sn_packed_weights_bytes_bwd_bf16x3(), 2)
+
+
+def xc_slab_bytes(s):
+    return (8 if s < 8 else 16) * 2048
+
+
+class X3ChainRun:
+    """one workgroup pass (4 waves x 32 points) of the generated bf16x3 backward-chain statement"""
+    BIND = dict(vaA="v32", vaB="v33", vs="v34", goff="v35", gsig="v36", stw0="v37", stw1="v38", stw2="v39", stw3="v40", str="v41", vo="v42",
+                blob="s[4:5]", sm="s6", gplo="s12", gphi="s13", srlo="s16", srhi="s17",
+                **{"sw%d_%d" % (l, w): "v%d" % (64 + 4 * l + w) for l in range(8) for w in range(4)})
+
+    def __init__(self, params, fwd_state, g_y2, g_sigma):
+        """fwd_state: (10, 128, 256) float32 view of the forward's acts (sign words in slot 9, columns 128..191); g_y2: (128, 128) fp32
+        pre-activation gradient of dir_encoding (the kernel's C++ prologue computes it and splits it into AGPR set 0); g_sigma: (128,)"""
+        self.blob = backward_blob_bf16x3(params)
+        wg = G.Workgroup(4)
+        wg.mem.add("bblob", BLOB_BASE, data=self.blob.tobytes(), writable=False)
+        self.G = wg.mem.add("G", G_BASE, nbytes=10 * X3_ROWS * 1024)
+        self.G[:] = 0xEE
+        off = 0
+        for s in range(3):
+            n = xc_slab_bytes(s)
+            wg.lds.b[XC_RING_OFF + s * XC_SLOT: XC_RING_OFF + s * XC_SLOT + n] = self.blob[off: off + n]
+            off += n
+        tail0 = sum(xc_slab_bytes(s) for s in range(72))
+        wg.lds.b[0: BB_TAIL_FLOATS * 4] = self.blob[tail0: tail0 + BB_TAIL_FLOATS * 4]
+        g, k = LANE >> 3, LANE & 7
+        words = np.ascontiguousarray(fwd_state[9]).view(np.uint32)[:, 128:192]        # (128 rows, 64 dwords)
+        hi = G.bf16_rne(g_y2)
+        lo = G.bf16_rne((g_y2 - G.bf16_to_f32(hi)).astype(np.float32))
+        for w, wave in enumerate(wg.waves):
+            for part, bits in ((0, hi), (1, lo)):
+                for ks in range(8):
+                    base = part * 64 + ks * 4                                         # set 0
+                    for i in range(4):
+                        word = np.zeros(64, np.uint32)
+                        for ee in range(2):
+                            q = 8 * ks + 2 * i + ee
+                            for h in (0, 1):
+                                sel = LH == h
+                                word[sel] |= bits[32 * w + LJ[sel], hid_slot_feature(q, h)] << (16 * ee)
+                        wave.a[base + i] = word
+            for l in range(8):                                                        # the lane's four words of layer l
+                rows = words[32 * w + 4 * l: 32 * w + 4 * l + 4].reshape(64, 4)       # [lane][tile pair]
+                for q in range(4):
+                    wave.v[64 + 4 * l + q] = rows[:, q]
+            sb = XC_STAGE_OFF + w * 4096
+            wave.v[32] = XC_RING_OFF + LANE * 16
+            wave.v[33] = XC_RING_OFF + 2 * XC_SLOT + LANE * 16
+            wave.v[34] = 4 * (BB_ZERO_FLOATS + BB_AUX_SIGT + 128 * LH)
+            wave.v[35] = (w * 64 + LANE) * 16 + off
+            wave.v[36] = np.asarray(g_sigma[32 * w + LJ], np.float32).view(np.uint32)
+            stw0 = sb + LJ * 128 + 16 * (LH ^ (LJ & 7))
+            for i in range(4):
+                wave.v[37 + i] = stw0 ^ (32 * i)
+            wave.v[41] = sb + g * 128 + 16 * (k ^ g)
+            wave.v[42] = g * 1024 + 16 * k
+            wave.s[4], wave.s[5] = BLOB_BASE & 0xFFFFFFFF, BLOB_BASE >> 32
+            wave.s[6] = XC_RING_OFF + w * 1024
+            gp = G_BASE + (8 * X3_ROWS + 32 * w) * 1024
+            wave.s[12], wave.s[13] = gp & 0xFFFFFFFF, gp >> 32
+            wave.s[16], wave.s[17] = (X3_ROWS * 1024) & 0xFFFFFFFF, (X3_ROWS * 1024) >> 32
+            wave.vm = [("store", None)] * 8
+        self.wg = wg
+        self.goff0 = [w_.v[35].copy() for w_ in wg.waves]
+
+    def run(self, lines):
+        self.wg.run(G.bind(lines, self.BIND))
+        return self
+
+    def state(self):
+        return self.G.view(np.float32).reshape(10, X3_ROWS, 256)

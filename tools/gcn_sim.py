@@ -228,6 +228,9 @@ class Wave:
         for mm in re.finditer(r"\b(offset|offset0|offset1):(\d+)", rest):
             mods[mm.group(1)] = int(mm.group(2))
         rest = re.sub(r"\b(offset|offset0|offset1):\d+", "", rest)
+        for mm in re.finditer(r"\b(neg_lo|neg_hi):\[([01](?:,[01])*)\]", rest):        # VOP3P source modifiers, one flag per source
+            mods[mm.group(1)] = [int(x) for x in mm.group(2).split(",")]
+        rest = re.sub(r"\b(neg_lo|neg_hi):\[[01](?:,[01])*\]", "", rest)
         flags = set(re.findall(r"\b(nt|sc0|sc1|off)\b", rest))
         rest = re.sub(r"\b(nt|sc0|sc1)\b", "", rest)
         args = [a.strip() for a in rest.split(",") if a.strip()] if rest.strip() else []
@@ -326,6 +329,18 @@ class Wave:
                 x, y = y, x
             self.wr(d, x); self.wr(s0, y)
             return None
+        if op == "v_pk_add_f32":                             # two fp32 adds on register pairs; neg_lo / neg_hi negate element 0 / 1 of a source
+            d, s0, s1 = (_parse_reg(x) for x in args)
+            assert d[2] == 2 and s0[2] == 2 and s1[2] == 2 and d[1] % 2 == 0 and s0[1] % 2 == 0 and s1[1] % 2 == 0, text
+            A, B = f32(self.rd(s0)).copy(), f32(self.rd(s1)).copy()
+            nl, nh = mods.get("neg_lo", [0, 0]), mods.get("neg_hi", [0, 0])
+            for src, k in ((A, 0), (B, 1)):
+                if nl[k]:
+                    src[0] = -src[0]
+                if nh[k]:
+                    src[1] = -src[1]
+            self.wr(d, u32(A + B))
+            return None
         if op.startswith("v_"):
             d = _parse_reg(args[0])
             S = [self.rd(_parse_reg(a)) for a in args[1:]]
@@ -355,6 +370,10 @@ class Wave:
                 r = (S[0] << (S[1] & 31)) + S[2]
             elif op == "v_bfe_u32":
                 r = (S[0] >> (S[1] & 31)) & ((np.uint32(1) << (S[2] & 31)) - 1)
+            elif op == "v_bfe_i32":                              # sign-extended field (width 1: 0 or 0xffffffff)
+                wdt = int(S[2][0]) & 31
+                fld = (S[0].astype(np.uint64) >> (S[1].astype(np.uint64) & 31)) & ((1 << wdt) - 1)
+                r = np.where(fld >> (wdt - 1) & 1, fld | (0xFFFFFFFF ^ ((1 << wdt) - 1)), fld)
             elif op == "v_cvt_pk_bf16_f32":
                 r = bf16_rne(f32(S[0])) | (bf16_rne(f32(S[1])) << 16)
             elif op == "v_pk_max_i16":
@@ -373,6 +392,8 @@ class Wave:
                 r = u32(f32(S[0]) * f32(S[1]))
             elif op == "v_add_f32":
                 r = u32(f32(S[0]) + f32(S[1]))
+            elif op == "v_sub_f32":
+                r = u32(f32(S[0]) - f32(S[1]))
             elif op == "v_fmac_f32":
                 r = u32((f32(S[0]).astype(np.float64) * f32(S[1]).astype(np.float64) + f32(self.rd(d)).astype(np.float64)).astype(np.float32))
             elif op == "v_dot2c_f32_bf16":                       # d += a.lo * b.lo + a.hi * b.hi (fp32)
