@@ -53,6 +53,9 @@ KNOBS = dict(prefetch=3,        # A-fragment prefetch distance in k-steps (ring 
              b1_gap=3,          # B1 sits behind this MFMA of a slab (3 = behind k-step 0)
              b2_lead=4,         # B2 sits this many k-steps before the end of the slab
              epi_from=1,        # the previous tile's epilogue starts behind this MFMA of the slab
+             one_bar=0,         # experiment: ONE sync point per slab doing both jobs (as the 4-k-step slabs always do)
+             abl_sign=1, abl_relu=1, abl_vstore=1, abl_stage=1,   # timing ablations (0 = leave the work out: WRONG results): sign bits, ReLU,
+                                # the global row stores, the whole staging round trip (swaps + LDS write / read + stores)
              pk=0)              # 1: v_pk_add_f32 for the chain sum and the remainder (two instructions less per pair -- but packed fp32 VALU
                                 # beside MFMAs is an anti-lever on this chip: MI355X_MICROARCH.md, and measured here: -8 % cycles, -20 % clock)
 
@@ -107,7 +110,7 @@ def gen(knobs):
     b1, b2 = {}, {}
     for s in range(N_SLABS):
         b1[s] = first[s] + K["b1_gap"] - 1
-        b2[s] = first[s + 1] - 1 - 3 * K["b2_lead"] if nk_of(s) >= 8 else b1[s]
+        b2[s] = first[s + 1] - 1 - 3 * K["b2_lead"] if (nk_of(s) >= 8 and not K["one_bar"]) else b1[s]
         assert b2[s] >= b1[s]
 
     # ---- A fragments (the first D k-steps are loaded in the preamble: slab 0 is resident)
@@ -156,7 +159,7 @@ def gen(knobs):
             else:
                 for e in range(4):
                     V("v_add_f32 v%d, v%d, v%d" % (a + e, a + e, b + e), (a + e,))
-            if relu:
+            if relu and K["abl_relu"]:
                 for e in range(4):
                     V("v_max_f32 v%d, 0, v%d" % (a + e, a + e), (a + e,))
             V("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (b, a, a + 1), (b,))
@@ -179,7 +182,7 @@ def gen(knobs):
             V("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (b + 3, a + 2, a + 3), (b + 3,))
             V("v_accvgpr_write_b32 a%d, v%d" % (rl, b + 2), (("a", rl),))
             V("v_accvgpr_write_b32 a%d, v%d" % (rl + 1, b + 3), (("a", rl + 1),))
-            if relu:                                                 # sign bits of the post-ReLU pairs: bit k <- low value, 16 + k <- high value
+            if relu and K["abl_sign"]:                               # sign bits of the post-ReLU pairs: bit k <- low value, 16 + k <- high value
                 for half in range(2):
                     k = 2 * i + half + 8 * (t & 1)
                     V("v_pk_min_u16 v%d, v%d, %%[c01]" % (VM, b + half), (VM,))
@@ -188,9 +191,10 @@ def gen(knobs):
                     else:
                         V("v_lshl_or_b32 v%d, v%d, %d, v%d" % (sgw, VM, k, sgw), (sgw,))
             # lanes 0..31 <- the hi chunk [h0 h1 | partner's h0 h1], lanes 32..63 <- the lo chunk [partner's l0 l1 | l0 l1]
-            items.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (b, b + 2), (b, b + 2), None, "acc", (b, b + 2)))
-            items.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (b + 1, b + 3), (b + 1, b + 3), None, "acc", (b + 1, b + 3)))
-            items.append(("ds_write", "ds_write_b128 %%[stw%d], v[%d:%d]" % (i, b, b + 3), (), None, "acc"))
+            if K["abl_stage"]:
+                items.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (b, b + 2), (b, b + 2), None, "acc", (b, b + 2)))
+                items.append(("swap", "v_permlane32_swap_b32 v%d, v%d" % (b + 1, b + 3), (b + 1, b + 3), None, "acc", (b + 1, b + 3)))
+                items.append(("ds_write", "ds_write_b128 %%[stw%d], v[%d:%d]" % (i, b, b + 3), (), None, "acc"))
         # the tile's row stores: row group n = rows 8 n .. 8 n + 7 of the staged tile, lane (g, k) = row g, 16-byte chunk k
         rows = []
         def rd(n):
@@ -198,6 +202,9 @@ def gen(knobs):
             rows.append(("ds_read", "ds_read_b128 v[%d:%d], %%[str] offset:%d" % (ro, ro + 3, 1024 * n), (), ("ro", s, n), "post"))
         def st_(n):
             ro = ROW_A if (n % rows_n) == 0 else ROW_B
+            if not K["abl_vstore"]:
+                rows.append(("valu", "s_nop 0", (), ("ro", s, n), "post"))      # timing ablation: the staged row is still waited for
+                return
             rows.append(("vstore", "global_store_dwordx4 %%[vo], v[%d:%d], s[%d:%d] offset:%d nt" % (ro, ro + 3, SGPR_ACTS, SGPR_ACTS + 1, 128 * t),
                          (), ("ro", s, n), "post", (SGPR_ACTS, SGPR_ACTS + 1)))
             if n < 3:
@@ -221,6 +228,8 @@ def gen(knobs):
                 rows.append(("salu", "s_addc_u32 s%d, s%d, 0" % (SGPR_SIGN + 1, SGPR_SIGN + 1), (SGPR_SIGN + 1,), None, "post"))
             rows.append(("salu", "s_add_u32 s%d, s%d, %%[srlo]" % (SGPR_ACTS, SGPR_ACTS), (SGPR_ACTS,), None, "post"))      # next layer: acts[L + 1]
             rows.append(("salu", "s_addc_u32 s%d, s%d, %%[srhi]" % (SGPR_ACTS + 1, SGPR_ACTS + 1), (SGPR_ACTS + 1,), None, "post"))
+        if not K["abl_stage"]:
+            rows = [r for r in rows if r[0] == "salu"]
         return items + rows
 
     COST = {"ds_read": K["lds_cost"], "ds_write": K["lds_cost"], "valu": K["valu_cost"], "swap": K["valu_cost"],
