@@ -378,17 +378,21 @@ def train_cfg3_full_record(O, dev, dtype="bf16", steps=8, warmup=3):
     n_rays = sum(batch[k].shape[0] for k in ("rays", "rays_full", "rays_side", "rays_proj"))
 
     def timed(fn, n, w):
+        """median of n individually synchronised steps after w warm-up steps: the discriminator's convolutions go through MIOpen, whose
+        first calls per shape search for an algorithm (a fresh box has no cache) -- a mean over the first few steps measures that search"""
         for _ in range(w):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             out = fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n, out
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), out
     np.random.seed(0)
     full = make(True)
-    t_full, (out_g, out_d) = timed(lambda: full.train_step_adversarial(batch), steps, warmup)
+    t_full, (out_g, out_d) = timed(lambda: full.train_step_adversarial(batch), max(steps, 12), max(warmup, 6))
     assert torch.isfinite(out_g["loss"]).item() and torch.isfinite(out_d["loss"]).item()
     side = batch["rays_side"].reshape(-1, 8)
 

@@ -93,13 +93,11 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
   f32x16 acc0 = load_bias(lds_zero, 0, h), acc1; // the two accumulator sets (VGPRs)
   // per-wave staging tile of the g_y row stores (sn_mlp_pipe.h XPOSE_*)
   char* const xp = smem + BWD_TAIL_BYTES + 3 * BWD_RING_SLOT + wave * XPOSE_WAVE_BYTES;
-  // staging tile: 32 point rows x 128 B, the 16-byte chunk c of row j stored at chunk c ^ (j & 7).  Writes (ds_write_b128: served 8
-  // contiguous lanes at a time over 32 banks; lane (j, h) holds chunk 2 q + h of slice q) and row reads (lane (g, k) = row 8 i + g,
-  // chunk k) are both conflict-free in the guide's bank model (MI355X_MICROARCH.md "LDS"; tools/gcn_sim.py counts the same layout for
-  // the bf16x3 streams).  The 36-float-pitch tile of rounds 1-4 was conflict-free for the writes but two-way for part of the reads
-  // (row g at dword 36 g: lanes 12..15 of a 16-lane read group wrap onto lanes 0..3's banks): SQ_LDS_BANK_CONFLICT 7.7-8.1 %
-  const unsigned xp_w = (unsigned)(j * 128 + 16 * (h ^ (j & 7)));                       // chunk of slice 0; slice q: xp_w ^ (32 q)
-  const unsigned xp_r = (unsigned)((lane >> 3) * 128 + 16 * ((lane & 7) ^ (lane >> 3)));    // row lane>>3, 16-byte chunk lane&7
+  // (36-float pitch: conflict-free for the 8-lane write groups, two-way for part of the 16-lane read groups -- SQ_LDS_BANK_CONFLICT 7.7-8.1 %.
+  // The conflict-free tile of the bf16x3 streams, 128-byte rows with chunk ^= row & 7, was measured here in round 5: conflict fraction 0.000
+  // and 0.4-1 % SLOWER, one more VALU per staging write: profiles/r05_f32_staging_ab.txt.  The conflicts are not what this kernel waits for.)
+  const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;                       // this lane's register quads
+  const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;    // row lane>>3, 16-byte chunk lane&7
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -150,10 +148,10 @@ mlp_bwd_chain_f32_kernel(const char* __restrict__ bblob, const float* __restrict
     auto stage = [&](int q, const float (&v)[4]) __attribute__((always_inline)) {
       f32x4 o;
       o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-      *reinterpret_cast<f32x4*>(xp + (xp_w ^ (unsigned)(32 * q))) = o;
+      *reinterpret_cast<f32x4*>(xp + xp_w + 32 * q) = o;
     };
     auto store_rows = [&](int slot, int t, int i) __attribute__((always_inline)) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(xp + xp_r + 1024 * i);
+      const f32x4 o = *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
       const char* base = reinterpret_cast<const char*>(G) + (((long)slot * slot_rows + p_wave + 8 * i) * 256 + 32 * t) * 4;
       unsigned go = g_off;
       asm volatile("" : "+v"(go));               // opaque per store: no hoisted per-slot address registers

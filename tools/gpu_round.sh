@@ -46,3 +46,5 @@ for f in glob.glob("gpurun_out/prof/**/pmc_x3_counter_collection.csv", recursive
 PY
 echo "== pmc train (cycles, MFMA-busy, clock of the training kernels)"
 bash tools/train_pmc.sh > gpurun_out/train_pmc.log 2>&1; echo "exit $?"; tail -12 gpurun_out/train_pmc.txt
+echo "== bf16x3 training stages: generated streams vs compiler-scheduled (time, bit identity)"
+python tools/x3_stage_time.py 20 2>&1 | grep -v amdgpu.ids | tee gpurun_out/x3_stage_time.txt
