@@ -56,3 +56,46 @@ def test_dead_rank_takes_the_job_down():
     finally:
         os.remove(script)
     assert rc != 0
+
+
+def test_a_rank_failing_in_setup_makes_every_rank_skip_the_record():
+    """the multi-rank records wrapped collective-bearing code in a per-rank `except`; a rank failing alone left the others
+    blocked in the record's first collective.  bench.setup_agreed runs the collective-FREE setup, then all ranks all-reduce a success flag:
+    rank 1's failure becomes SetupFailed on BOTH ranks (here: two gloo ranks on CPU), and both are still able to run the next collective."""
+    sys.path.insert(0, REPO)
+    import bench
+    script = os.path.join(REPO, "tests", "_setup_agreed_ranks.py")
+    with open(script, "w") as f:
+        f.write(
+            "import os, sys, json\n"
+            "sys.path.insert(0, %r)\n"
+            "import torch, torch.distributed as dist, bench\n"
+            "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+            "dist.init_process_group('gloo')\n"
+            "dev = torch.device('cpu')\n"
+            "def setup():\n"
+            "    if rank == 1:\n"
+            "        raise MemoryError('rank 1 ran out of memory building its batch')\n"
+            "    return 'ok'\n"
+            "try:\n"
+            "    bench.setup_agreed(setup, dev, world); got = 'entered'\n"
+            "except bench.SetupFailed as e:\n"
+            "    got = 'skipped: ' + str(e)\n"
+            "ok = bench.setup_agreed(lambda: 42, dev, world)          # the next record's setup: everyone fine again\n"
+            "t = torch.ones(1); dist.all_reduce(t)\n"
+            "print(json.dumps({'rank': rank, 'got': got, 'next': ok, 'sum': float(t.item())}), file=sys.stderr, flush=True)\n"
+            "dist.destroy_process_group()\n" % REPO)
+    import io, contextlib
+    try:
+        out = subprocess.run([sys.executable, "-c",
+                              "import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_ranks(2, [], script=%r, timeout=120))" % (REPO, script)],
+                             env=_clean_env(), capture_output=True, text=True, timeout=300)
+    finally:
+        os.remove(script)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.loads(l) for l in out.stderr.splitlines() if l.startswith("{")]
+    assert len(recs) == 2, out.stderr[-2000:]
+    by = {r["rank"]: r for r in recs}
+    assert by[0]["got"].startswith("skipped: setup failed on another rank")
+    assert by[1]["got"].startswith("skipped: MemoryError")
+    assert all(r["next"] == 42 and r["sum"] == 2.0 for r in recs)
