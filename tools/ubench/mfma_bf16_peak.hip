@@ -8,6 +8,10 @@
 //   mode 3: mode 2 + 3 VALU instructions (v_cvt_pk_bf16_f32 / v_pk_max / v_accvgpr_write-like moves) per MFMA
 //   mode 4: mode 1 with HALF of the B operands zero (a ReLU layer's activations: the fused MLP's actual B operand statistics)
 //   mode 5: mode 4 + the ds_read_b128 per MFMA pair of mode 2
+//   mode 6: mode 4 + one ds_read_b128 per FOUR MFMAs -- the A-fragment stream of a wave that owned FOUR point tiles (half
+//           the fragment reads per MFMA; the AGPR file holds the activations of two tiles, so this flow does not exist as a kernel)
+//   mode 7: mode 6 with the B operands of every second MFMA read from LDS as well (one more ds_read_b128 per two MFMAs): the same four-tile
+//           flow with the activations of two of the tiles kept in LDS instead of AGPRs -- the only way it would fit the register file
 // prints TFLOP/s (dense, 32*32*16*2 FLOP per MFMA) and the clock an MFMA-bound stream implies (32 cycles per MFMA per SIMD).
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_bf16_peak tools/ubench/mfma_bf16_peak.hip
 #include <hip/hip_runtime.h>
@@ -20,7 +24,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE_>
 __global__ void __launch_bounds__(256) k(const u32x4* __restrict__ src, float* out, int iters) {
-  constexpr int MODE = MODE_ == 4 ? 1 : MODE_ == 5 ? 2 : MODE_;      // 4, 5: the loops of 1, 2 over ReLU-like B operands
+  constexpr int MODE = MODE_ == 4 ? 1 : MODE_ == 5 ? 2 : MODE_ >= 6 ? 1 : MODE_;      // 4, 5: the loops of 1, 2 over ReLU-like B operands
 
   __shared__ __attribute__((aligned(16))) u32x4 lds[2048];           // 32 KB of operand tiles
   const int lane = threadIdx.x & 63;
@@ -48,11 +52,15 @@ __global__ void __launch_bounds__(256) k(const u32x4* __restrict__ src, float* o
     for (int g = 0; g < 8; ++g) {
       u32x4 an = a[g];
       if (MODE >= 2) an = lds[((it * 8 + g) & 31) * 64 + lane];
+      if (MODE_ >= 6 && (g & 1) == 0) an = lds[((it * 8 + g) & 31) * 64 + lane];          // one A fragment per FOUR MFMAs
+      u32x4 bn = b[g];
+      if (MODE_ == 7) bn = lds[((it * 8 + g + 16) & 31) * 64 + lane];                     // ... and the B operand of every second MFMA from LDS
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a[g]), "v"(b[g]));
       if (MODE >= 3) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0\n\tv_mov_b32 %0, %0" : "+v"(junk) : "v"(c0[0]), "v"(c0[1]));
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a[g]), "v"(b[(g + 1) & 7]));
       if (MODE >= 3) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0\n\tv_mov_b32 %0, %0" : "+v"(junk) : "v"(c1[0]), "v"(c1[1]));
-      if (MODE >= 2) a[g] = an;
+      if (MODE >= 2 || (MODE_ >= 6 && (g & 1) == 0)) a[g] = an;
+      if (MODE_ == 7) b[g] = bn;
     }
     if ((it & 63) == 63) {                                            // keep the accumulators finite: scale back now and then
       for (int r = 0; r < 16; ++r) { c0[r] *= 1e-6f; c1[r] *= 1e-6f; }
@@ -103,6 +111,8 @@ int main(int argc, char** argv) {
     run<3>("mode 3: mode 2 + 3 VALU / MFMA", src, d, n_cu, target_ms);
     run<4>("mode 4: random A, half-zero B (ReLU-like)", src, d, n_cu, target_ms);
     run<5>("mode 5: mode 4 + ds_read_b128 / 2 MFMA", src, d, n_cu, target_ms);
+    run<6>("mode 6: mode 4 + ds_read_b128 / 4 MFMA", src, d, n_cu, target_ms);
+    run<7>("mode 7: mode 6 + B of every 2nd MFMA from LDS", src, d, n_cu, target_ms);
   }
   return 0;
 }
