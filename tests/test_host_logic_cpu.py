@@ -110,3 +110,46 @@ def test_checkpoint_key_filter(tmp_path):
     assert lin.bias.item() == 7.0
     with pytest.raises(RuntimeError):
         load_ckpt(lin, {"m.nope": torch.tensor([7.0])}, model_name="m")          # unknown entries fail in load_state_dict
+
+
+def test_bench_line_keeps_every_named_config_and_stays_under_the_driver_tail():
+    """BASELINE config 4's record used to be `dropped` from the one JSON line.  A full-size result (every record the
+    N = 1 bench produces, with its prose) must compact to < 8 KB with the contract keys, `roofline`, `cpu_baseline` and the records of all
+    named configs present."""
+    import json
+    import bench
+    d = json.load(open(os.path.join(REPO, "profiles", "r05_final_bench_fp32.json")))
+    prose = "x" * 400
+    res = dict(d)
+    res["records"] = {k: dict(v, workload=prose, losses=prose, roofline=dict(v.get("roofline") or {}, kernel=prose, traffic_note=prose))
+                      for k, v in d["records"].items()}
+    for k in ("train_dp", "train_dp_graph", "train_dp_fp32", "train_step", "train_step_bf16", "train_step_bf16x3", "torch_eager_gpu_baseline"):
+        if k in res:
+            res[k] = dict(res[k], sample=prose, launch=prose, optimizer=prose)
+    line = bench.compact_line(res)
+    text = json.dumps(line)
+    assert len(text) < 8000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    for k in ("bf16", "bf16x3", "config5_bf16", "train_cfg2_fp32", "train_cfg3_bf16", "train_cfg3_full_bf16", "train_cfg4_bf16"):
+        assert k in line["records"], (k, line.get("dropped"))
+    assert "torch_eager_gpu_baseline" in line and line["torch_eager_gpu_baseline"]["kind"] == "reference"
+
+
+def test_committed_pmc_profile_is_only_used_for_the_kernel_sources_it_was_measured_on():
+    """roofline.traffic falls back to profiles/pmc_traffic.json only when that profile carries THIS tree's kernel-source hash
+    (the GPU box has no .git: a commit id could not be checked there); otherwise it is null with a note that says why."""
+    import json
+    import bench
+    tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+    sha = bench.kernel_sources_sha()
+    assert len(sha) == 16 and sha == bench.kernel_sources_sha()
+    got, note = bench.pmc_traffic(tj["points"], "fp32")                # no args: the committed-profile path
+    if tj.get("kernel_sources_sha") == sha:
+        assert got == tj["hbm_bytes"] and "NOT by this run" in note
+    else:
+        assert got is None and "other kernel sources" in note
+    assert bench.pmc_traffic(12345, "fp32")[0] is None                 # another workload: no profile
