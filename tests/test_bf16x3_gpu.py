@@ -316,6 +316,44 @@ def test_generated_x3_training_kernels_equal_the_compiler_scheduled_ones_bit_for
     assert torch.isfinite(res[0][0].view(torch.float32)).all()
 
 
+def test_generated_x3_training_kernels_classic_heads_equal_the_compiler_scheduled_ones():
+    """the same bit identity for NeRF(use_new_activation=False) (ReLU / Sigmoid heads, nerf.py:91-100): the `_classic` builds of the
+    generated kernels (dir section and chain prologue compiled with SN_CLASSIC_HEADS) against the `_classic` compiler-scheduled ones"""
+    import sinnerf_amd
+    from sinnerf_amd import _lib
+    n_rays, S = 700, 64
+    rays = np.ascontiguousarray(O.lego_rays(400, 400, seed=0)[::211][:n_rays])
+    z = O.coarse_z_vals(rays, S, False, 1.0, np.random.RandomState(1).uniform(0, 1, (n_rays, S)).astype(np.float32))
+    rays_t, z_t = torch.from_numpy(rays).to(dev()), torch.from_numpy(z).to(dev())
+    P = n_rays * S
+    rows = -(-P // 128) * 128
+    m3 = sinnerf_amd.NeRF(compute_dtype=DT)                                   # use_new_activation=False
+    m3.load_state_dict({k: torch.from_numpy(v) for k, v in O.init_params(3, True).items()})
+    m3 = m3.to(dev())
+    assert m3.kernel_dtype(_lib.SN_DTYPE_BF16X3) & _lib.SN_DTYPE_CLASSIC_HEADS
+    g_raw = torch.from_numpy(np.random.RandomState(2).standard_normal((P, 4)).astype(np.float32)).to(dev())
+    res = []
+    for flag in (0, _lib.SN_DTYPE_COMPILER_SCHEDULED):
+        code = m3.kernel_dtype(_lib.SN_DTYPE_BF16X3) | flag
+        out = torch.full((n_rays, S, 4), 7.0, device=dev())
+        acts = torch.full((10, rows, 256), 7.0, device=dev())
+        emb = torch.full((rows, 128), 7.0, device=dev())
+        G = torch.zeros((10, rows, 256), device=dev())
+        g_o = torch.zeros((P, 4), device=dev())
+        _lib.check(_lib.lib.sn_mlp_forward_train(_lib.ptr(m3.packed()), code, _lib.ptr(rays_t), _lib.ptr(z_t), n_rays, S, _lib.ptr(out), _lib.ptr(acts),
+                                                 _lib.ptr(emb), rows, _lib.stream_ptr()), "fwd")
+        _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m3.packed_bwd(DT)), code, _lib.ptr(acts), _lib.ptr(out), _lib.ptr(g_raw), P, rows, _lib.ptr(G),
+                                                  _lib.ptr(g_o), _lib.stream_ptr()), "chain")
+        torch.cuda.synchronize()
+        res.append([t.view(torch.int32) for t in (out, acts, emb, G, g_o)])
+    for name, new, old in zip(("out", "acts", "emb", "G", "g_out"), *res):
+        assert torch.equal(new, old), (name, int((new != old).sum()))
+    o = res[0][0].view(torch.float32)
+    assert torch.isfinite(o).all() and (o[..., :3] >= 0).all() and (o[..., :3] <= 1).all()      # Sigmoid outputs
+    d = res[0][1].view(torch.float32)[9, :P, :128]
+    assert (d >= 0).all() and (d == 0).float().mean() > 0.05                                    # slot 9: a ReLU output, not a softplus one
+
+
 # ---- stage-level bars against the ORACLE's emulation of this arithmetic (VERDICT r4 weak #2 / next #3) ------------------------------
 # The three tests above compare HIP with HIP (x3 kernel vs fp32 kernel on the same state): regression, not parity.  Below, every
 # stage output is held to oracle_np under bf16x3_operands() / nerf_backward(operand_round="bf16x3") -- the same (hi, lo) operand pairs
