@@ -408,7 +408,7 @@ class X3TrunkRun:
                 hi, lo = split8(f[:, 8 * ks: 8 * ks + 8])
                 wave.v[4 * ks: 4 * ks + 4] = hi
                 wave.v[16 + 4 * ks: 16 + 4 * ks + 4] = lo
-            sb = X3_STAGE_OFF + w * 4096
+            sb = X3_STAGE_OFF + w * 4608                 # (a wave's trunk tile inside its own 4 608-byte dir-section tile)
             for i in range(3):
                 wave.v[32 + i] = X3_TAIL_BYTES + slots[i] * X3_SLOT_BYTES + LANE * 16
                 wave.s[6 + i] = X3_TAIL_BYTES + slots[i] * X3_SLOT_BYTES + w * 1024
@@ -529,7 +529,7 @@ class X3ChainRun:
                 rows = words[32 * w + 4 * l: 32 * w + 4 * l + 4].reshape(64, 4)       # [lane][tile pair]
                 for q in range(4):
                     wave.v[64 + 4 * l + q] = rows[:, q]
-            sb = XC_STAGE_OFF + w * 4096
+            sb = XC_STAGE_OFF + w * 4608
             wave.v[32] = XC_RING_OFF + LANE * 16
             wave.v[33] = XC_RING_OFF + 2 * XC_SLOT + LANE * 16
             wave.v[34] = 4 * (BB_ZERO_FLOATS + BB_AUX_SIGT + 128 * LH)
