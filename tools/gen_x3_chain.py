@@ -11,7 +11,7 @@ scheduler of tools/gen_bf16_trunk.py (class Gen) like the training forward (tool
 tools/gcn_sim.py (tests/test_streams_cpu.py).
 
 Per output tile (slab s = tile t of chain layer L) the deferred epilogue, run inside slab s + 1, per block of four accumulator registers:
-  x = A + B (v_pk_add_f32); [xyz_encoding_final^T: the sigma head's term x += sigma.weight[f] g_sigma (nerf.py:136), v_fmac_f32];
+  x = A + B (v_add_f32); [xyz_encoding_final^T: the sigma head's term x += sigma.weight[f] g_sigma (nerf.py:136), v_fmac_f32];
   [ReLU mask from the SIGN WORD the training forward left for this (layer, tile pair): v_bfe_i32 + v_and_b32 per value]; hi = cvt_pk(v)
   -> AGPRs of the other activation set; lo = cvt_pk(v - float(hi)) -> AGPRs; two v_permlane32_swap_b32 + ONE ds_write_b128 into the
   wave's staging tile (32 rows x 128 B, chunk ^= row & 7: conflict-free both ways); then the tile's row stores: 4 x (ds_read_b128 +

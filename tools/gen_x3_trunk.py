@@ -8,15 +8,16 @@ fragment then the lo fragment, csrc/sn_layout.h DT_BF16X3), 3 264 MFMAs.  Same a
 training state ("x3 state": (hi, lo) pairs in slots 0..8, ReLU sign words in the unused half of slot 9) as the compiler-scheduled
 mlp_fwd_bf16x3_kernel<false, 0, true> it replaces -- held to it bit for bit on the device (tests/test_bf16x3_gpu.py) and executed on
 the CPU by tools/gcn_sim.py (tests/test_streams_cpu.py).  What changes is who lays out the instruction stream: the compiler-scheduled
-kernel issued 6.1 non-MFMA instructions per MFMA with the waves parked 24 % of the time and ran its matrix pipe 45 % busy
-(profiles/r04_x3_train_kernels.txt); here the whole trunk is ONE asm statement from the list scheduler of tools/gen_bf16_trunk.py
+kernel issued 6.1 non-MFMA instructions per MFMA with the waves parked 24 % of the time and ran its matrix pipe 45-50 % busy
+(profiles/r04_x3_train_kernels.txt; this stream: 4.7 per MFMA, 54-58 % busy, -14 % cycles -- most of which the power-limited chip returns as clock:
+profiles/r05_x3_stage_ab.txt); here the whole trunk is ONE asm statement from the list scheduler of tools/gen_bf16_trunk.py
 (class Gen): MFMAs back to back, everything else dealt into their 32-cycle shadows with counted lgkmcnt / vmcnt waits.
 
 Per slab (one 32-row output tile x full K) the fillers are
   * A fragments: per k-step two ds_read_b128 (hi, lo) into a ring of four 8-register entries, prefetch distance 3 k-steps;
   * the bias of the next slab (4 x ds_read_b128 into v[192:207], the C operand of chain A's first MFMA);
-  * the deferred epilogue of the previous slab's tile, per block of four accumulator registers (27 VALU + 1 LDS):
-      v = A + B (v_pk_add_f32) [ReLU: v_max_f32]; hi = cvt_pk(v) -> AGPRs; lo = cvt_pk(v - float(hi)) (v_pk_add_f32 neg) -> AGPRs;
+  * the deferred epilogue of the previous slab's tile, per block of four accumulator registers (31 VALU + 1 LDS; 27 with pk=1):
+      v = A + B (v_add_f32) [ReLU: v_max_f32]; hi = cvt_pk(v) -> AGPRs; lo = cvt_pk(v - float(hi)) (v_sub_f32) -> AGPRs;
       [layer 8: sigma head v_fmac_f32 on the fp32 ReLU outputs]; ReLU sign bits (v_pk_min_u16 + v_lshl_or_b32) into the layer's
       sign words; two v_permlane32_swap_b32 give lanes 0..31 the whole 16-byte hi chunk of 8 features and lanes 32..63 the lo chunk;
       ONE ds_write_b128 into the wave's staging tile [32 rows x 128 B, 16-byte chunk c of row j at chunk c ^ (j & 7)] -- writes
