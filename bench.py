@@ -98,13 +98,16 @@ def roofline_record(dtype, n_rays, NS, NI, ms_fine, ms_coarse, ms_step, traffic=
 
 
 def kernel_sources_sha():
-    """sha256 over the kernel sources and their generators (what a committed PMC profile was measured ON): a profile stamped with a
-    different hash describes other kernels and is refused.  (The GPU box has no .git: a commit id cannot be checked there.)"""
+    """sha256 over the kernel sources as they are COMPILED -- csrc/*.hip, *.h, the generated *.inc instruction streams (build products of
+    tools/gen_*.py, present wherever the library was built) and the Makefile: what a committed PMC profile was measured ON.  A profile stamped
+    with a different hash describes other kernels and is refused.  (The GPU box has no .git: a commit id cannot be checked there; the generators'
+    own text is not hashed -- a docstring edit changes no kernel.)"""
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(REPO, "sinnerf_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "sinnerf_amd", "csrc", "*.h"))
-                   + glob.glob(os.path.join(REPO, "tools", "gen_*.py")) + [os.path.join(REPO, "sinnerf_amd", "csrc", "Makefile")])
+    csrc = os.path.join(REPO, "sinnerf_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.inc"))
+                   + [os.path.join(csrc, "Makefile")])
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
     return h.hexdigest()[:16]
