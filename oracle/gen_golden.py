@@ -32,8 +32,9 @@ torch.set_num_threads(8)
 
 
 def ref_model(seed, teacher, new_act=True):
+    """seed: int -> oracle_np.init_params(seed, teacher); "trained:coarse" / "trained:fine" -> the trained-student fixture."""
     m = NeRF(use_new_activation=new_act)
-    p = O.init_params(seed, teacher)
+    p = O.trained_params(seed.split(":")[1]) if isinstance(seed, str) else O.init_params(seed, teacher)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
     return m.eval(), p
 
@@ -92,7 +93,9 @@ def case_render(name, rays, seeds, teacher, **kw):
             k, d = next(it); assert k == "rand"; rng["u"] = d
         k, d = next(it); assert k == "randn"; rng["noise_fine"] = d
     assert next(it, None) is None
-    meta = dict(seed_coarse=seeds[0], seed_fine=seeds[1], teacher=int(teacher),
+    trained = isinstance(seeds[0], str)
+    meta = dict(seed_coarse=-1 if trained else seeds[0], seed_fine=-1 if trained else seeds[1], teacher=int(teacher),
+                weights="trained_student" if trained else "init",
                 use_disp=int(kw.get("use_disp", False)), test_time=int(kw.get("test_time", False)),
                 chunk=kw.get("chunk", 32768),
                 **{k: kw[k] for k in ("N_samples", "perturb", "noise_std", "N_importance", "white_back")})
@@ -162,7 +165,7 @@ def main():
     print("done ->", OUT)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--grads", "--rays", "--loss", "--pfm", "--classic-heads")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--grads", "--rays", "--loss", "--pfm", "--classic-heads", "--trained")):
     main()
 
 
@@ -189,7 +192,9 @@ def case_grad(name, rays, seeds, **kw):
     arrays = {"rays": rays, "loss": np.asarray(loss.item())}
     arrays.update({"rng_" + k: v for k, v in zip(names, draws)})
     arrays.update({"coef_" + k: v for k, v in coef.items()})
-    arrays.update({"meta_" + k: np.asarray(v) for k, v in dict(seed_coarse=seeds[0], seed_fine=seeds[1], **kw).items()})
+    trained = isinstance(seeds[0], str)
+    arrays.update({"meta_" + k: np.asarray(v) for k, v in dict(seed_coarse=-1 if trained else seeds[0], seed_fine=-1 if trained else seeds[1],
+                                                               weights="trained_student" if trained else "init", **kw).items()})
     arrays.update({"out_" + k: v.detach().numpy() for k, v in res.items()})
     idx_r = np.random.RandomState(5)
     for tag, m in (("coarse", mc), ("fine", mf)):
@@ -387,3 +392,26 @@ def main_pfm():
 
 if __name__ == "__main__" and "--pfm" in sys.argv:
     main_pfm()
+
+
+def main_trained():
+    """TRAINED weights: tests/golden/trained_student.npz (tools/train_student.py: the 2 000-step fp32 student of
+    tools/convergence.py, trained once on the MI355X) rendered by the unmodified reference -- eval 64+64 lego, 64+128 llff
+    (white_back=False), one perturb=1 / noise_std=1 training render, one autograd-gradient case."""
+    T = ("trained:coarse", "trained:fine")
+    lego = O.lego_rays(400, 400, seed=1)               # the student's held-out pose
+    sel = np.random.RandomState(23).choice(lego.shape[0], 192, replace=False)
+    lego_s = np.ascontiguousarray(lego[sel])
+    case_render("render_trained_lego_eval", lego_s, T, True, N_samples=64, perturb=0, noise_std=0, N_importance=64, white_back=True)
+    case_render("render_trained_llff_eval_128", llff_like_rays(96, 15), T, True, N_samples=64, perturb=0, noise_std=0,
+                N_importance=128, white_back=False)
+    case_render("render_trained_lego_train", lego_s[:128], T, True, N_samples=64, perturb=1.0, noise_std=1.0, N_importance=64,
+                white_back=True)
+    lego0 = O.lego_rays(400, 400, seed=0)              # a training pose
+    sel0 = np.random.RandomState(29).choice(lego0.shape[0], 96, replace=False)
+    case_grad("grad_trained_lego_train", np.ascontiguousarray(lego0[sel0]), T, N_samples=64, perturb=1.0, noise_std=1.0,
+              N_importance=64, white_back=True)
+
+
+if __name__ == "__main__" and "--trained" in sys.argv:
+    main_trained()

@@ -21,6 +21,8 @@ Conventions
 * ``params`` is a dict keyed exactly like ``NeRF.state_dict()``
   (``xyz_encoding_1.0.weight`` ... ``rgb.0.bias``), values ``np.float32`` arrays.
 """
+import os
+
 import numpy as np
 
 F = np.float32
@@ -90,6 +92,24 @@ class bf16_operands:
 
 _HEADS_FP32 = True
 _SPLIT3 = False
+
+
+def fp16_round(a):
+    """Round fp32 -> fp16 -> fp32 (RNE, overflow -> inf as v_cvt_pk_f16_f32 does without clamp)."""
+    with np.errstate(over="ignore"):
+        return np.ascontiguousarray(a, F).astype(np.float16).astype(F)
+
+
+class fp16_operands(bf16_operands):
+    """Context manager: as ``bf16_operands`` with fp16-rounded operands (11 significand bits instead of 8; v_mfma_f32_32x32x16_f16
+    runs at the bf16 rate on gfx950).  ORACLE-SIDE EXPERIMENT ONLY: no kernel implements it; tools/precision_probe.py
+    prints what it would buy on the trained-weight fixtures."""
+
+    def __enter__(self):
+        global _OPERAND_ROUND
+        super().__enter__()
+        _OPERAND_ROUND = fp16_round
+        return self
 
 
 def bf16_split(a):
@@ -597,6 +617,27 @@ def init_params(seed, teacher=False):
         p["sigma.weight"] = (p["sigma.weight"] * F(8)).astype(F)
         p["sigma.bias"] = np.full((1,), 0.3, F)
     return p
+
+
+TRAINED_STUDENT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "trained_student.npz")
+
+
+def trained_params(tag, path=None):
+    """TRAINED weights: the 2 000-step fp32 student of tools/convergence.py (tools/train_student.py writes the fixture
+    tests/golden/trained_student.npz; tag = "coarse" | "fine"; keys = the reference's ``NeRF.state_dict()``, nerf.py:66-103).
+    ``scale`` variants for the precision study live in model_params()."""
+    z = np.load(path or TRAINED_STUDENT)
+    p = {k[len(tag) + 1:]: np.ascontiguousarray(z[k], F) for k in z.files if k.startswith(tag + ".")}
+    assert set(p) == set(param_shapes()), sorted(set(p) ^ set(param_shapes()))
+    return p
+
+
+def model_params(meta):
+    """[coarse, fine] parameter dicts of a golden render / gradient case from its ``meta_*`` entries: seeded init weights
+    (``seed_coarse`` / ``seed_fine`` / ``teacher``) or, when ``meta["weights"] == "trained_student"``, the trained fixture."""
+    if str(meta.get("weights", "")) == "trained_student":
+        return [trained_params("coarse"), trained_params("fine")]
+    return [init_params(meta["seed_coarse"], bool(meta.get("teacher", True))), init_params(meta["seed_fine"], bool(meta.get("teacher", True)))]
 
 
 def lego_rays(H, W, seed=0, camera_angle_x=0.6911112, radius=4.0, near=2.0, far=6.0, sel=None):

@@ -1,0 +1,122 @@
+"""GPU: parity on TRAINED weights (SURVEY section 7 "precision behaviour changes with trained weights").
+tests/golden/trained_student.npz is the 2 000-step fp32 student (tools/train_student.py); render_trained_* / grad_trained_* are the
+UNMODIFIED reference's outputs on it (oracle/gen_golden.py --trained).  Bars: fp32 AND bf16x3 at the fp32 bars of tests/helpers.py
+(1e-3 rel + 1e-5 on rgb / depth, opacity 1e-4), bf16 at |dPSNR| <= 0.05 dB (north_star), gradients norm-wise.  Every measured
+err/bound is printed and appended to gpurun_out/trained_parity.json (quoted in DESIGN.md section 2)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_np as O                                                                   # noqa: E402
+from tests.helpers import check_render, load_case                                                   # noqa: E402
+from tests.test_oracle_grads import grad_errors, load_grad_case                                    # noqa: E402
+from tests.test_parity_gpu import dev, embeddings, injected_rng, rng_order, to_np                   # noqa: E402
+from tests.test_trained_weights_cpu import TRAINED_GRAD_CASES, TRAINED_RENDER_CASES, err_over_bound  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def record(key, value):
+    path = os.path.join(REPO, "gpurun_out", "trained_parity.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d[key] = value
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+
+
+def trained_models(dtype="fp32", train=False):
+    import sinnerf_amd
+    out = []
+    for tag in ("coarse", "fine"):
+        m = sinnerf_amd.NeRF(use_new_activation=True, compute_dtype=dtype)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in O.trained_params(tag).items()})
+        m = m.to(dev())
+        out.append(m.train() if train else m.eval())
+    return out
+
+
+def render_case(name, dtype):
+    import sinnerf_amd
+    rays, meta, rng, ref = load_case(name)
+    with torch.no_grad(), injected_rng(rng_order(meta, rng, rays.shape[0])) as left:
+        res = sinnerf_amd.render_rays(trained_models(dtype), embeddings(), torch.from_numpy(rays).to(dev()), meta["N_samples"],
+                                      bool(meta["use_disp"]), meta["perturb"], meta["noise_std"], meta["N_importance"], meta["chunk"],
+                                      bool(meta["white_back"]), test_time=bool(meta["test_time"]))
+        assert not left, "render_rays consumed fewer random draws than the reference"
+    torch.cuda.synchronize()
+    assert set(res.keys()) == set(ref.keys())
+    return to_np(res), ref
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name", TRAINED_RENDER_CASES)
+def test_render_trained_weights_at_the_fp32_bar(name, dtype):
+    got, ref = render_case(name, dtype)
+    e = err_over_bound(got, ref)
+    print(f"{name} [{dtype}]: worst err / fp32 bound = {e:.4f}")
+    record(f"{name}:{dtype}:err_over_bound", e)
+    check_render(got, ref, tag=f"{name}:{dtype}")
+
+
+@pytest.mark.parametrize("name", TRAINED_RENDER_CASES)
+def test_render_trained_weights_bf16_psnr_bar(name):
+    """north_star's reduced-precision bar: PSNR within 0.05 dB of the reference render (SURVEY section 8d protocol: gt = reference
+    render + fixed pixel noise of sigma 0.02)."""
+    got, ref = render_case(name, "bf16")
+    gt = ref["rgb_fine"] + np.random.RandomState(0).normal(0, 0.02, ref["rgb_fine"].shape).astype(np.float32)
+    d = O.psnr(got["rgb_fine"], gt) - O.psnr(ref["rgb_fine"], gt)
+    e = err_over_bound(got, ref)
+    print(f"{name} [bf16]: dPSNR = {d:+.4f} dB, PSNR(new, ref) = {O.psnr(got['rgb_fine'], ref['rgb_fine']):.1f} dB, err / fp32 bound = {e:.3f}")
+    record(f"{name}:bf16:dpsnr_db", d)
+    record(f"{name}:bf16:err_over_bound", e)
+    assert all(np.isfinite(v).all() for v in got.values())
+    assert abs(d) <= 0.05, d
+    assert O.psnr(got["rgb_fine"], ref["rgb_fine"]) > 50.0
+
+
+@pytest.mark.parametrize("name", TRAINED_GRAD_CASES)
+def test_render_gradients_on_trained_weights(name):
+    """autograd gradients of the reference on the trained student (perturb=1, noise_std=1, the recorded draws injected): the all-fp32 HIP
+    path at the bars test_render_rays_gradients_golden uses; bf16x3 at the bars of test_bf16x3_render_gradients_golden (ReLU kinks);
+    bf16 norm-wise (3e-2 on the large tensors, cosine >= 0.999) against the same golden gradients."""
+    import sinnerf_amd
+    from tests.test_grads_gpu import model_grads
+    z, meta, rng, coef = load_grad_case(name)
+    rays = z["rays"]
+    got = {}
+    for dt in ("fp32", "bf16x3", "bf16"):
+        mc, mf = trained_models(dt, train=True)
+        with injected_rng(rng_order(dict(meta, use_disp=0), rng, rays.shape[0])) as left:
+            res = sinnerf_amd.render_rays([mc, mf], embeddings(), torch.from_numpy(rays).to(dev()), meta["N_samples"], False, meta["perturb"],
+                                          meta["noise_std"], meta["N_importance"], 32768, bool(meta["white_back"]))
+            assert not left
+        loss = sum((res[k] * torch.from_numpy(v).to(dev())).sum() for k, v in coef.items())
+        tol = 2e-4 if dt != "bf16" else 2e-2
+        assert abs(loss.item() - float(z["loss"])) <= tol * max(1.0, abs(float(z["loss"]))), (dt, loss.item(), float(z["loss"]))
+        loss.backward()
+        got[dt] = [model_grads(mc), model_grads(mf)]
+    worst = {}
+    for dt in got:
+        errs = grad_errors(z, got[dt])
+        worst[dt] = {"sampled_coarse": max(e for (t, _), (e, _) in errs.items() if t == "coarse"),
+                     "sampled_fine": max(e for (t, _), (e, _) in errs.items() if t == "fine"),
+                     "norm_coarse": max(d for (t, _), (_, d) in errs.items() if t == "coarse"),
+                     "norm_fine": max(d for (t, _), (_, d) in errs.items() if t == "fine")}
+        print(name, dt, {k: "%.2e" % v for k, v in worst[dt].items()})
+        record(f"{name}:{dt}:grad_err", worst[dt])
+    w = worst["fp32"]
+    assert w["sampled_coarse"] <= 1e-4 and w["norm_coarse"] <= 1e-4 and w["sampled_fine"] <= 5e-3 and w["norm_fine"] <= 5e-3, w
+    w = worst["bf16x3"]
+    assert max(w["sampled_coarse"], w["sampled_fine"]) <= 1e-2 and max(w["norm_coarse"], w["norm_fine"]) <= 2e-3, w
+    # bf16: whole tensors against the all-fp32 HIP path, norm-wise + direction (sampled entries are too few for a 1e-2-class arithmetic)
+    for g16, g32 in zip(got["bf16"], got["fp32"]):
+        big = [k for k, v in g32.items() if v.ndim == 2 and v.size >= 128 * 256]
+        for k in big:
+            d = np.linalg.norm(g16[k] - g32[k]) / max(np.linalg.norm(g32[k]), 1e-30)
+            c = float((g16[k] * g32[k]).sum() / max(np.linalg.norm(g16[k]) * np.linalg.norm(g32[k]), 1e-30))
+            assert d <= 3e-2 and c >= 0.999, (k, d, c)

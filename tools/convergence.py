@@ -57,7 +57,7 @@ def batches(n_rays, steps, seed):
     return [torch.randint(0, n_rays, (BATCH,), generator=g) for _ in range(steps)]
 
 
-def run_amd(dtype, seed, steps, sc, dev):
+def run_amd(dtype, seed, steps, sc, dev, keep_state=None):
     from sinnerf_amd.system import SinNeRFSystem
     train_rays, tgt, held, tgt_held = sc
     sysm = SinNeRFSystem(N_importance=64, compute_dtype=dtype, perturb=1.0, noise_std=1.0, white_back=True, lr=5e-4,
@@ -91,6 +91,9 @@ def run_amd(dtype, seed, steps, sc, dev):
             losses.append((i, float(out["loss"])))
     evaluate(steps)
     torch.cuda.synchronize()
+    if keep_state is not None:                                     # tools/train_student.py: the trained weights as a fixture
+        for tag, m in zip(("coarse", "fine"), sysm.models):
+            keep_state[tag] = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
     return {"path": dtype, "seed": seed, "psnr_curve": curve, "loss_curve": losses, "final_psnr": curve[-1][1],
             "seconds": time.perf_counter() - t0}
 
