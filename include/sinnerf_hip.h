@@ -58,6 +58,11 @@ extern "C" {
  * bit 1: dtype SN_DTYPE_BF16 only -- run the compiler-scheduled kernel (csrc/sn_mlp_fwd_bf16.hip) instead of the
  * hand-scheduled one (csrc/sn_mlp_fwd_bf16_v3.hip); same arithmetic, kept for A/B timing and as the sigma-only / training form. */
 #define SN_FLAG_BF16_COMPILER_SCHEDULED 2
+/* bit 2: dtype SN_DTYPE_F32 only -- run the round-1..5 inference kernel (csrc/sn_mlp_fwd.hip: weights through an LDS ring filled by
+ * LDS-DMA, one barrier per slab) instead of the round-6 one (csrc/sn_mlp_fwd_f32g.hip: A fragments straight from L2 into a register
+ * ring, no VALU instruction in the trunk, no barrier); bit-identical results, kept for A/B timing.  Also honoured by
+ * sn_mlp_forward_embedded. */
+#define SN_FLAG_F32_LDS_RING 4
 
 int sn_abi_version(void);
 const char* sn_error_string(int code);

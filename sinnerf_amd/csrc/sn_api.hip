@@ -7,6 +7,10 @@ extern "C" {
 int sn_mlp_forward_f32_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                               int sigma_only, int input_mode, float* out, float* acts, float* emb,
                               long slot_rows, hipStream_t stream);
+int sn_mlp_forward_f32g_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld, int sigma_only,
+                               int input_mode, float* out, hipStream_t stream);
+int sn_mlp_forward_f32g_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld, int sigma_only,
+                                       int input_mode, float* out, hipStream_t stream);
 int sn_mlp_forward_f32_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                               int sigma_only, int input_mode, float* out, float* acts, float* emb,
                               long slot_rows, hipStream_t stream);
@@ -213,6 +217,9 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out, nullptr,
                                                   nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
+  if (!(flags & SN_FLAG_F32_LDS_RING))           // round 6: fragments straight from L2, VALU-free trunk (csrc/sn_mlp_fwd_f32g.hip)
+    return SN_HEADS(classic, sn_mlp_forward_f32g)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out,
+                                                  (hipStream_t)stream);
   return SN_HEADS(classic, sn_mlp_forward_f32)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0,
                                                out, nullptr, nullptr, 0, (hipStream_t)stream);
 }
@@ -367,6 +374,8 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   if (dtype == SN_DTYPE_BF16)
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;
+  if (!(flags & SN_FLAG_F32_LDS_RING))
+    return SN_HEADS(classic, sn_mlp_forward_f32g)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, (hipStream_t)stream);
   return SN_HEADS(classic, sn_mlp_forward_f32)(blob, x, nullptr, n_rows, ld, sigma_only, 1,
                                                out, nullptr, nullptr, 0, (hipStream_t)stream);
 }

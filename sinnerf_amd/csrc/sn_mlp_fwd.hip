@@ -74,6 +74,13 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
   const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;                       // this lane's register quads
   const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;    // row lane>>3, 16-byte chunk lane&7
   const unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
+  // epilogue staging (epi32_*_lds, sn_mlp_pipe.h): where this lane's accumulator quad q goes.  Training forward: the quad's place in the
+  // staging tile of the activation stores (row j, floats 8 q + 4 h ..), which the row stores read afterwards; inference: a tile of its own.
+  unsigned epi_a = STORE ? (unsigned)(size_t)xp + xp_w : (unsigned)(size_t)(smem + MLP_F32_LDS_BYTES_V2 + wave * EPI_WAVE_BYTES) + lane * 16;
+  constexpr int EPI_Q = STORE ? 32 : 1024;                   // byte step between the quads of a lane
+  unsigned vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));             // opaque: stays ONE live register (an immediate would be re-materialised per block)
+  asm volatile("" : "+v"(epi_a));
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
   const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * 32;       // wave-uniform, in SGPRs
@@ -136,25 +143,31 @@ mlp_fwd_f32_kernel(const char* __restrict__ blob, const float* __restrict__ in0,
       __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
     }
   };
+  auto quad = [](const f32x16& r, int q) __attribute__((always_inline)) {       // registers 4q..4q+3 of an accumulator set, as they lie
+    f32x4 x;
+    x[0] = r[4 * q]; x[1] = r[4 * q + 1]; x[2] = r[4 * q + 2]; x[3] = r[4 * q + 3];
+    return x;
+  };
   auto relu_slice = [&](auto wset, int slot, int t, int q, const f32x16& r) __attribute__((always_inline)) {
     constexpr int W = decltype(wset)::value;
-    float v[4];
-    epi32_relu(W * 128 + 16 * t + 4 * q, r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3], v);
     if (slot == 7) {                             // layer 8 feeds the sigma head: same accumulation order as a K-slot sweep
+      f32x4 v;                                   // ... which needs the activated values in VGPRs: ReLU on the VALU here
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = relu1(r[4 * q + i]);
       const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t + 4 * q);
       sg = __builtin_fmaf(w[0], v[0], sg);
       sg = __builtin_fmaf(w[1], v[1], sg);
       sg = __builtin_fmaf(w[2], v[2], sg);
       sg = __builtin_fmaf(w[3], v[3], sg);
       asm volatile("" : "+v"(sg));
+      epi32_copy_lds(W * 128 + 16 * t + 4 * q, epi_a, EPI_Q * q, v);
+    } else {                                     // no VALU: ds_write_b128, ReLU by LDS integer max, ds_read_b128 into the AGPRs
+      epi32_relu_lds(W * 128 + 16 * t + 4 * q, epi_a, EPI_Q * q, quad(r, q), vzero);
     }
-    stage(q, v);
   };
   auto copy_slice = [&](auto wset, int slot, int t, int q, const f32x16& r) __attribute__((always_inline)) {   // xyz_encoding_final
     constexpr int W = decltype(wset)::value;
-    epi32_copy(W * 128 + 16 * t + 4 * q, r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
-    const float v[4] = {r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
-    stage(q, v);
+    epi32_copy_lds(W * 128 + 16 * t + 4 * q, epi_a, EPI_Q * q, quad(r, q));
   };
 #define SN_LW_CUR (ring.slot(cslot) + lane * 16)
 #define SN_LW_NEXT (ring.slot(cslot == 2 ? 0 : cslot + 1) + lane * 16)
@@ -315,7 +328,7 @@ extern "C" int SN_LAUNCH_NAME(sn_mlp_forward_f32)(const void* blob, const float*
   // persistent launch: one workgroup per CU (the 135 KB LDS ring admits exactly one), each walks tiles b, b+grid, ...
   const int n_cu = snh::cu_count();
   dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
-  const size_t lds = MLP_F32_LDS_BYTES_V2 + (store ? XPOSE_LDS_BYTES : 0);
+  const size_t lds = MLP_F32_LDS_BYTES_V2 + (store ? XPOSE_LDS_BYTES : EPI_LDS_BYTES);
   const char* b = reinterpret_cast<const char*>(blob);
 #define SN_LAUNCH(SO, IM, ST)                                                                                    \
   do {                                                                                                           \

@@ -1,0 +1,322 @@
+// sn_mlp_fwd_f32g.hip -- fused NeRF MLP forward for gfx950 (MI355X), fp32 INFERENCE path, third generation (round 6).
+//
+// Replaces the same reference sequence as sn_mlp_fwd.hip (xyz = o + d z, Embedding, cat, NeRF.forward: models/rendering.py:189-201,
+// :284-285, models/nerf.py:36-41, :122-148) with the same arithmetic (v_mfma_f32_32x32x2_f32 in the same K order, the same VALU
+// heads: bit-identical outputs), but a data flow built on what tools/ubench/f32_gap_cost.hip measured
+// (profiles/r06_ubench_f32_gap_cost.txt):
+//
+//   * the f32-input MFMA runs on the f32 VECTOR pipe.  A VALU instruction between two MFMAs is not hidden in the MFMA's shadow
+//     as it is beside the bf16 MFMAs: a gap with n VALU instructions costs 9.6 + 4 n cycles of matrix time (v_mov, v_max,
+//     v_accvgpr_write alike) -- while s_nop, s_waitcnt, SALU, ds_read / ds_write, global loads cost NOTHING there.  (The round-1 law
+//     "64.2 N_mfma + 4.6 N_other" had lumped the classes together.)
+//   * so the trunk carries NO VALU instruction at all:
+//       - A fragments come STRAIGHT FROM L2 into a register ring (buffer_load_dwordx4 with a constant per-lane offset and SGPR slab
+//         offsets: no per-lane address arithmetic), eight groups = 32 MFMAs = 2 048 cycles ahead of their use.  No LDS ring, no
+//         LDS-DMA, no per-slab barrier: the four waves of a workgroup never wait for each other (the packed weights, 2.4 MB, stay
+//         resident in every XCD's 4 MB L2; one wave reads 1 KB per 256 cycles = 16 B/clk per CU, a quarter of the L1 path);
+//       - the epilogue of a 32 x 32 output tile is an LDS round trip (sn_mlp_pipe.h epi32_relu_lds): ds_write_b128 of the
+//         accumulators, ReLU as ds_max_i32 against 0, ds_read_b128 straight into the AGPRs of the next layer's B operand;
+//       - it is deferred into the next slab's first groups ACROSS layer boundaries too (the next layer reads a tile's K-slots only
+//         in its groups 4 t ..), so no layer end drains the matrix pipe.
+//   * what VALU work is left sits where it cannot be avoided: the embeddings (exact range reduction), the sigma head's 256 FMAs,
+//     ShiftedSoftplus and the rgb head -- 2.6 k instructions per 128-point tile beside 9 280 MFMAs per wave.
+// The training forward (activation stores) and the backward chain stay on sn_mlp_fwd.hip / sn_mlp_bwd.hip (LDS ring, same epilogues).
+#include "sn_mlp_pipe.h"
+#include <type_traits>
+
+namespace snk {
+
+constexpr int FD = 8;                                        // fragment ring depth (groups of four k-steps)
+constexpr int F32G_LDS_BYTES = TAIL_LDS_BYTES + EPI_LDS_BYTES;   // bias / head table + the epilogue staging of four waves
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+// one 1 KB A fragment (64 lanes x 16 B): wave-uniform byte offset in an SGPR, constant per-lane offset in a VGPR
+SN_DEV f32x4 load_frag(rsrc_t rs, unsigned voff, unsigned soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+// One slab = NG0 + NG1 groups of four k-steps (SET0 / SET1 / bv as in slab_f32a).  fr = the fragment ring: on entry the fragments of
+// groups 0 .. FD-2 of this slab are in flight or landed in entries (RB + g) % FD; group g's first gap requests group g - 1 + FD into the
+// entry group g - 1 vacated (of this slab at byte offset `so`, or of the stream's next slab at `so_next`).  pending(q): slice q of the
+// previous slab's epilogue (groups 0..3).  acc = this slab's accumulators (bias-initialised), accn = the previous slab's result until
+// pending() has consumed it, then the bias of slab s_next.
+template <int NG0, int NG1, int SET0, int SET1, int RB, class Pending>
+SN_DEV void slab_f32g(f32x16& acc, f32x16& accn, f32x4 (&fr)[FD], rsrc_t rs, unsigned voff, unsigned so, unsigned so_next,
+                      const float* bv, const float* lds_bias, int s_next, int h, Pending&& pending) {
+  constexpr int NG = NG0 + NG1;
+  static_assert(NG >= FD && NG % 4 == 0, "the ring never reaches past the next slab");
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the epilogue's AGPR loads (groups 0..3) have landed
+    if (g == 4) accn = load_bias(lds_bias, s_next, h);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 a_cur = fr[(RB + g) % FD];
+    auto mma = [&](int kk) __attribute__((always_inline)) {
+      if (g == 0 && kk == 0) {
+        if (SET0 < 0) mma32_v<true>(acc, a_cur[0], bv[0]); else mma32_a<true>(acc, a_cur[0], SET0 * 128);
+      } else if (g < NG0) {
+        if (SET0 < 0) mma32_v<false>(acc, a_cur[kk], bv[4 * g + kk]); else mma32_a<false>(acc, a_cur[kk], SET0 * 128 + 4 * g + kk);
+      } else {
+        if (SET1 < 0) mma32_v<false>(acc, a_cur[kk], bv[4 * (g - NG0) + kk]);
+        else mma32_a<false>(acc, a_cur[kk], SET1 * 128 + 4 * (g - NG0) + kk);
+      }
+    };
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    {                                            // gap 2: the fragment FD - 1 groups ahead, into the entry the previous group left
+      const int r = g - 1 + FD;
+      fr[(RB + g - 1 + FD) % FD] = (r < NG) ? load_frag(rs, voff, so + r * 1024) : load_frag(rs, voff, so_next + (r - NG) * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g < 4) pending(g);                       // gap 3: epilogue slice of the previous slab (LDS instructions only in the trunk)
+    __builtin_amdgcn_sched_barrier(0);
+    mma(3);
+  }
+}
+
+constexpr unsigned slab_byte_offset(int s) { return (unsigned)(snl::slab_elem_offset(s) * 4); }
+
+// INPUT_MODE 0: points from (rays, z_vals); 1: pre-embedded rows x[p, 0:63(+27)] with leading dimension ld (NeRF.forward path)
+template <bool SIGMA_ONLY, int INPUT_MODE>
+__global__ void __launch_bounds__(256)
+mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1, long P, int S,
+                    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds_bias = reinterpret_cast<float*>(smem);
+  const float* lds_aux = lds_bias + snl::BIAS_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  const long n_tiles = (P + 127) / 128;
+  constexpr int N_USED = SIGMA_ONLY ? snl::SLAB_FIN : snl::N_SLABS;
+
+  {
+    const float4* gb = reinterpret_cast<const float4*>(blob + snl::bias_byte_offset(snl::DT_F32));
+    float4* lb = reinterpret_cast<float4*>(lds_bias);
+    for (int i = tid; i < snl::TAIL_FLOATS / 4; i += 256) lb[i] = gb[i];
+  }
+  __syncthreads();                               // bias / head table visible; the ONLY barrier of the kernel
+
+  asm volatile("" ::: "a0", "a255");             // size the kernel for the whole hand-managed AGPR file (sn_mlp_pipe.h)
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(blob), 0, (int)snl::blob_bytes(snl::DT_F32), 0x00020000);
+  unsigned voff = lane * 16;
+  asm volatile("" : "+v"(voff));
+  f32x4 fr[FD];
+#pragma unroll
+  for (int g = 0; g < FD - 1; ++g) fr[g] = load_frag(rs, voff, g * 1024);      // slab 0, groups 0 .. FD-2
+  f32x16 acc0 = load_bias(lds_bias, 0, h), acc1;
+  unsigned epi_a = (unsigned)(size_t)(smem + TAIL_LDS_BYTES + wave * EPI_WAVE_BYTES) + lane * 16;
+  unsigned vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  asm volatile("" : "+v"(epi_a));
+
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const long p_wave = (tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * 32;
+  const long p_raw = p_wave + j;
+  const bool valid = p_raw < P;
+  const long p = valid ? p_raw : P - 1;
+
+  float xe[32];
+  if (INPUT_MODE == 0) {
+    const long ray = p / S;
+    const float* rp = in0 + ray * 8;
+    const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+    const float zz = in1[p];
+    // xyz = o + d*z with separate roundings (torch: mul then add, rendering.py:284-285)
+    const float x = __fadd_rn(ox, __fmul_rn(dx, zz));
+    const float y = __fadd_rn(oy, __fmul_rn(dy, zz));
+    const float z = __fadd_rn(oz, __fmul_rn(dz, zz));
+    embed_xyz(x, y, z, h, xe);
+  } else {
+    const float* row = in0 + p * (long)S;        // S = leading dimension here
+    int hh = h;
+    asm volatile("" : "+v"(hh));
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int c0 = snl::xyz_slot_col(0, e), c1 = snl::xyz_slot_col(1, e);
+      const int c = hh ? c1 : c0;
+      xe[e] = (c >= 0) ? row[c < 0 ? 0 : c] : 0.0f;
+    }
+  }
+
+  float sg = 0.0f;                               // sigma head partial of this lane half (nerf.py:136), K-slot order
+
+  auto quad = [](const f32x16& r, int q) __attribute__((always_inline)) {
+    f32x4 x;
+    x[0] = r[4 * q]; x[1] = r[4 * q + 1]; x[2] = r[4 * q + 2]; x[3] = r[4 * q + 3];
+    return x;
+  };
+  // epilogue slice q of output tile t of a layer: accumulator registers 4q..4q+3 -> K-slots 16t+4q.. of activation set W
+  auto relu_slice = [&](auto wset, auto slot_c, int t, int q, const f32x16& r) __attribute__((always_inline)) {
+    constexpr int W = decltype(wset)::value;
+    constexpr int slot = decltype(slot_c)::value;
+    if (slot == 7) {                             // layer 8 feeds the sigma head, which needs the activated values in VGPRs
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = relu1(r[4 * q + i]);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t + 4 * q);
+      sg = __builtin_fmaf(w[0], v[0], sg);
+      sg = __builtin_fmaf(w[1], v[1], sg);
+      sg = __builtin_fmaf(w[2], v[2], sg);
+      sg = __builtin_fmaf(w[3], v[3], sg);
+      asm volatile("" : "+v"(sg));
+      epi32_copy_lds(W * 128 + 16 * t + 4 * q, epi_a, 1024 * q, v);
+    } else {
+      epi32_relu_lds(W * 128 + 16 * t + 4 * q, epi_a, 1024 * q, quad(r, q), vzero);
+    }
+  };
+  auto copy_slice = [&](auto wset, auto, int t, int q, const f32x16& r) __attribute__((always_inline)) {       // xyz_encoding_final
+    constexpr int W = decltype(wset)::value;
+    epi32_copy_lds(W * 128 + 16 * t + 4 * q, epi_a, 1024 * q, quad(r, q));
+  };
+  auto no_slice = [&](auto, auto, int, int, const f32x16&) __attribute__((always_inline)) {};
+
+#define SN_C(V_) std::integral_constant<int, V_>{}
+  // slab S_ (stream index, literal) = output tile S_ % 8 of its layer; its first groups run the epilogue PEPI_ of the previous slab
+  // (tile PT_ of the layer that writes set PW_ / slot PSLOT_).  Even slabs accumulate in acc0, odd ones in acc1.
+#define SN_SLABG(S_, NG0_, NG1_, S0_, S1_, BV_, PEPI_, PW_, PSLOT_, PT_)                                                  \
+  do {                                                                                                                    \
+    constexpr int s_nx = ((S_) + 1 == N_USED) ? 0 : (S_) + 1;                                                             \
+    constexpr int rb = (S_) >= snl::SLAB_DIR ? (4 * ((S_) - snl::SLAB_DIR)) % FD : 0;                                     \
+    if (((S_) & 1) == 0)                                                                                                  \
+      slab_f32g<NG0_, NG1_, S0_, S1_, rb>(acc0, acc1, fr, rs, voff, slab_byte_offset(S_), slab_byte_offset(s_nx), BV_,    \
+          lds_bias, s_nx, h, [&](int q) __attribute__((always_inline)) { PEPI_(SN_C(PW_), SN_C(PSLOT_), PT_, q, acc1); }); \
+    else                                                                                                                  \
+      slab_f32g<NG0_, NG1_, S0_, S1_, rb>(acc1, acc0, fr, rs, voff, slab_byte_offset(S_), slab_byte_offset(s_nx), BV_,    \
+          lds_bias, s_nx, h, [&](int q) __attribute__((always_inline)) { PEPI_(SN_C(PW_), SN_C(PSLOT_), PT_, q, acc0); }); \
+  } while (0)
+  // the 8 output tiles of layer slot L_ (stream slabs 8 L_ ..): tile 0 finishes the PREVIOUS layer's tile 7 (PEPI_ / PW_ / PSLOT_)
+#define SN_LAYERG(L_, NG0_, NG1_, S0_, S1_, EPI_, W_, PEPI_, PW_, PSLOT_)                 \
+  do {                                                                                    \
+    SN_SLABG(8 * (L_) + 0, NG0_, NG1_, S0_, S1_, xe, PEPI_, PW_, PSLOT_, 7);              \
+    SN_SLABG(8 * (L_) + 1, NG0_, NG1_, S0_, S1_, xe, EPI_, W_, L_, 0);                    \
+    SN_SLABG(8 * (L_) + 2, NG0_, NG1_, S0_, S1_, xe, EPI_, W_, L_, 1);                    \
+    SN_SLABG(8 * (L_) + 3, NG0_, NG1_, S0_, S1_, xe, EPI_, W_, L_, 2);                    \
+    SN_SLABG(8 * (L_) + 4, NG0_, NG1_, S0_, S1_, xe, EPI_, W_, L_, 3);                    \
+    SN_SLABG(8 * (L_) + 5, NG0_, NG1_, S0_, S1_, xe, EPI_, W_, L_, 4);                    \
+    SN_SLABG(8 * (L_) + 6, NG0_, NG1_, S0_, S1_, xe, EPI_, W_, L_, 5);                    \
+    SN_SLABG(8 * (L_) + 7, NG0_, NG1_, S0_, S1_, xe, EPI_, W_, L_, 6);                    \
+  } while (0)
+
+  // layer 0 (xyz_encoding_1, nerf.py:68) reads the xyz embedding (VGPRs), writes set 0; odd layers read set 0 and write set 1, even
+  // layers the reverse; the skip layer (nerf.py:133) reads the embedding first, then set 1
+  SN_LAYERG(0, 8, 0, -1, -1, relu_slice, 0, no_slice, 0, 0);
+  SN_LAYERG(1, 32, 0, 0, 0, relu_slice, 1, relu_slice, 0, 0);
+  SN_LAYERG(2, 32, 0, 1, 1, relu_slice, 0, relu_slice, 1, 1);
+  SN_LAYERG(3, 32, 0, 0, 0, relu_slice, 1, relu_slice, 0, 2);
+  SN_LAYERG(4, 8, 32, -1, 1, relu_slice, 0, relu_slice, 1, 3);
+  SN_LAYERG(5, 32, 0, 0, 0, relu_slice, 1, relu_slice, 0, 4);
+  SN_LAYERG(6, 32, 0, 1, 1, relu_slice, 0, relu_slice, 1, 5);
+  SN_LAYERG(7, 32, 0, 0, 0, relu_slice, 1, relu_slice, 0, 6);
+
+  if (SIGMA_ONLY) {
+    mfma32_result_fence(acc1);                   // slab 63's result: the one epilogue of the tile that is not deferred
+#pragma unroll
+    for (int q = 0; q < 4; ++q) relu_slice(SN_C(1), SN_C(7), 7, q, acc1);
+    const float sigma = sg + __shfl_xor(sg, 32, 64) + lds_aux[snl::AUX_HEADB];
+    if (valid && h == 0) out[p_raw] = sigma;
+    continue;                                    // (acc0 already holds slab 0's bias: slab 63 requested it as its s_next)
+  }
+
+  // xyz_encoding_final (nerf.py:140), no activation: reads set 1, writes set 0; its first slab finishes layer 8 (and the sigma head)
+  SN_LAYERG(8, 32, 0, 1, 1, copy_slice, 0, relu_slice, 1, 7);
+  const float sigma = sg + __shfl_xor(sg, 32, 64) + lds_aux[snl::AUX_HEADB];     // nerf.py:136
+
+  // dir_encoding + ShiftedSoftplus (nerf.py:142-143): reads set 0 and the dir embedding (VGPRs)
+  float de[16];
+  if (INPUT_MODE == 0) {
+    const float* rp = in0 + (p / S) * 8;
+    embed_dir(rp[3], rp[4], rp[5], h, de);
+  } else {
+    const float* row = in0 + p * (long)S;
+    int hh = h;
+    asm volatile("" : "+v"(hh));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c0 = snl::dir_slot_col(0, e), c1 = snl::dir_slot_col(1, e);
+      const int c = hh ? c1 : c0;
+      de[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
+    }
+  }
+  // rgb head (nerf.py:144) accumulated from the softplus outputs while they are produced: 3 rows x this half's 64 K-slots
+  float c3[3] = {0.0f, 0.0f, 0.0f};
+  auto ssp_slice = [&](auto, auto, int t, int q, const f32x16& r) __attribute__((always_inline)) {
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = SN_NEWACT ? shifted_softplus_fast(r[4 * q + i]) : relu1(r[4 * q + i]);   // nerf.py:84 / :94
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_RGBW + c * 128 + h * 64 + 16 * t + 4 * q);
+      c3[c] = __builtin_fmaf(w[0], v[0], c3[c]);
+      c3[c] = __builtin_fmaf(w[1], v[1], c3[c]);
+      c3[c] = __builtin_fmaf(w[2], v[2], c3[c]);
+      c3[c] = __builtin_fmaf(w[3], v[3], c3[c]);
+    }
+    asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
+  };
+  SN_SLABG(72, 32, 4, 0, -1, de, copy_slice, 0, 8, 7);
+  SN_SLABG(73, 32, 4, 0, -1, de, ssp_slice, 0, 9, 0);
+  SN_SLABG(74, 32, 4, 0, -1, de, ssp_slice, 0, 9, 1);
+  SN_SLABG(75, 32, 4, 0, -1, de, ssp_slice, 0, 9, 2);
+  mfma32_result_fence(acc1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ssp_slice(SN_C(0), SN_C(9), 3, q, acc1);
+
+  // WidenedSigmoid (resp. Sigmoid; nerf.py:144) of the three cross-half sums
+  {
+    float o3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o3[c] = c3[c] + __shfl_xor(c3[c], 32, 64) + lds_aux[snl::AUX_HEADB + 1 + c];
+    if (valid && h == 0) {
+      float4 o;
+      o.x = rgb_activation(o3[0]);
+      o.y = rgb_activation(o3[1]);
+      o.z = rgb_activation(o3[2]);
+      o.w = sigma;                               // cat([rgb, sigma]) nerf.py:146
+      reinterpret_cast<float4*>(out)[p_raw] = o;
+    }
+  }
+  }  // persistent tile loop
+#undef SN_C
+#undef SN_SLABG
+#undef SN_LAYERG
+}
+
+}  // namespace snk
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int SN_LAUNCH_NAME(sn_mlp_forward_f32g)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                                                   int sigma_only, int input_mode, float* out, hipStream_t stream) {
+  using namespace snk;
+  if (n_points <= 0) return 0;
+  const long tiles = (n_points + 127) / 128;
+  const int n_cu = snh::cu_count();              // persistent: one workgroup per CU (408 registers per lane: one wave per SIMD)
+  dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
+  const size_t lds = F32G_LDS_BYTES;
+  const char* b = reinterpret_cast<const char*>(blob);
+#define SN_LAUNCH(SO, IM)                                                                              \
+  do {                                                                                                 \
+    auto kfn = mlp_fwd_f32g_kernel<SO, IM>;                                                            \
+    SN_ENSURE_DYN_LDS(kfn, lds);                                                                       \
+    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out);            \
+  } while (0)
+#ifdef SN_CLASSIC_HEADS                         // the sigma-only kernels never reach the heads: sn_api.hip routes them to the main pass
+  if (sigma_only) return -4;
+  if (input_mode == 0) SN_LAUNCH(false, 0); else SN_LAUNCH(false, 1);
+#else
+  if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0); else SN_LAUNCH(false, 0); }
+  else { if (sigma_only) SN_LAUNCH(true, 1); else SN_LAUNCH(false, 1); }
+#endif
+#undef SN_LAUNCH
+  return (int)hipGetLastError();
+}

@@ -30,6 +30,9 @@ constexpr int MLP_F32_LDS_BYTES_V2 = TAIL_LDS_BYTES + 3 * RING_SLOT_BYTES;   // 
 constexpr int XPOSE_PITCH = 36;                              // floats per point row (32 + 4: conflict-free b128 both ways)
 constexpr int XPOSE_WAVE_BYTES = 32 * XPOSE_PITCH * 4;       // 4608
 constexpr int XPOSE_LDS_BYTES = 4 * XPOSE_WAVE_BYTES;        // 18432
+// Inference: per-wave staging of the epilogue's LDS round trip (epi32_relu_lds): quad q of lane l at q * 1024 + l * 16
+constexpr int EPI_WAVE_BYTES = 4096;
+constexpr int EPI_LDS_BYTES = 4 * EPI_WAVE_BYTES;            // 16384
 
 template <int BYTES_PER_K, int SLOT_BYTES>
 struct RingT {
@@ -45,6 +48,7 @@ struct RingT {
   int pieces, piece;    // staging state of the slab being staged (pieces of 4096 B, the last one may be partial)
   int slab_bytes;
   const char* gp;       // per-lane global source of the next piece
+  const char* gps;      // wave-uniform global source of the next piece (piece_static_s)
   char* lp;             // wave-uniform LDS destination of the next piece
 
   SN_DEV char* slot(int k) const { return base + k * SLOT_BYTES; }
@@ -86,6 +90,20 @@ struct RingT {
   SN_DEV void piece_load() {
     asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(gp) : "memory");
     gp += 4096; lp += 4096;
+  }
+  // ... with the wave-uniform source in an SGPR pair and ONE constant per-lane VGPR offset (tid * 16): no VALU per piece.
+  // v_mfma_f32_32x32x2_f32 runs on the f32 VECTOR pipe: any VALU instruction between two of them costs 9.6 + 4 n cycles per gap
+  // (tools/ubench/f32_gap_cost.hip, profiles/r06_ubench_f32_gap_cost.txt: SALU, waits, LDS, global and LDS-DMA instructions cost
+  // nothing there), and the per-lane 64-bit `gp += 4096` of piece_static() is a v_lshl_add_u64 per piece -- 568 such gaps per point
+  // tile of the fp32 forward.  Used by slab_f32a (fp32 forward and backward chain).
+  SN_DEV void begin_static_s() {
+    gps = gnext;
+    lp = slot(stage_slot) + wbase;
+  }
+  SN_DEV void piece_static_s() {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %2"     /* SALU write of the address pair -> VMEM: 5 wait states (check_agpr.py rule 5) */
+                 :: "v"((unsigned)(tid * 16)), "s"((unsigned)(size_t)lp), "s"(gps) : "memory");
+    gps += 4096; lp += 4096;
   }
   SN_DEV void skip_static() { gp += 4096; lp += 4096; }      // a trailing partial piece this wave has no share of
   template <int NBYTES>
@@ -185,8 +203,10 @@ SN_DEV void slab_f32a(f32x16& acc, f32x16& accn, f32x4 (&af)[2], const char* lw,
     if (g == GB) {                               // sync point (one longer gap per slab)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      ring.begin_static();
+      ring.begin_static_s();
     }
+    if (g == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the LDS round trips of the epilogue slices (epi32_*_lds, groups 0..3)
+                                                                      // have landed in their AGPRs: consumers are >= 1 slab (or 22 groups) away
     if (g == 4) accn = load_bias(lds_bias, s_next, h);
     __builtin_amdgcn_sched_barrier(0);
     const f32x4 a_cur = af[g & 1];
@@ -218,7 +238,7 @@ SN_DEV void slab_f32a(f32x16& acc, f32x16& accn, f32x4 (&af)[2], const char* lw,
     __builtin_amdgcn_sched_barrier(0);
     if (g >= GB && g < GL) {                     // gap 2: weight DMA
 #pragma unroll
-      for (int i = 0; i < PPG; ++i) if ((g - GB) * PPG + i < NP) ring.piece_static();
+      for (int i = 0; i < PPG; ++i) if ((g - GB) * PPG + i < NP) ring.piece_static_s();
       __builtin_amdgcn_sched_barrier(0);
     }
     mma(2);
@@ -246,6 +266,24 @@ SN_DEV void epi32_copy(int reg, float x0, float x1, float x2, float x3) {       
   asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%5], %1\n\t"
                "v_accvgpr_write_b32 a[%6], %2\n\tv_accvgpr_write_b32 a[%7], %3"
                :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1), "n"(reg + 2), "n"(reg + 3));
+}
+
+// Epilogue blocks WITHOUT VALU work (round 6).  The f32-input MFMA shares its pipe with the VALU (above): the eight VALU of an
+// epi32_relu block cost 9.6 + 32 cycles of matrix time, four blocks per slab.  LDS instructions cost nothing between MFMAs, and on
+// gfx90a+ a DS load can target AGPRs directly: the four accumulator values go out with ONE ds_write_b128 into a wave-private staging
+// tile, ReLU is four ds_max_i32 against 0 on the written words (as signed integers every negative float -- and -0.0 -- is < 0, every
+// positive float is itself: max_i32(bits, 0) == bits of max(x, +0.0) for every non-NaN x; the LDS executes one wave's instructions
+// in order), and ONE ds_read_b128 puts the result into a[reg..reg+3].  `zero` = a VGPR holding 0.  The consumer waits with
+// s_waitcnt lgkmcnt(0) (slab_f32a, group 6).  addr = this lane's byte address of the staging quad; OFF = immediate offset.
+SN_DEV void epi32_relu_lds(int reg, unsigned addr, int off, f32x4 x, unsigned zero) {
+  asm volatile("ds_write_b128 %0, %1 offset:%3\n\t"
+               "ds_max_i32 %0, %2 offset:%3\n\tds_max_i32 %0, %2 offset:%4\n\tds_max_i32 %0, %2 offset:%5\n\tds_max_i32 %0, %2 offset:%6\n\t"
+               "ds_read_b128 a[%7:%8], %0 offset:%3"
+               :: "v"(addr), "v"(x), "v"(zero), "n"(off), "n"(off + 4), "n"(off + 8), "n"(off + 12), "n"(reg), "n"(reg + 3) : "memory");
+}
+SN_DEV void epi32_copy_lds(int reg, unsigned addr, int off, f32x4 x) {       // no activation; also: values already activated on the VALU
+  asm volatile("ds_write_b128 %0, %1 offset:%2\n\tds_read_b128 a[%3:%4], %0 offset:%2"
+               :: "v"(addr), "v"(x), "n"(off), "n"(reg), "n"(reg + 3) : "memory");
 }
 
 // ReLU as ONE v_max_f32 (fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max first: 2 VALU per value, and

@@ -149,3 +149,28 @@ def broadcast_parameters(modules, src=0):
                 dist.broadcast(t.data, src=src)
             if hasattr(m, "invalidate_packed"):          # written through .data: Parameter._version did not move
                 m.invalidate_packed()
+
+
+def all_reduce_mean_grads(params):
+    """Average the ``.grad`` of stock-PyTorch side modules over the ranks before their optimiser steps -- what DDP does for every
+    parameter of the LightningModule, the discriminator included (``train.py:51-52``, ``sinnerf.py:202-210``).  ONE flat all-reduce
+    of the coalesced gradients; a no-op at world size 1.  Parameters without a gradient contribute zeros (DDP's unused-parameter
+    behaviour) so that every rank reduces the same buffer."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for p, g in zip(params, grads):
+        n = g.numel()
+        if p.grad is None:
+            p.grad = flat[off:off + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n
+

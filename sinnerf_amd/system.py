@@ -21,7 +21,7 @@ from torch import nn
 
 from .nerf import Embedding, NeRF
 from .optim import FlatAdam
-from .parallel import broadcast_parameters
+from .parallel import all_reduce_mean_grads, broadcast_parameters
 from .losses import psnr, render_loss      # noqa: F401  (psnr re-exported: metrics.py:14-15)
 from .rendering import render_rays
 
@@ -118,7 +118,9 @@ class SinNeRFSystem(nn.Module):
         loss_real = torch.relu(torch.ones_like(pred_real) - pred_real).mean()
         loss_gen = torch.relu(torch.ones_like(pred_fake) + pred_fake).mean()
         loss_d = (loss_real + loss_gen) / 2
-        return {"loss": loss_d, "log": {"train/loss_d": loss_d.detach()}}
+        # sinnerf.py:499: the total the reference back-propagates in the optimizer_idx == 1 pass carries loss_d * dis_weight
+        # (Adam is almost, not exactly, scale-invariant -- eps, weight_decay coupling); the raw value goes to the log
+        return {"loss": loss_d * self.hparams.dis_weight, "log": {"train/loss_d": loss_d.detach()}}
 
     # ---- sinnerf.py:171-193 -------------------------------------------------------------------------------------
     def forward(self, rays):
@@ -280,6 +282,8 @@ class SinNeRFSystem(nn.Module):
         """Replicas start identical (what DDP's constructor does, train.py:51-52); returns the flat gradient buffer whose
         all-reduce is the step's one exchange."""
         broadcast_parameters(self.models)
+        if self.D is not None:                   # the reference wraps the WHOLE LightningModule in DDP (train.py:51-52): D starts identical too
+            broadcast_parameters([self.D])
         self._ensure_flat_optimizer()            # (an existing FlatAdam already saw the broadcast: its flat buffer IS p.data)
         if self._flat is None:
             raise RuntimeError("setup_distributed: parameters are on the host; move the module to a ROCm device first")
@@ -339,6 +343,7 @@ class SinNeRFSystem(nn.Module):
         self.opt_d.zero_grad(set_to_none=True)
         out_d = self.discriminator_step(batch)
         out_d["loss"].backward()
+        all_reduce_mean_grads(d_params)          # DDP averages D's gradients like every other parameter's (no-op at world size 1)
         self.opt_d.step()
         return out_g, out_d
 

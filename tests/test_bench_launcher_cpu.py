@@ -99,3 +99,24 @@ def test_a_rank_failing_in_setup_makes_every_rank_skip_the_record():
     assert by[0]["got"].startswith("skipped: setup failed on another rank")
     assert by[1]["got"].startswith("skipped: MemoryError")
     assert all(r["next"] == 42 and r["sum"] == 2.0 for r in recs)
+
+
+def test_no_roofline_fraction_can_exceed_one():
+    """the bf16x3 training records printed frac 1.9 (algorithmic FLOPs against the fp32 MFMA peak while the kernels run three
+    bf16 MFMAs per product).  They are priced on the pipe they use now, and compact_line refuses any `frac*` above 1."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    f = B.mfma_frac_fields("bf16x3", 308.9)                     # the round-5 step: 308.9 TF algorithmic
+    assert abs(f["frac_of_mfma_peak"] - 3 * 308.9 / 2500.0) < 1e-12 and f["frac_of_mfma_peak"] < 1
+    assert f["algorithmic_tflops"] == 308.9 and abs(f["x_fp32_mfma_peak"] - 308.9 / 157.3) < 1e-12
+    assert B.mfma_frac_fields("fp32", 130.0)["frac_of_mfma_peak"] == 130.0 / 157.3
+    res = {"metric": "m", "value": 1.0, "roofline": {"frac": 0.9}, "records": {"x": {"roofline": {"frac": 1.96}}}}
+    assert B.fracs_above_one(res) == [("/records/x/roofline/frac", 1.96)]
+    try:
+        B.compact_line(res)
+    except AssertionError:
+        pass
+    else:
+        raise AssertionError("compact_line accepted a fraction above 1")

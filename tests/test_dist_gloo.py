@@ -104,3 +104,59 @@ def test_system_surface_shapes():
     assert "nerf_coarse.xyz_encoding_1.0.weight" in sd and "nerf_fine.rgb.0.bias" in sd      # PL checkpoint key names
     with pytest.raises(RuntimeError):
         s(torch.zeros(4, 8))                                 # CPU tensors: no fallback
+
+
+def _worker_side_module(rank, world, port, q):
+    """the discriminator side of the multi-rank step: D replicas start identical and their gradients are averaged
+    before opt_d.step(), as DDP does for the whole LightningModule of the reference (train.py:51-52, sinnerf.py:202-210)"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sinnerf_amd.parallel import all_reduce_mean_grads
+        torch.manual_seed(50 + rank)                         # replicas start different
+        D = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 1, 3))
+        D[1].running_mean.add_(rank + 1.0)                   # ... buffers too
+        broadcast_parameters([D])
+        w0 = torch.cat([t.detach().reshape(-1) for t in list(D.parameters()) + list(D.buffers())]).double()
+        opt = torch.optim.Adam(D.parameters(), lr=1e-2)
+        x = torch.randn(2, 3, 9, 9, generator=torch.Generator().manual_seed(9 + rank))      # every rank its own patches
+        D[2].bias.requires_grad_(False)                      # a frozen parameter is skipped, not crashed on
+        D(x).mean().backward()
+        local = torch.cat([p.grad.reshape(-1) for p in D.parameters() if p.requires_grad]).double().clone()
+        all_reduce_mean_grads(list(D.parameters()))
+        red = torch.cat([p.grad.reshape(-1) for p in D.parameters() if p.requires_grad]).double().clone()
+        opt.step()
+        w1 = torch.cat([p.detach().reshape(-1) for p in D.parameters()]).double()
+        q.put((rank, w0.numpy(), local.numpy(), red.numpy(), w1.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_discriminator_replicas_stay_identical_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_side_module, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1])              # parameters AND buffers broadcast
+    assert not np.allclose(res[0][2], res[1][2])             # the local gradients differ (different patches) ...
+    mean = (res[0][2] + res[1][2]) / 2
+    for r in res:
+        assert np.allclose(r[3], mean, rtol=0, atol=1e-7)    # ... every rank steps with their mean
+    assert np.array_equal(res[0][4], res[1][4])              # the replicas are still identical after the Adam step
+
+
+def test_system_broadcasts_an_attached_discriminator_and_scales_its_loss():
+    """single process: setup_distributed() covers self.D, discriminator_step returns loss_d * dis_weight (sinnerf.py:499)"""
+    import inspect
+    from sinnerf_amd import system
+    src = inspect.getsource(system.SinNeRFSystem.setup_distributed)
+    assert "broadcast_parameters([self.D])" in src
+    src = inspect.getsource(system.SinNeRFSystem.train_step_adversarial)
+    assert src.index("all_reduce_mean_grads(d_params)") < src.index("self.opt_d.step()")
+    assert "loss_d * self.hparams.dis_weight" in inspect.getsource(system.SinNeRFSystem.discriminator_step)

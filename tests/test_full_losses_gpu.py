@@ -175,7 +175,10 @@ def test_both_optimizer_passes_of_the_patch_step():
     np.random.seed(9); torch.manual_seed(9)
     pr, pf_ = Dc(batch["real_patch"]), Dc(fake)
     want = (torch.relu(1 - pr).mean() + torch.relu(1 + pf_).mean()) / 2
-    assert abs(out_d["loss"].item() - want.item()) <= 1e-4 * max(1.0, abs(want.item())), (out_d["loss"].item(), want.item())
+    # (the returned 'loss' is what the reference back-propagates in this pass, loss_d * dis_weight -- sinnerf.py:499; the log holds loss_d)
+    got_d = out_d["log"]["train/loss_d"].item()
+    assert abs(got_d - want.item()) <= 1e-4 * max(1.0, abs(want.item())), (got_d, want.item())
+    assert abs(out_d["loss"].item() - sysm.hparams.dis_weight * want.item()) <= 1e-4 * sysm.hparams.dis_weight * max(1.0, abs(want.item()))
     # ... and the driver runs both passes: D moves in pass 1 only, the NeRFs receive nothing from it
     w1 = [p.detach().clone() for p in sysm.nerf_fine.parameters()]
     out_g, out_d2 = sysm.train_step_adversarial(batch)

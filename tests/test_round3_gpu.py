@@ -224,6 +224,10 @@ def test_bench_self_launch_two_gloo_ranks_one_gpu():
     assert c5["n_ranks"] == 2 and c5["value"] > 0 and c5["gathered_rows_on_rank0"] == 2 * c5["rays_per_rank"] == 240 * 240
     assert c4["n_ranks"] == 2 and c4["all_reduce_backend"] == "gloo" and c4["all_reduce_us"] > 0 and c4["ms_per_step"] > 0
     assert full["records"]["train_cfg4_dp"]["replicas_identical_after"] >= 3
+    # ... and the STRONG-scaling form of the headline workload (round 6): ONE frame of the headline shape partitioned over the ranks
+    hs = rec["records"]["headline_frame_sharded"]
+    assert hs["scaling"] == "strong" and hs["n_ranks"] == 2 and hs["gathered_rows_on_rank0"] == 2 * hs["rays_per_rank"] == 120 * 120
+    assert hs["value"] > 0 and hs["dtype"] == "fp32"
 
 
 def _train_forward(model, rays_t, z_t, flag):

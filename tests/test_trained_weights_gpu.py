@@ -83,7 +83,7 @@ def test_render_trained_weights_bf16_psnr_bar(name):
 def test_render_gradients_on_trained_weights(name):
     """autograd gradients of the reference on the trained student (perturb=1, noise_std=1, the recorded draws injected): the all-fp32 HIP
     path at the bars test_render_rays_gradients_golden uses; bf16x3 at the bars of test_bf16x3_render_gradients_golden (ReLU kinks);
-    bf16 norm-wise (3e-2 on the large tensors, cosine >= 0.999) against the same golden gradients."""
+    bf16 against the oracle's bf16-emulated backward (3e-2 norm-wise, cosine >= 0.9995) and, loosely, the fp32 gradients (cosine >= 0.99)."""
     import sinnerf_amd
     from tests.test_grads_gpu import model_grads
     z, meta, rng, coef = load_grad_case(name)
@@ -113,10 +113,27 @@ def test_render_gradients_on_trained_weights(name):
     assert w["sampled_coarse"] <= 1e-4 and w["norm_coarse"] <= 1e-4 and w["sampled_fine"] <= 5e-3 and w["norm_fine"] <= 5e-3, w
     w = worst["bf16x3"]
     assert max(w["sampled_coarse"], w["sampled_fine"]) <= 1e-2 and max(w["norm_coarse"], w["norm_fine"]) <= 2e-3, w
-    # bf16: whole tensors against the all-fp32 HIP path, norm-wise + direction (sampled entries are too few for a 1e-2-class arithmetic)
-    for g16, g32 in zip(got["bf16"], got["fp32"]):
-        big = [k for k, v in g32.items() if v.ndim == 2 and v.size >= 128 * 256]
+    # bf16: against the oracle's backward with the SAME operand roundings (forward under bf16_operands(), backward with
+    # operand_round=bf16_round) at the bars tests/test_round3_gpu.py holds the init-weight llff patch to (3e-2 norm-wise, cosine 0.9995
+    # on the large tensors), and loosely against the all-fp32 gradients (cosine >= 0.99: mixed precision is validated at convergence
+    # length, tests/test_convergence_gpu.py -- one 96-ray batch differs by 5-10 % norm-wise in the first trunk layers, measured)
+    models = O.model_params(meta)
+    up = {k: v.astype(np.float64) for k, v in coef.items()}
+    with O.bf16_operands():
+        ref16 = O.render_rays_backward(models, rays, up, meta["N_samples"], False, meta["perturb"], meta["noise_std"], meta["N_importance"],
+                                       bool(meta["white_back"]), rng, operand_round=O.bf16_round)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    cos = lambda a, b: float((a * b).sum() / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+    worst16, worst_cos32 = 0.0, 1.0
+    for g16, r16, g32 in zip(got["bf16"], ref16, got["fp32"]):
+        big = [k for k, v in r16.items() if np.asarray(v).size >= 256]
         for k in big:
-            d = np.linalg.norm(g16[k] - g32[k]) / max(np.linalg.norm(g32[k]), 1e-30)
-            c = float((g16[k] * g32[k]).sum() / max(np.linalg.norm(g16[k]) * np.linalg.norm(g32[k]), 1e-30))
-            assert d <= 3e-2 and c >= 0.999, (k, d, c)
+            d, c = rel(g16[k], np.asarray(r16[k], np.float64)), cos(g16[k], np.asarray(r16[k], np.float64))
+            worst16 = max(worst16, d)
+            assert d <= 3e-2 and c >= 0.9995, (k, d, c)
+            c32 = cos(g16[k], g32[k])
+            worst_cos32 = min(worst_cos32, c32)
+            assert c32 >= 0.99, (k, c32)
+    print(name, "bf16 vs bf16-emulated oracle: worst norm-wise %.2e; worst cosine vs the all-fp32 HIP gradients %.5f" % (worst16, worst_cos32))
+    record(f"{name}:bf16:vs_emulated_oracle_norm", worst16)
+    record(f"{name}:bf16:worst_cosine_vs_fp32", worst_cos32)
