@@ -364,15 +364,59 @@ def setup_agreed(setup, dev, world):
     return obj
 
 
+class VitStandIn(torch.nn.Module):
+    """Bench-side stand-in for the DINO ViT-S/16 of models/extractor.py:20-24 (`torch.hub.load('facebookresearch/dino:main', 'dino_vits16')`:
+    weights from the network, not runnable offline): the SAME architecture from stock torch.nn -- 16x16 patch embedding, cls token, 197
+    learned positions, 12 pre-norm blocks of width 384 / 6 heads / MLP ratio 4, GELU -- with RANDOM weights.  It exists
+    to put the ViT term's cost (two 224x224 forwards + their backward into the side render per step, sinnerf.py:332-339) into the config-3
+    record; its values mean nothing.  `feature(x)` = VitExtractor.get_feature_from_input(x)[-1][0, 0, :] after SinNeRF.get_vit_feature's
+    resize + ImageNet normalisation (sinnerf.py:162-169): the cls token of the LAST BLOCK's output.  Never imported by sinnerf_amd/."""
+
+    class Block(torch.nn.Module):
+        def __init__(self, dim=384, heads=6):
+            super().__init__()
+            self.norm1, self.norm2 = torch.nn.LayerNorm(dim, eps=1e-6), torch.nn.LayerNorm(dim, eps=1e-6)
+            self.qkv, self.proj = torch.nn.Linear(dim, 3 * dim), torch.nn.Linear(dim, dim)
+            self.fc1, self.fc2 = torch.nn.Linear(dim, 4 * dim), torch.nn.Linear(4 * dim, dim)
+            self.heads = heads
+
+        def forward(self, x):
+            B, N, C = x.shape
+            q, k, v = self.qkv(self.norm1(x)).reshape(B, N, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+            a = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+            x = x + self.proj(a.transpose(1, 2).reshape(B, N, C))
+            return x + self.fc2(torch.nn.functional.gelu(self.fc1(self.norm2(x))))
+
+    def __init__(self, dim=384, depth=12, heads=6):
+        super().__init__()
+        self.patch_embed = torch.nn.Conv2d(3, dim, 16, 16)
+        self.cls_token = torch.nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = torch.nn.Parameter(torch.randn(1, 197, dim) * 0.02)
+        self.blocks = torch.nn.ModuleList([VitStandIn.Block(dim, heads) for _ in range(depth)])
+        for p in self.parameters():
+            p.requires_grad_(False)                              # the reference never optimises the extractor
+
+    def feature(self, x):
+        mean = torch.tensor([0.485, 0.456, 0.406], device=x.device).reshape(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=x.device).reshape(1, 3, 1, 1)
+        x = (torch.nn.functional.interpolate(x, size=(224, 224)) - mean) / std
+        t = self.patch_embed(x).flatten(2).transpose(1, 2)
+        t = torch.cat([self.cls_token.expand(t.shape[0], -1, -1), t], 1) + self.pos_embed
+        for b in self.blocks:
+            t = b(t)
+        return t[0, 0, :]
+
+
 def train_cfg3_full_record(O, dev, dtype="bf16", steps=8, warmup=3):
     """BASELINE configs[2] AS NAMED -- "llff/room 504x378 patch 63x84 sW/sH=4 full SinNeRF losses, bf16" -- on what is runnable offline:
-    the llff four-render step with the ADVERSARIAL term through the reference's UNMODIFIED models/discriminator.py (staged into
+    the llff four-render step with the DINO-ViT term of sinnerf.py:332-339 through a stand-in of the same architecture with random weights
+    (VitStandIn above, vit_weight 10 = README "Step 1") AND the ADVERSARIAL term through the reference's UNMODIFIED models/discriminator.py (staged into
     oracle/_ref by build(); sinnerf.py:143-145 with --patch_size unset as in the README's LLFF commands, hinge loss, dis_weight 0.01 =
     README "Step 2") and BOTH optimiser passes per batch (pytorch-lightning 0.10 calls training_step once per optimiser, sinnerf.py:271):
     pass 0 = four renders with gradients + -mean(D(side patch)) + flat all-reduce + Adam; pass 1 = one no-grad side render, hinge D loss,
-    D backward, opt_d.  The discriminator stays on stock PyTorch-ROCm (north_star); the DINO-ViT term (sinnerf.py:332-339) needs weights
-    from the network and is not runnable offline.  Reports the whole step and the share of it spent on the HIP path (the same step with
-    the MSE stand-in for the side loss + the no-grad side render, both timed here)."""
+    D backward, opt_d.  Discriminator and ViT stay on stock PyTorch-ROCm (north_star).  Reports the whole step with both terms, the step
+    with the discriminator only (round 5's record), and the share spent on the HIP path (the same step with the MSE stand-in for the side
+    loss + the no-grad side render, both timed here)."""
     from oracle import stage_ref
     from sinnerf_amd.system import SinNeRFSystem
     if not stage_ref.discriminator_available():
@@ -409,8 +453,25 @@ def train_cfg3_full_record(O, dev, dtype="bf16", steps=8, warmup=3):
         return float(np.median(ts)), out
     np.random.seed(0)
     full = make(True)
+    t_dis, (out_g, out_d) = timed(lambda: full.train_step_adversarial(batch), max(steps, 12), max(warmup, 6))
+    assert torch.isfinite(out_g["loss"]).item() and torch.isfinite(out_d["loss"]).item()
+    # ... plus the ViT term: loss_vit = mse(f(side rgb_coarse), ref_) + mse(f(side rgb_fine), ref_) (sinnerf.py:332-339), ref_ = f(real patch)
+    torch.manual_seed(11)
+    vit = VitStandIn().to(dev).eval()
+    vit_weight = 10.0
+    with torch.no_grad():
+        ref_ = vit.feature(batch["real_patch"])
+    adv = full._generator_adv_loss
+
+    def side_with_vit(results_side, b):
+        patch = lambda k: results_side[k].reshape(1, psx, psy, 3).permute(0, 3, 1, 2)
+        mse = torch.nn.functional.mse_loss
+        l_vit = mse(vit.feature(patch("rgb_coarse")), ref_) + mse(vit.feature(patch("rgb_fine")), ref_)
+        return adv(results_side, b) + vit_weight * l_vit
+    full.side_loss = side_with_vit
     t_full, (out_g, out_d) = timed(lambda: full.train_step_adversarial(batch), max(steps, 12), max(warmup, 6))
     assert torch.isfinite(out_g["loss"]).item() and torch.isfinite(out_d["loss"]).item()
+    vit_params = sum(p.numel() for p in vit.parameters())
     side = batch["rays_side"].reshape(-1, 8)
 
     def side_render():
@@ -421,13 +482,17 @@ def train_cfg3_full_record(O, dev, dtype="bf16", steps=8, warmup=3):
     t_plain, _ = timed(lambda: plain.train_step(batch), steps, warmup)
     d_params = sum(p.numel() for p in full.D.parameters())
     pts = n_rays * 192
-    return {"workload": what + " + hinge GAN through the reference Discriminator (imsize=-1: %d parameters, logits (1,1,12,18)), both optimiser passes" % d_params,
+    return {"workload": what + " + 10 x ViT-S/16 feature loss (stand-in: DINO's architecture, random weights, %d parameters) + hinge GAN through the "
+                               "reference Discriminator (imsize=-1: %d parameters, logits (1,1,12,18)), both optimiser passes" % (vit_params, d_params),
             "dtype": dtype, "rays_per_step": n_rays, "ms_per_step": t_full * 1e3, "train_rays_per_s": n_rays / t_full,
+            "ms_per_step_discriminator_only": t_dis * 1e3,
             "hip_path_ms": (t_plain + t_side) * 1e3, "hip_path_share": (t_plain + t_side) / t_full,
             "generator_pass_standin_ms": t_plain * 1e3, "side_render_nograd_ms": t_side * 1e3,
-            "discriminator_and_glue_ms": (t_full - t_plain - t_side) * 1e3,
-            "losses": "pass 0: MSE(rays) + MSE(full patch) + SL1 depth(rays, proj) + 0.01 x hinge G loss; pass 1: hinge D loss on real patch / detached side render",
-            "vit": "not runnable offline (DINO weights)", "loss_g": float(out_g["loss"].detach()), "loss_d": float(out_d["loss"].detach()),
+            "vit_ms": (t_full - t_dis) * 1e3, "discriminator_and_glue_ms": (t_dis - t_plain - t_side) * 1e3,
+            "losses": "pass 0: MSE(rays) + MSE(full patch) + SL1 depth(rays, proj) + 10 x [mse(vit(side coarse), ref) + mse(vit(side fine), ref)] "
+                      "+ 0.01 x hinge G loss; pass 1: hinge D loss on real patch / detached side render",
+            "vit": "stand-in: ViT-S/16 of DINO's shape from stock torch.nn, random weights (the trained extractor needs the network)",
+            "loss_g": float(out_g["loss"].detach()), "loss_d": float(out_d["loss"].detach()),
             "roofline": train_hbm_roofline(t_plain * 1e3, pts) if dtype == "bf16" else None}
 
 

@@ -281,6 +281,14 @@ SN_DEV void epi32_relu_lds(int reg, unsigned addr, int off, f32x4 x, unsigned ze
                "ds_read_b128 a[%7:%8], %0 offset:%3"
                :: "v"(addr), "v"(x), "v"(zero), "n"(off), "n"(off + 4), "n"(off + 8), "n"(off + 12), "n"(reg), "n"(reg + 3) : "memory");
 }
+// ... the same round trip as SINGLE instructions, for kernels that deal them one per MFMA gap (sn_mlp_fwd_f32g.hip: issued as one
+// burst per slice, the six LDS instructions of four lock-stepped waves fill the LDS data FIFO and the wave's next MFMA waits for the
+// last of them to ISSUE -- 2 % of the fine pass; one LDS instruction per gap costs nothing, tools/ubench/f32_gap_cost.hip)
+SN_DEV void lds_put_quad(unsigned addr, int off, f32x4 x) { asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(x), "n"(off) : "memory"); }
+SN_DEV void lds_relu_word(unsigned addr, int off, unsigned zero) { asm volatile("ds_max_i32 %0, %1 offset:%2" :: "v"(addr), "v"(zero), "n"(off) : "memory"); }
+SN_DEV void lds_get_quad_agpr(int reg, unsigned addr, int off) {
+  asm volatile("ds_read_b128 a[%1:%2], %0 offset:%3" :: "v"(addr), "n"(reg), "n"(reg + 3), "n"(off) : "memory");
+}
 SN_DEV void epi32_copy_lds(int reg, unsigned addr, int off, f32x4 x) {       // no activation; also: values already activated on the VALU
   asm volatile("ds_write_b128 %0, %1 offset:%2\n\tds_read_b128 a[%3:%4], %0 offset:%2"
                :: "v"(addr), "v"(x), "n"(off), "n"(reg), "n"(reg + 3) : "memory");
@@ -295,15 +303,18 @@ SN_DEV float relu1(float x) {
 }
 
 // ShiftedSoftplus (models/activations.py:33-35) on hardware exp2/log2:  max(x-1,0) + log1p(exp(-|x-1|)).
-// log1p(e) for e in (0,1]: u = 1+e; log(u) * e/(u-1) restores the bits lost in 1+e (u-1 is exact); e < 2^-24 -> e.
+// log1p(e) for e in (0,1]: u = fl(1+e), d = u-1 (exact).  log(u) has lost the bits 1+e rounded away; they come back as the first-order
+// term (e - d)/u ~ e - d: |e - d| <= 2^-24, so replacing the factor 1/u in [1/2, 1] by 1 is an absolute error <= 3e-8 on a result >= e/2
+// -- and it is exactly right where it matters (e << 1: u -> 1; e < 2^-24: d = 0, log(u) = 0, result = e).  Round 6: this form has no
+// division, compare or select -- beside the f32-input MFMA every VALU instruction is matrix time (a reciprocal: 16 cycles) -- and the same
+// accuracy as the `log(u) * e/d` form of rounds 1-5 (max rel. error 1.8e-6 over [-30, 30], the exp2 argument's rounding; numpy emulation).
 SN_DEV float shifted_softplus_fast(float x) {
   const float sx = x - 1.0f;
   const float e = __builtin_amdgcn_exp2f(-fabsf(sx) * 1.44269504088896340736f);
   const float u = 1.0f + e;
   const float d = u - 1.0f;
   const float l = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
-  const float lp = (d == 0.0f) ? e : l * (e / d);
-  return fmaxf(sx, 0.0f) + lp;
+  return fmaxf(sx, 0.0f) + (l + (e - d));
 }
 
 }  // namespace snk

@@ -15,6 +15,7 @@ from sinnerf_amd import rendering, _lib                # noqa: E402
 
 RING = 4                                               # SN_FLAG_F32_LDS_RING
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+FULL_ONLY = bool(os.environ.get("F32_AB_FULL_ONLY"))     # timing variants (tools/build_variant_f32g.sh) only carry the frame render's kernel
 dev = torch.device("cuda:0")
 rays = torch.from_numpy(O.lego_rays(400, 400, 0)).to(dev)
 torch.manual_seed(0)
@@ -26,7 +27,7 @@ pts = rays.shape[0] * 128
 outs = {}
 with torch.no_grad():
     for name, flags in (("f32g (round 6)", 0), ("LDS ring (rounds 1-5)", RING), ("f32g (round 6) again", 0)):
-        for sigma_only in (False, True):
+        for sigma_only in ((False,) if FULL_ONLY else (False, True)):
             for _ in range(1):
                 o = rendering._mlp(m, rays, z, sigma_only, flags)
             torch.cuda.synchronize()
@@ -41,10 +42,12 @@ with torch.no_grad():
             outs[(flags, sigma_only)] = o
             print("%-24s %-10s %8.3f ms  %6.1f TFLOP/s  %.4f of 157.3 TF" % (name, "sigma-only" if sigma_only else "full", ms, flop / ms / 1e9,
                                                                          flop / ms / 1e9 / 157.3))
-    for so in (False, True):
+    for so in ((False,) if FULL_ONLY else (False, True)):
         same = torch.equal(outs[(0, so)], outs[(RING, so)])
         print("bit-identical outputs (%s): %s" % ("sigma-only" if so else "full", same))
         assert same
+    if FULL_ONLY:
+        sys.exit(0)
     # pre-embedded rows through NeRF.forward's entry (sn_mlp_forward_embedded)
     x = torch.randn(5000, 90, device=dev)
     a = torch.empty(5000, 4, device=dev); b = torch.empty(5000, 4, device=dev)

@@ -41,6 +41,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define F_SALU4 "s_add_u32 %8, %8, 1\n\ts_add_u32 %8, %8, 3\n\ts_add_u32 %8, %8, 5\n\ts_add_u32 %8, %8, 7\n\t"
 #define F_WAIT1 "s_waitcnt lgkmcnt(15)\n\t"
 #define F_WAITV "s_waitcnt vmcnt(63)\n\t"
+// LDS atomics (the ReLU-by-integer-max of the first round-6 epilogue) and LDS stores
+#define F_DSMAX16 "ds_max_i32 %9, %4\n\t"                 /* lane stride 16 B: 4-way bank conflict */
+#define F_DSMAX4 "ds_max_i32 %17, %4\n\t"                 /* lane stride 4 B: conflict-free */
+#define F_DSW128 "ds_write_b128 %9, %10\n\t"
+#define G_VMAX16 "v_max_f32 %4, 0, %2\n\tv_max_f32 %5, 0, %3\n\tv_max_f32 %6, 0, %2\n\tv_max_f32 %7, 0, %3\n\t" \
+                 "v_max_f32 %4, 0, %2\n\tv_max_f32 %5, 0, %3\n\tv_max_f32 %6, 0, %2\n\tv_max_f32 %7, 0, %3\n\t" \
+                 "v_max_f32 %4, 0, %2\n\tv_max_f32 %5, 0, %3\n\tv_max_f32 %6, 0, %2\n\tv_max_f32 %7, 0, %3\n\t" \
+                 "v_max_f32 %4, 0, %2\n\tv_max_f32 %5, 0, %3\n\tv_max_f32 %6, 0, %2\n\tv_max_f32 %7, 0, %3\n\t"
 // per-group fillers (k = group 0..3)
 #define G_NONE ""
 #define G_DS0 "ds_read_b128 %10, %9\n\t"
@@ -96,6 +104,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + 32768 + wave * 4096);                               \
     f32x4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;                                                                              \
     const unsigned goff = lane * 16;                                                                                                 \
+    const unsigned la4 = (unsigned)(size_t)smem + 16384 + wave * 4096 + lane * 4;                                                    \
     asm volatile("v_accvgpr_write_b32 a8, %0\n\tv_accvgpr_write_b32 a9, %1" ::"v"(b), "v"(a) : "a0", "a1", "a8", "a9");             \
     long long t_begin = 0, t_end = 0, r_begin = 0, r_end = 0;                                                                        \
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin), "=s"(r_begin));                         \
@@ -104,7 +113,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
       asm volatile(BODYSTR                                                                                                           \
                    : "+v"(c0), "+v"(c1), "+v"(a), "+v"(b), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+s"(s0), "+v"(la), "+v"(q0),     \
                      "+v"(q1), "+v"(q2), "+v"(q3)                                                                                    \
-                   : "v"(goff), "s"(gb), "s"(m0v)                                                                                    \
+                   : "v"(goff), "s"(gb), "s"(m0v), "v"(la4)                                                                          \
                    : "memory", "a0", "a1");                                                                                          \
     }                                                                                                                                \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(r_end)); \
@@ -148,13 +157,31 @@ KERNEL(k_mix_gen_global_2chains, BODY2(F_NONE, G_GEN0, G_GEN1, G_GEN2, G_GEN3))
 KERNEL(k_mix_gen_lds, BODY1(F_NONE, G_GENL0, G_GENL1, G_GENL2, G_GENL3))
 KERNEL(k_mix_gen_lds_2chains, BODY2(F_NONE, G_GENL0, G_GENL1, G_GENL2, G_GENL3))
 
+// ---- instruction FETCH: the same bodies, but 64 / 256 / 512 copies of them in straight-line code (22 / 90 / 180 KB: the fused MLP kernel
+// is ~195 KB of straight-line code per point tile; the instruction cache holds 64 KB per pair of CUs)
+#define REP4(X) X X X X
+#define REP16(X) REP4(REP4(X))
+#define REP64(X) REP4(REP16(X))
+#define REP256(X) REP4(REP64(X))
+#define REP512(X) REP256(X) REP256(X)
+KERNEL(k_gl_per4_code22k, REP64(BODY1(F_NONE, G_GL0, G_GL1, G_GL2, G_GL3)))
+KERNEL(k_gl_per4_code90k, REP256(BODY1(F_NONE, G_GL0, G_GL1, G_GL2, G_GL3)))
+KERNEL(k_gl_per4_code180k, REP512(BODY1(F_NONE, G_GL0, G_GL1, G_GL2, G_GL3)))
+KERNEL(k_bare_code130k, REP512(BODY1(F_NONE, G_NONE, G_NONE, G_NONE, G_NONE)))
+KERNEL(k_nop_gl_code250k, REP512(BODY1(F_NOP, G_GL0, G_GL1, G_GL2, G_GL3)))
+
+KERNEL(k_dsmax_stride16_per1, BODY1(F_DSMAX16, G_NONE, G_NONE, G_NONE, G_NONE))
+KERNEL(k_dsmax_stride4_per1, BODY1(F_DSMAX4, G_NONE, G_NONE, G_NONE, G_NONE))
+KERNEL(k_dswrite128_per1, BODY1(F_DSW128, G_NONE, G_NONE, G_NONE, G_NONE))
+KERNEL(k_vmax16_one_gap_per16, BODY1(F_NONE, G_VMAX16, G_NONE, G_NONE, G_NONE))
+
 typedef void (*kern_t)(const float*, const char*, float*, long long*, int);
 
-static void run(const char* name, kern_t kern, double n_other, const float* src, const char* wts, float* d, long long* clk, int n_cu) {
+static void run(const char* name, kern_t kern, double n_other, const float* src, const char* wts, float* d, long long* clk, int n_cu, int rep = 1) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  int iters = 2000;
+  int iters = 2000 / rep + 1;
   float ms = 0;
   for (int pass = 0; pass < 3; ++pass) {
     hipEventRecord(e0);
@@ -162,14 +189,14 @@ static void run(const char* name, kern_t kern, double n_other, const float* src,
     hipEventRecord(e1);
     if (hipEventSynchronize(e1) != hipSuccess) { printf("%-28s FAILED: %s\n", name, hipGetErrorString(hipGetLastError())); return; }
     hipEventElapsedTime(&ms, e0, e1);
-    if (pass == 0) iters = (int)(iters * 12.0 / ms);
+    if (pass == 0) iters = (int)(iters * 12.0 / ms) + 1;
   }
   std::vector<long long> h(n_cu * 8);
   hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
   double cyc = 0, rt = 0;
   for (int i = 0; i < n_cu * 4; ++i) { cyc += (double)h[2 * i]; rt += (double)h[2 * i + 1]; }
   cyc /= n_cu * 4; rt /= n_cu * 4;
-  const double n = (double)iters * 32;
+  const double n = (double)iters * 32 * rep;
   const double tf = (double)n_cu * 4 * n * 4096 / ms / 1e9;
   printf("%-28s other/MFMA %.2f  %7.3f ms  %6.1f TF  frac %.3f  cycles/MFMA %6.2f  (+%5.2f per other)  clock %.2f GHz\n", name, n_other, ms, tf,
          tf / 157.3, cyc / n, n_other > 0 ? (cyc / n - 64.0) / n_other : 0.0, cyc / (rt * 10.0) );
@@ -204,6 +231,12 @@ int main() {
     RUN(k_mix_shipped, 1.06); RUN(k_mix_shipped_2chains, 1.06);
     RUN(k_mix_gen_global, 0.75); RUN(k_mix_gen_global_2chains, 0.75);
     RUN(k_mix_gen_lds, 0.75); RUN(k_mix_gen_lds_2chains, 0.75);
+    RUN(k_dsmax_stride16_per1, 1); RUN(k_dsmax_stride4_per1, 1); RUN(k_dswrite128_per1, 1); RUN(k_vmax16_one_gap_per16, 1);
+    run("k_gl_per4_code22k", k_gl_per4_code22k, 0.5, src, wts, d, clk, n_cu, 64);
+    run("k_gl_per4_code90k", k_gl_per4_code90k, 0.5, src, wts, d, clk, n_cu, 256);
+    run("k_gl_per4_code180k", k_gl_per4_code180k, 0.5, src, wts, d, clk, n_cu, 512);
+    run("k_bare_code130k", k_bare_code130k, 0, src, wts, d, clk, n_cu, 512);
+    run("k_nop_gl_code250k", k_nop_gl_code250k, 1.5, src, wts, d, clk, n_cu, 512);
   }
   return 0;
 }
