@@ -104,7 +104,7 @@ def roofline_record(dtype, n_rays, NS, NI, ms_fine, ms_coarse, ms_step, traffic=
                 "mlp_share_of_step": (ms_fine + ms_coarse) / ms_step}
     peak = PEAK_TFLOPS[dtype]
     return {"bound": "mfma",
-            "kernel": "mlp_fwd_%s_kernel (fine pass, %d points/launch)" % ("f32" if dtype == "fp32" else "bf16", n_rays * (NS + NI)),
+            "kernel": "mlp_fwd_%s_kernel (fine pass, %d points/launch)" % ("f32g" if dtype == "fp32" else "bf16_v3", n_rays * (NS + NI)),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "traffic_note": traffic_note or "no PMC summary for this workload",
             "flop_per_launch": flop_fine, "avg_launch_ms": ms_fine, "coarse_launch_ms": ms_coarse,
@@ -148,7 +148,21 @@ def live_pmc_traffic(args, n_points, timeout=120):
             cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", cnt, "--pmc", cnt, "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-extra", "--no-cpu-baseline", "--no-pmc", "--dtype", args.dtype,
                    "--hw", str(args.hw[0]), str(args.hw[1]), "--n-importance", str(args.n_importance), "--full-json", os.path.join(tmp, "child.json")]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            # own session: on a timeout the whole group goes -- rocprofv3 AND the python child it started (killing only
+            # rocprofv3 can leave the grandchild rendering on the GPU under the records that follow)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                raise
+            if rc != 0:
+                raise subprocess.CalledProcessError(rc, cmd)
             best = (-1.0, None)
             for f in glob.glob(os.path.join(tmp, "**", cnt + "_counter_collection.csv"), recursive=True):
                 per = {}
@@ -327,7 +341,7 @@ def train_cfg_record(O, dev, dtype, cfg, steps=3, warmup=2):
     if dtype == "bf16":
         rec["roofline"] = train_hbm_roofline(step_s * 1e3, pts)
     else:
-        rec["roofline"] = {"bound": "mfma", "kernel": ("fp32 training step: mlp_fwd_f32_kernel<STORE> + mlp_bwd_chain_f32_kernel + dw_f32_asm_kernel + "
+        rec["roofline"] = {"bound": "mfma", "kernel": ("fp32 training step: mlp_fwd_f32g_kernel<STORE> + mlp_bwd_chain_f32_kernel + dw_f32_asm_kernel + "
                                                        "dw_narrow_f32_kernel" if dtype == "fp32" else
                                                        "bf16x3 training step: mlp_fwd_bf16x3_kernel<STORE> + mlp_bwd_chain_bf16x3_kernel + dw_kernel "
                                                        "(3-term split, (hi, lo) state)") + " (4 renders, coarse + fine)",

@@ -31,8 +31,17 @@ namespace snk {
 #ifndef SN_F32G_FD
 #define SN_F32G_FD 8
 #endif
-constexpr int FD = SN_F32G_FD;
-constexpr int EPI_STEPS = 24;                    // steps of an epilogue program: slice q = step / 6 (write, four ReLU words, AGPR load)
+constexpr int FD_INFER = SN_F32G_FD;
+// training forward: the activation stores share the vector-memory counter with the fragment loads and retire after them (HBM write
+// acknowledgements under 3 TB/s of stores: microseconds) -- a counted wait for a fragment also waits for every OLDER store, so the ring
+// reaches 16 groups = 4 096 cycles ahead there
+#ifndef SN_F32G_FD_STORE
+#define SN_F32G_FD_STORE 16
+#endif
+constexpr int FD_STORE = SN_F32G_FD_STORE;
+// steps of an epilogue program: slice q = step / 6 (write, four ReLU words, AGPR load) = 24; the training forward appends the row stores
+// of the staged 32-point x 32-feature tile: two row-group reads ahead of four (store, next read) steps
+constexpr int EPI_STEPS = 24, EPI_STEPS_STORE = 30;
 // timing-build knobs (tools/build_variant_f32g.sh; results are WRONG with any of them set): SN_F32G_NO_ATOMICS leaves the ReLU's LDS
 // integer max out, SN_F32G_NO_EPI the whole LDS round trip, SN_F32G_WAIT_G moves the epilogue's lgkmcnt wait, SN_F32G_NO_RAY_LOADS feeds
 // constants instead of (rays, z_vals)
@@ -40,6 +49,7 @@ constexpr int EPI_STEPS = 24;                    // steps of an epilogue program
 #define SN_F32G_WAIT_G 6
 #endif
 constexpr int F32G_LDS_BYTES = TAIL_LDS_BYTES + EPI_LDS_BYTES;   // bias / head table + the epilogue staging of four waves
+constexpr int F32G_LDS_BYTES_STORE = TAIL_LDS_BYTES + XPOSE_LDS_BYTES;   // ... training forward: the staging tiles of the activation stores
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -58,7 +68,7 @@ SN_DEV f32x4 load_frag(rsrc_t rs, unsigned voff, unsigned soff) {
 // from the third on (the previous slab's last MFMA has retired by then) -- in the trunk every step is one LDS instruction.
 // acc = this slab's accumulators (bias-initialised), accn = the previous slab's result until the steps have consumed it (the last
 // reader is step 18, behind MFMA 20), then the bias of slab s_next (requested in group 6).
-template <int NG0, int NG1, int SET0, int SET1, int G0, int TOT, class Pending>
+template <int NG0, int NG1, int SET0, int SET1, int G0, int TOT, int NSTEPS, int FD, class Pending>
 SN_DEV void slab_f32g(f32x16& acc, f32x16& accn, f32x4 (&fr)[FD], rsrc_t rs, unsigned voff,
                       const float* bv, const float* lds_bias, int s_next, int h, Pending&& pending) {
   constexpr int NG = NG0 + NG1;
@@ -83,7 +93,7 @@ SN_DEV void slab_f32g(f32x16& acc, f32x16& accn, f32x4 (&fr)[FD], rsrc_t rs, uns
     };
     auto step = [&](int kk) __attribute__((always_inline)) {
       const int st = 4 * g + kk - 2;
-      if (st >= 0 && st < EPI_STEPS) pending(st);
+      if (st >= 0 && st < NSTEPS) pending(st);
     };
     mma(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -108,10 +118,15 @@ SN_DEV void slab_f32g(f32x16& acc, f32x16& accn, f32x4 (&fr)[FD], rsrc_t rs, uns
 constexpr unsigned slab_byte_offset(int s) { return (unsigned)(snl::slab_elem_offset(s) * 4); }
 
 // INPUT_MODE 0: points from (rays, z_vals); 1: pre-embedded rows x[p, 0:63(+27)] with leading dimension ld (NeRF.forward path)
-template <bool SIGMA_ONLY, int INPUT_MODE>
+// STORE: training forward -- additionally writes every layer's activations (acts[10][slot_rows][256]: h1..h8, final, h2) and the embedded
+// inputs (emb[slot_rows][128]: xyz columns 0..62, dir columns 64..90, reference column order; pre-embedded rows: the caller builds emb)
+// for the backward pass, exactly as mlp_fwd_f32_kernel<.., STORE> did (sn_mlp_fwd.hip): same values, same layout.
+template <bool SIGMA_ONLY, int INPUT_MODE, bool STORE>
 __global__ void __launch_bounds__(256)
 mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0, const float* __restrict__ in1, long P, int S,
-                    float* __restrict__ out) {
+                    float* __restrict__ out, float* __restrict__ acts, float* __restrict__ emb, long slot_rows) {
+  constexpr int FD = STORE ? FD_STORE : FD_INFER;
+  constexpr int NSTEPS = STORE ? EPI_STEPS_STORE : EPI_STEPS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_bias = reinterpret_cast<float*>(smem);
   const float* lds_aux = lds_bias + snl::BIAS_FLOATS;
@@ -139,7 +154,17 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #pragma unroll
   for (int g = 0; g < FD - 1; ++g) fr[g] = load_frag(rs, voff, g * 1024);      // slab 0, groups 0 .. FD-2
   f32x16 acc0 = load_bias(lds_bias, 0, h), acc1;
-  unsigned epi_a = (unsigned)(size_t)(smem + TAIL_LDS_BYTES + wave * EPI_WAVE_BYTES) + lane * 16;
+  // epilogue staging: where this lane's accumulator quad q goes.  Inference: a tile of its own (quad q of lane l at 1024 q + 16 l).
+  // Training forward: the quad's place in the [point row][feature] staging tile of the activation stores (row j, floats 8 q + 4 h ..;
+  // 36-float pitch, sn_mlp_pipe.h XPOSE_*), which the row stores read afterwards.
+  char* const xp = smem + TAIL_LDS_BYTES + wave * XPOSE_WAVE_BYTES;
+  const unsigned xp_w = (unsigned)(j * XPOSE_PITCH + 4 * h) * 4u;
+  const unsigned xp_r = (unsigned)((lane >> 3) * XPOSE_PITCH + 4 * (lane & 7)) * 4u;    // row lane>>3, 16-byte chunk lane&7
+  unsigned g_off = (unsigned)((lane >> 3) * 256 + 4 * (lane & 7)) * 4u;
+  constexpr int EQ = STORE ? 32 : 1024;          // byte step between the quads of a lane
+  unsigned epi_a = STORE ? (unsigned)(size_t)xp + xp_w : (unsigned)(size_t)(smem + TAIL_LDS_BYTES + wave * EPI_WAVE_BYTES) + lane * 16;
+  asm volatile("" : "+v"(g_off));
+  f32x4 rowbuf[2];
   unsigned vzero;
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   asm volatile("" : "+v"(epi_a));
@@ -177,6 +202,12 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     }
   }
 
+  if (STORE && INPUT_MODE == 0) {                // rows are allocated for whole 128-point tiles: no predicate.  (Pre-embedded rows: the
+    int hh = h;                                  // caller builds emb itself, it is a column re-layout of x)
+    asm volatile("" : "+v"(hh));                 // the half-dependent offsets stay inside the tile loop
+    store_emb_xyz(emb + p_raw * 128, xe, hh);    // columns [0, 63); the pad columns 63, 91..127 are never read back
+  }
+
   float sg = 0.0f;                               // sigma head partial of this lane half (nerf.py:136), K-slot order
   float sv[16];                                  // layer 8: the activated values of a tile between the VALU step and their LDS writes
 
@@ -187,6 +218,32 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   };
   // epilogue PROGRAMS of output tile t of a layer (accumulator registers 4q..4q+3 -> K-slots 16t+4q.. of activation set W), one
   // instruction per step: slice q = st / 6 -- st % 6 == 0: ds_write_b128 of the quad, 1..4: ReLU of one word, 5: ds_read_b128 -> AGPRs
+  // training forward, steps 24..29: row group i (8 points x 128 B) of the staged tile -> acts[slot][point][32t..32t+31], non-temporal (5 GB
+  // of write-once data must not evict the L2-resident weights); every read two steps ahead of its store
+  const long p_wave_c = p_wave;
+  auto row_read = [&](int i) __attribute__((always_inline)) {         // (compiler-tracked LDS load: it places the lgkmcnt wait of the store)
+    return *reinterpret_cast<const f32x4*>(xp + xp_r + 8 * i * XPOSE_PITCH * 4);
+  };
+  auto row_store = [&](int slot, int t, int i, const f32x4& o) __attribute__((always_inline)) {
+    // wave-uniform 64-bit base (SALU) + one 32-bit per-lane offset, kept opaque: hipcc otherwise precomputes a 64-bit VGPR address per slot
+    const char* base = reinterpret_cast<const char*>(acts) + (((long)slot * slot_rows + p_wave_c + 8 * i) * 256 + 32 * t) * 4;
+    unsigned go = g_off;
+    asm volatile("" : "+v"(go));
+#ifdef SN_F32G_NO_ROW_STORES                     // timing build: the staging round trip without the global stores
+    asm volatile("" :: "v"(o), "s"(base), "v"(go));
+#else
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(const_cast<char*>(base) + go));
+#endif
+  };
+  auto row_step = [&](int slot, int t, int k) __attribute__((always_inline)) {
+    if (!STORE) return;
+    if (k == 0) rowbuf[0] = row_read(0);
+    else if (k == 1) rowbuf[1] = row_read(1);
+    else if (k == 2) { row_store(slot, t, 0, rowbuf[0]); rowbuf[0] = row_read(2); }
+    else if (k == 3) { row_store(slot, t, 1, rowbuf[1]); rowbuf[1] = row_read(3); }
+    else if (k == 4) row_store(slot, t, 2, rowbuf[0]);
+    else if (k == 5) row_store(slot, t, 3, rowbuf[1]);
+  };
   f32x4 sw[4];                                   // layer 8: the sigma head's weights of a tile (requested a step ahead of their use)
   auto relu_prog = [&](auto wset, auto slot_c, int t, int st, const f32x16& r) __attribute__((always_inline)) {
     constexpr int W = decltype(wset)::value;
@@ -205,23 +262,27 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       } else if (st >= 4 && st < 8) {
         f32x4 x;
         x[0] = sv[4 * (st - 4)]; x[1] = sv[4 * (st - 4) + 1]; x[2] = sv[4 * (st - 4) + 2]; x[3] = sv[4 * (st - 4) + 3];
-        lds_put_quad(epi_a, 1024 * (st - 4), x);
+        lds_put_quad(epi_a, EQ * (st - 4), x);
       } else if (st >= 8 && st < 12) {
-        lds_get_quad_agpr(W * 128 + 16 * t + 4 * (st - 8), epi_a, 1024 * (st - 8));
+        lds_get_quad_agpr(W * 128 + 16 * t + 4 * (st - 8), epi_a, EQ * (st - 8));
+      } else if (st >= 24) {
+        row_step(7, t, st - 24);
       }
       return;
     }
-    if (k == 0) lds_put_quad(epi_a, 1024 * q, quad(r, q));
+    if (st >= 24) { row_step(slot, t, st - 24); return; }
+    if (k == 0) lds_put_quad(epi_a, EQ * q, quad(r, q));
 #ifndef SN_F32G_NO_ATOMICS
-    else if (k < 5) lds_relu_word(epi_a, 1024 * q + 4 * (k - 1), vzero);
+    else if (k < 5) lds_relu_word(epi_a, EQ * q + 4 * (k - 1), vzero);
 #endif
-    else if (k == 5) lds_get_quad_agpr(W * 128 + 16 * t + 4 * q, epi_a, 1024 * q);
+    else if (k == 5) lds_get_quad_agpr(W * 128 + 16 * t + 4 * q, epi_a, EQ * q);
   };
   auto copy_prog = [&](auto wset, auto, int t, int st, const f32x16& r) __attribute__((always_inline)) {       // xyz_encoding_final
     constexpr int W = decltype(wset)::value;
     const int q = st / 6, k = st % 6;
-    if (k == 0) lds_put_quad(epi_a, 1024 * q, quad(r, q));
-    else if (k == 5) lds_get_quad_agpr(W * 128 + 16 * t + 4 * q, epi_a, 1024 * q);
+    if (st >= 24) { row_step(8, t, st - 24); return; }
+    if (k == 0) lds_put_quad(epi_a, EQ * q, quad(r, q));
+    else if (k == 5) lds_get_quad_agpr(W * 128 + 16 * t + 4 * q, epi_a, EQ * q);
   };
   auto no_prog = [&](auto, auto, int, int, const f32x16&) __attribute__((always_inline)) {};
 
@@ -233,10 +294,10 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     constexpr int s_nx = ((S_) + 1 == N_USED) ? 0 : (S_) + 1;                                                             \
     constexpr int g0 = (int)(slab_byte_offset(S_) / 1024), tot = (int)(slab_byte_offset(N_USED) / 1024);                  \
     if (((S_) & 1) == 0)                                                                                                  \
-      slab_f32g<NG0_, NG1_, S0_, S1_, g0, tot>(acc0, acc1, fr, rs, voff, BV_,                                             \
+      slab_f32g<NG0_, NG1_, S0_, S1_, g0, tot, NSTEPS, FD>(acc0, acc1, fr, rs, voff, BV_,                                             \
           lds_bias, s_nx, h, [&](int st) __attribute__((always_inline)) { PEPI_(SN_C(PW_), SN_C(PSLOT_), PT_, st, acc1); }); \
     else                                                                                                                  \
-      slab_f32g<NG0_, NG1_, S0_, S1_, g0, tot>(acc1, acc0, fr, rs, voff, BV_,                                             \
+      slab_f32g<NG0_, NG1_, S0_, S1_, g0, tot, NSTEPS, FD>(acc1, acc0, fr, rs, voff, BV_,                                             \
           lds_bias, s_nx, h, [&](int st) __attribute__((always_inline)) { PEPI_(SN_C(PW_), SN_C(PSLOT_), PT_, st, acc0); }); \
   } while (0)
   // the 8 output tiles of layer slot L_ (stream slabs 8 L_ ..): tile 0 finishes the PREVIOUS layer's tile 7 (PEPI_ / PW_ / PSLOT_)
@@ -292,9 +353,15 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       de[e] = (c >= 0) ? row[63 + (c < 0 ? 0 : c)] : 0.0f;
     }
   }
+  if (STORE && INPUT_MODE == 0) {
+    int hh = h;
+    asm volatile("" : "+v"(hh));
+    store_emb_dir(emb + p_raw * 128 + 64, de, hh);                 // columns [64, 91)
+  }
   // rgb head (nerf.py:144) accumulated from the softplus outputs while they are produced: 3 rows x this half's 64 K-slots
   float c3[3] = {0.0f, 0.0f, 0.0f};
   auto ssp_slice = [&](auto, auto, int t, int st, const f32x16& r) __attribute__((always_inline)) {
+    if (st >= 24) { row_step(9, t, st - 24); return; }
     if (st % 6 != 0) return;                     // VALU work (ShiftedSoftplus + the rgb head): slice q in ONE gap, six MFMAs apart
     const int q = st / 6;
     float v[4];
@@ -309,6 +376,11 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
       c3[c] = __builtin_fmaf(w[3], v[3], c3[c]);
     }
     asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
+    if (STORE) {                                 // slot 9 of the training state: the softplus outputs
+      f32x4 o;
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+      *reinterpret_cast<f32x4*>(xp + xp_w + 32 * q) = o;
+    }
   };
   SN_SLABG(72, 32, 4, 0, -1, de, copy_prog, 0, 8, 7);
   SN_SLABG(73, 32, 4, 0, -1, de, ssp_slice, 0, 9, 0);
@@ -317,6 +389,10 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   mfma32_result_fence(acc1);
 #pragma unroll
   for (int q = 0; q < 4; ++q) ssp_slice(SN_C(0), SN_C(9), 3, 6 * q, acc1);
+  if (STORE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_store(9, 3, i, row_read(i));
+  }
 
   // WidenedSigmoid (resp. Sigmoid; nerf.py:144) of the three cross-half sums
   {
@@ -342,29 +418,42 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 
 // ---------------------------------------------------------------------------------------------------
 extern "C" int SN_LAUNCH_NAME(sn_mlp_forward_f32g)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                                                   int sigma_only, int input_mode, float* out, hipStream_t stream) {
+                                                   int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
+                                                   hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
-  const int n_cu = snh::cu_count();              // persistent: one workgroup per CU (408 registers per lane: one wave per SIMD)
+  const bool store = acts != nullptr;
+  if (store && (sigma_only || emb == nullptr || slot_rows < tiles * 128)) return -1;
+  const int n_cu = snh::cu_count();              // persistent: one workgroup per CU (~400 registers per lane: one wave per SIMD)
   dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(256);
-  const size_t lds = F32G_LDS_BYTES;
+  const size_t lds = store ? F32G_LDS_BYTES_STORE : F32G_LDS_BYTES;
   const char* b = reinterpret_cast<const char*>(blob);
-#define SN_LAUNCH(SO, IM)                                                                              \
-  do {                                                                                                 \
-    auto kfn = mlp_fwd_f32g_kernel<SO, IM>;                                                            \
-    SN_ENSURE_DYN_LDS(kfn, lds);                                                                       \
-    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out);            \
+#define SN_LAUNCH(SO, IM, ST)                                                                                       \
+  do {                                                                                                              \
+    auto kfn = mlp_fwd_f32g_kernel<SO, IM, ST>;                                                                     \
+    SN_ENSURE_DYN_LDS(kfn, lds);                                                                                    \
+    hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows);   \
   } while (0)
-#if defined(SN_F32G_AB)                         // timing builds: the frame render's instantiation only (compile time)
-  if (sigma_only || input_mode != 0) return -4;
-  SN_LAUNCH(false, 0);
-#elif defined(SN_CLASSIC_HEADS)                 // the sigma-only kernels never reach the heads: sn_api.hip routes them to the main pass
-  if (sigma_only) return -4;
-  if (input_mode == 0) SN_LAUNCH(false, 0); else SN_LAUNCH(false, 1);
+#if defined(SN_F32G_AB)                         // timing builds: ONE instantiation (compile time): the frame render's, or the training
+#ifdef SN_F32G_AB_STORE                         // forward's with -DSN_F32G_AB_STORE
+  if (!store || input_mode != 0) return -4;
+  SN_LAUNCH(false, 0, true);
 #else
-  if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0); else SN_LAUNCH(false, 0); }
-  else { if (sigma_only) SN_LAUNCH(true, 1); else SN_LAUNCH(false, 1); }
+  if (store || sigma_only || input_mode != 0) return -4;
+  SN_LAUNCH(false, 0, false);
+#endif
+#else
+  if (store) {
+    if (input_mode == 0) SN_LAUNCH(false, 0, true); else SN_LAUNCH(false, 1, true);
+  }
+#ifdef SN_CLASSIC_HEADS                         // the sigma-only kernels never reach the heads: sn_api.hip routes them to the main pass
+  else if (sigma_only) return -4;
+  else if (input_mode == 0) SN_LAUNCH(false, 0, false); else SN_LAUNCH(false, 1, false);
+#else
+  else if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false); }
+  else { if (sigma_only) SN_LAUNCH(true, 1, false); else SN_LAUNCH(false, 1, false); }
+#endif
 #endif
 #undef SN_LAUNCH
   return (int)hipGetLastError();

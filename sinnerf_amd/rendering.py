@@ -34,7 +34,17 @@ def _is_pow2_bands(e, in_channels, n_freqs):
     is cached on the object, keyed on the band tensor's identity and version: a render call is launch-latency sensitive and must
     not convert 14 band values to Python floats every time (nor sync a device on them if the bands were moved there)."""
     fb = getattr(e, "freq_bands", None)
-    key = (id(fb), getattr(fb, "_version", None), in_channels, n_freqs)
+    if isinstance(fb, torch.Tensor):
+        # identity + version + storage: `fb.data = ...` / `set_()` change data_ptr() without bumping _version, a replaced tensor may reuse
+        # the id (ADVICE r5); host bands (10 / 4 values) are cheap enough to key on by VALUE
+        key = (id(fb), fb._version, fb.data_ptr(), tuple(fb.shape), str(fb.device), in_channels, n_freqs)
+        if fb.device.type == "cpu" and fb.numel() <= 16:
+            key += (tuple(fb.detach().reshape(-1).tolist()),)
+    else:                                        # list / tuple / ndarray bands: in-place edits are invisible to identity -- key on the values
+        try:
+            key = (tuple(float(v) for v in fb), in_channels, n_freqs) if fb is not None else (None, in_channels, n_freqs)
+        except TypeError:
+            key = (id(fb), in_channels, n_freqs)
     hit = getattr(e, "_sn_pow2_verdict", None)
     if hit is not None and hit[0] == key:
         return hit[1]

@@ -51,6 +51,23 @@ def test_embedding_verdict_is_cached_and_follows_the_bands():
     assert not rendering._fused_embeddings(e)
     with pytest.raises(NotImplementedError, match="Embedding"):
         rendering._check_embeddings(e)
+    # mutations that do NOT bump Tensor._version: .data swap, set_(), list-typed bands edited in place
+    e2 = sinnerf_amd.Embedding(3, 10)
+    assert rendering._is_pow2_bands(e2, 3, 10)
+    e2.freq_bands.data = torch.linspace(1.0, 512.0, 10)
+    assert not rendering._is_pow2_bands(e2, 3, 10)
+    e3 = sinnerf_amd.Embedding(3, 4)
+    assert rendering._is_pow2_bands(e3, 3, 4)
+    e3.freq_bands.set_(torch.tensor([1.0, 2.0, 4.0, 9.0]))
+    assert not rendering._is_pow2_bands(e3, 3, 4)
+
+    class ListBands:
+        in_channels, N_freqs = 3, 4
+        freq_bands = [1.0, 2.0, 4.0, 8.0]
+    lb = ListBands()
+    assert rendering._is_pow2_bands(lb, 3, 4)
+    lb.freq_bands[3] = 7.0
+    assert not rendering._is_pow2_bands(lb, 3, 4)
 
 
 def _lr_trace(sched, opt, n):

@@ -3,6 +3,9 @@
 R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+# the kernel sources these profiles are measured ON, hashed here -- on the measuring box, at measurement time: the summaries
+# carry this value; nothing re-stamps a profile afterwards (a hash-definition change means re-measuring, or `traffic: null`)
+python -c "import bench; print(bench.kernel_sources_sha())" > gpurun_out/kernel_sources_sha.txt 2>/dev/null
 echo "== pytest"; timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -5 gpurun_out/pytest_gpu.log
 echo "== smoke"; timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/smoke.log
 echo "== bench fp32"; timeout 600 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench.log | cut -c1-300

@@ -58,9 +58,8 @@ for name, disp in per.items():
         mode = "bf16x3" if ("bf16x3" in name or "dw_kernel" in name) else "bf16" if ("bf16" in name or "shorter" in suffix) else "fp32"   # step the launch belongs to
         out["kernels"][name + suffix] = {"step": mode, "fetch_bytes_x2": fetch, "write_bytes": write, "ms": ms,
                                          "hbm_TB_per_s": (fetch + write) / ms / 1e9, "bytes_per_point": (fetch + write) / POINTS}
-sys.path.insert(0, os.getcwd())
-from bench import kernel_sources_sha           # bench.py refuses a profile measured on other kernel sources  # noqa: E402
-out["kernel_sources_sha"] = kernel_sources_sha()
+# the hash of the kernel sources the profile was measured ON: written by tools/gpu_round.sh on the measuring box (never recomputed here)
+out["kernel_sources_sha"] = (open(f"{G}/kernel_sources_sha.txt").read().strip() if os.path.exists(f"{G}/kernel_sources_sha.txt") else "unstamped")
 out["git_head"] = subprocess.run(["git", "describe", "--always", "--dirty"], capture_output=True, text=True).stdout.strip() or "unknown"
 json.dump(out, open(f"{P}/{tag}_train_pmc.json", "w"), indent=1)
 if out["kernels"]:                      # the pointer bench.py follows (a lexicographic sort of the file names picked r03_run7 over r03_run33)

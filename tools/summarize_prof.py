@@ -50,7 +50,7 @@ if m:
     out["fine_pass_sq"] = {k: m[0][k] for k in ("dur_ms", "clock_ghz", "mfma_busy_frac", "wave_parked_frac(SQ_WAIT_ANY/SQ_WAVE_CYCLES)", "vgpr", "agpr")}
 if f and w:
     fetch, write = f[0]["FETCH_SIZE"] * 1024, w[0]["WRITE_SIZE"] * 1024
-    out["traffic"] = {"kernel": "mlp_fwd_f32_kernel fine pass", "points": POINTS, "fetch_bytes": fetch,
+    out["traffic"] = {"kernel": "mlp_fwd_f32g_kernel fine pass", "points": POINTS, "fetch_bytes": fetch,
                       "fetch_bytes_2x_corrected": 2 * fetch, "write_bytes": write, "hbm_bytes": 2 * fetch + write,
                       "algorithmic_bytes": POINTS * 20}
 # dynamic instruction mix of the fused MLP kernels (wave-level instruction counts summed over the launch)
@@ -88,7 +88,8 @@ if "traffic" in out:
     import subprocess
     head = subprocess.run(["git", "describe", "--always", "--dirty"], capture_output=True, text=True).stdout.strip() or "unknown"
     sys.path.insert(0, os.getcwd())
-    from bench import kernel_sources_sha           # the profile is only valid for the kernel sources it was measured on (bench.py pmc_traffic)
-    json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json", git_head=head, kernel_sources_sha=kernel_sources_sha()),
+    # the hash of the kernel sources the profile was measured ON: written by tools/gpu_round.sh on the measuring box (never recomputed here)
+    measured_sha = open("gpurun_out/kernel_sources_sha.txt").read().strip() if os.path.exists("gpurun_out/kernel_sources_sha.txt") else "unstamped"
+    json.dump(dict(out["traffic"], source=f"profiles/{tag}_pmc.json", git_head=head, kernel_sources_sha=measured_sha),
               open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "dispatches"}, indent=1)[:5000])
