@@ -31,7 +31,7 @@ sys.path.insert(0, REPO)
 
 FLOP_PER_POINT = 1186816            # SURVEY §8d / BASELINE.md §2 (un-padded MACs x2)
 FLOP_PER_POINT_TRAIN = 3489024      # forward + backward
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}      # MI355X_MICROARCH.md: dense MFMA peaks
 # compute_dtype="bf16x3" under autograd = forward, backward chain and weight gradients in the 3-term split on the bf16 MFMA (fp32-level
 # values; training state stored as (hi, lo) pairs in the bytes of the fp32 state).  Its records are priced against the pipe they RUN on
 # (VERDICT r5 "weak" #2): three bf16 MFMAs per product -> achieved = 3 x algorithmic against the 2.5 PF bf16 peak; the useful rate is kept
@@ -104,7 +104,7 @@ def roofline_record(dtype, n_rays, NS, NI, ms_fine, ms_coarse, ms_step, traffic=
                 "mlp_share_of_step": (ms_fine + ms_coarse) / ms_step}
     peak = PEAK_TFLOPS[dtype]
     return {"bound": "mfma",
-            "kernel": "mlp_fwd_%s_kernel (fine pass, %d points/launch)" % ("f32g" if dtype == "fp32" else "bf16_v3", n_rays * (NS + NI)),
+            "kernel": "mlp_fwd_%s_kernel (fine pass, %d points/launch)" % ({"fp32": "f32g", "fp16": "bf16_v3 [fp16 operands]"}.get(dtype, "bf16_v3"), n_rays * (NS + NI)),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "traffic_note": traffic_note or "no PMC summary for this workload",
             "flop_per_launch": flop_fine, "avg_launch_ms": ms_fine, "coarse_launch_ms": ms_coarse,
@@ -635,7 +635,7 @@ def compact_line(res):
     # priority: the other arithmetics of the headline frame, then every NAMED BASELINE config (configs[2..4]: the training step shapes in
     # bf16 -- config 3 also with the discriminator -- and the 800x800 frame), the GPU-side baseline, then the remaining precisions of the
     # same shapes; the per-stage / data-parallel legs that repeat information go last (train_dp_fp32 is the first to be dropped)
-    order = ["headline_frame_sharded", "bf16", "fp32", "bf16x3", "config5_bf16", "config5_sharded", "train_cfg4_dp",
+    order = ["headline_frame_sharded", "bf16", "fp32", "bf16x3", "fp16", "config5_bf16", "config5_sharded", "train_cfg4_dp",
              "train_cfg2_fp32", "train_cfg3_bf16", "train_cfg3_full_bf16", "train_cfg4_bf16", "train_cfg2_bf16", "train_cfg2_bf16x3"]
     late = ["train_cfg3_fp32", "train_cfg4_fp32", "config5_bf16x3", "config5_fp32"]
     prio = [("records", k) for k in order if k in rec]
@@ -994,7 +994,18 @@ def main():
                                  "max_abs_rgb_diff_vs_fp32_kernel": float((r3 - r32).abs().max()),
                                  "psnr_vs_fp32_kernel_dB": float(-10 * torch.log10(torch.mean((r3 - r32) ** 2).clamp_min(1e-20))),
                                  "roofline": roofline_record("bf16x3", n_rays, NS, NI, f3, c3, d3 / 3 * 1e3)}
-            del m3, r3, r32
+            del m3, r3
+            # fp16 operands on the bf16 instruction streams (SN_DTYPE_F16, round 6): the bf16 rate, 8 more operand bits
+            mh, _ = build_models(O, dev, "fp16")
+            dh, fh, ch = time_render(mh, emb, rays, NS, NI, 3, 1)
+            with torch.no_grad():
+                rh = sinnerf_amd.render_rays(mh, emb, rays, NS, False, 0, 0, NI, 1 << 19, True)["rgb_fine"]
+            records["fp16"] = {"value": n_rays * 3 / dh, "unit": "rays/s", "ms_per_step": dh / 3 * 1e3, "dtype": "fp16",
+                               "workload": "same frame, fp16-operand MFMAs (fp32 accumulate): the bf16 kernels' instruction streams with v_cvt_pk_f16_f32",
+                               "max_abs_rgb_diff_vs_fp32_kernel": float((rh - r32).abs().max()),
+                               "psnr_vs_fp32_kernel_dB": float(-10 * torch.log10(torch.mean((rh - r32) ** 2).clamp_min(1e-20))),
+                               "roofline": roofline_record("fp16", n_rays, NS, NI, fh, ch, dh / 3 * 1e3)}
+            del mh, rh, r32
             if (H, W, NI) == (400, 400, 64):
                 big = torch.from_numpy(O.lego_rays(800, 800, seed=0)).to(dev)          # BASELINE configs[4] shape, one GPU
                 for dt_name, k in (("bf16", 2), ("bf16x3", 1), ("fp32", 1)):

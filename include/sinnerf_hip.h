@@ -17,9 +17,10 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 4   /* 2: sn_sample_pdf_bins gained eps, dtype carries SN_DTYPE_CLASSIC_HEADS, sn_mlp_forward flag bits
+#define SN_ABI_VERSION 5   /* 2: sn_sample_pdf_bins gained eps, dtype carries SN_DTYPE_CLASSIC_HEADS, sn_mlp_forward flag bits
                             * 3: dtype carries SN_DTYPE_COMPILER_SCHEDULED and SN_DTYPE_EMB_BF16
-                            * 4: SN_DTYPE_BF16X3 (inference and training entries, packers), sn_pack_table_entries_dtype */
+                            * 4: SN_DTYPE_BF16X3 (inference and training entries, packers), sn_pack_table_entries_dtype
+                            * 5: SN_DTYPE_F16 (inference entries, packer), SN_FLAG_F32_LDS_RING */
 
 #define SN_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact fp32                                          */
 #define SN_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate                    */
@@ -35,6 +36,11 @@ extern "C" {
  * constructor's default (models/nerf.py:47-50, :91-100) -- ReLU after dir_encoding, Sigmoid after rgb -- instead of the
  * ShiftedSoftplus / WidenedSigmoid heads both reference call sites ask for (models/nerf.py:81-90, models/activations.py).
  * Blobs, training state and every other entry point are the same for both.                                          */
+#define SN_DTYPE_F16 4 /* ABI 5. sn_mlp_forward, sn_mlp_forward_embedded, sn_pack_weights only (INFERENCE): v_mfma_f32_32x32x16_f16,
+                        * fp16 operands (11 significand bits instead of bf16's 8) / fp32 accumulate at the bf16 matrix rate -- the
+                        * instruction streams of SN_DTYPE_BF16 with v_cvt_pk_f16_f32.  On the trained-weight fixtures its error is
+                        * 8-17x below SN_DTYPE_BF16's (tests/test_trained_weights_gpu.py); activations beyond +-65504 overflow (the
+                        * entry points do not check).  Blob layout and size = SN_DTYPE_BF16's. */
 #define SN_DTYPE_CLASSIC_HEADS 0x100
 /* OR-ed into `dtype` of sn_mlp_forward_train / sn_mlp_backward_chain (SN_DTYPE_BF16_STATE): run the compiler-scheduled kernels
  * (csrc/sn_mlp_fwd_bf16.hip, csrc/sn_mlp_bwd_bf16.hip) instead of the hand-scheduled ones (csrc/sn_mlp_fwd_bf16_t.hip, ...).

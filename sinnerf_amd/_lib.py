@@ -14,12 +14,13 @@ SN_DTYPE_F32 = 0
 SN_DTYPE_BF16 = 1
 SN_DTYPE_BF16_STATE = 2
 SN_DTYPE_BF16X3 = 3                 # inference + packer: fp32-level accuracy on the bf16 MFMA (3-term hi/lo split)
+SN_DTYPE_F16 = 4                    # inference + packer: fp16 operands on the bf16 kernels' instruction streams (ABI 5)
 SN_DTYPE_CLASSIC_HEADS = 0x100      # OR-ed into dtype: NeRF(use_new_activation=False) heads (include/sinnerf_hip.h)
 SN_FLAG_F32_LDS_RING = 4             # sn_mlp_forward flags: the LDS-ring fp32 inference kernel of rounds 1-5 (A/B; default = csrc/sn_mlp_fwd_f32g.hip)
 SN_DTYPE_COMPILER_SCHEDULED = 0x200 # OR-ed into dtype of the bf16-state training entries: the compiler-scheduled kernels (A/B, tests)
 N_RAW_TENSORS = 24
 SN_DTYPE_EMB_BF16 = 0x400           # ... emb stored as bf16 in K-slot order (hand-scheduled bf16-state kernels only)
-ABI_VERSION = 4                     # == SN_ABI_VERSION of include/sinnerf_hip.h this binding was written against
+ABI_VERSION = 5                     # == SN_ABI_VERSION of include/sinnerf_hip.h this binding was written against
 
 c_fp = ctypes.c_void_p      # device float*
 c_vp = ctypes.c_void_p

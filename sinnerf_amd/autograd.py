@@ -207,7 +207,9 @@ def render_rays_autograd(models, rays, N_samples, use_disp, perturb, noise_std, 
     n = rays.shape[0]
     stream = _lib.stream_ptr()
     for m in models:
-        dtype_code(m.compute_dtype)              # 'fp32', or 'bf16' = mixed precision: bf16-operand forward, fp32 backward
+        if dtype_code(m.compute_dtype) == _lib.SN_DTYPE_F16:       # 'fp32', 'bf16' (mixed precision) and 'bf16x3' have training kernels
+            raise NotImplementedError("sinnerf_amd: compute_dtype='fp16' is an INFERENCE arithmetic (sn_mlp_forward only); train in 'bf16' "
+                                      "(same matrix rate), 'bf16x3' or 'fp32', or render under torch.no_grad()")
     perturb_rand = torch.rand((n, N_samples), device=dev) if perturb > 0 else None
     z_vals = torch.empty((n, N_samples), dtype=torch.float32, device=dev)
     _lib.check(_lib.lib.sn_sample_coarse(_lib.ptr(rays), n, N_samples, int(bool(use_disp)), float(perturb),
@@ -270,6 +272,9 @@ def mlp_embedded_autograd(model, x, sigma_only):
     sites feed embeddings of data: rays / sample depths carry no gradient, rendering.py:312) -- asking for it raises.
     ``sigma_only`` (nerf.py:136-138) runs the full network on a zero direction embedding and returns the sigma column;
     the head / dir-branch parameters then receive exact zeros where torch would leave ``.grad`` at None."""
+    if dtype_code(model.compute_dtype) == _lib.SN_DTYPE_F16:
+        raise NotImplementedError("sinnerf_amd: compute_dtype='fp16' is an INFERENCE arithmetic; call under torch.no_grad() or train in "
+                                  "'bf16' / 'bf16x3' / 'fp32'")
     if x.requires_grad:
         raise NotImplementedError("sinnerf_amd.NeRF.forward: the gradient with respect to the embedded input x is not "
                                   "implemented (parameter gradients are); detach x, or differentiate through render_rays")

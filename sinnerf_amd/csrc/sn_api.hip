@@ -1,4 +1,5 @@
 // sn_api.hip -- the extern "C" boundary declared in include/sinnerf_hip.h + the weight packer.
+#include <hip/hip_fp16.h>
 #include "../../include/sinnerf_hip.h"
 #include "sn_device.h"
 #include "sn_layout.h"
@@ -51,6 +52,17 @@ int sn_mlp_forward_bf16_launch(const void* blob, const float* in0, const float* 
 int sn_mlp_forward_bf16_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
                                int state_bf16, hipStream_t stream);
+// ... the fp16-operand pass of the two bf16 inference kernels (SN_DTYPE_F16, -DSN_OPERAND_F16)
+int sn_mlp_forward_bf16_f16_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                               int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
+                               int state_bf16, hipStream_t stream);
+int sn_mlp_forward_bf16_f16_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                               int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
+                               int state_bf16, hipStream_t stream);
+int sn_mlp_forward_bf16_v3_f16_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
+                                  float* out, hipStream_t stream);
+int sn_mlp_forward_bf16_v3_f16_classic_launch(const void* blob, const float* rays, const float* z_vals, long n_points, int n_samples,
+                                  float* out, hipStream_t stream);
 int sn_mlp_forward_bf16x3_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld, int sigma_only,
                                  int input_mode, float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
 int sn_mlp_forward_bf16x3_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
@@ -112,6 +124,7 @@ pack_kernel(RawPtrs raw, const snl::PackEntry* __restrict__ table, long n, char*
     if (dtype == snl::DT_F32 || as_f32) *reinterpret_cast<float*>(blob + e.dst) = v;
     else if (e.src >= 0 && (e.src & snl::SRC_LO_FLAG))             // bf16x3: the remainder of the RNE high part, itself RNE
       *reinterpret_cast<unsigned short*>(blob + e.dst) = f32_to_bf16_rne(__fsub_rn(v, __uint_as_float((unsigned)f32_to_bf16_rne(v) << 16)));
+    else if (dtype == snl::DT_F16) *reinterpret_cast<__half*>(blob + e.dst) = __float2half_rn(v);    // SN_DTYPE_F16: fp16 operands (RNE)
     else *reinterpret_cast<unsigned short*>(blob + e.dst) = f32_to_bf16_rne(v);
   }
 }
@@ -140,17 +153,17 @@ const char* sn_error_string(int code) {
 }
 
 long sn_packed_weights_bytes(int dtype) {
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3 && dtype != SN_DTYPE_F16) return SN_E_UNSUPPORTED;
   return snl::blob_bytes(dtype);
 }
 long sn_pack_table_entries(void) { return snl::table_entries(); }
 long sn_pack_table_entries_dtype(int dtype) {
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3 && dtype != SN_DTYPE_F16) return SN_E_UNSUPPORTED;
   return snl::table_entries_dt(dtype);
 }
 
 int sn_build_pack_table(int dtype, int32_t* table_host) {
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3 && dtype != SN_DTYPE_F16) return SN_E_UNSUPPORTED;
   if (!table_host) return SN_E_BADARG;
   snl::build_pack_table(dtype, reinterpret_cast<snl::PackEntry*>(table_host));
   return 0;
@@ -181,7 +194,7 @@ int sn_build_pack_table_bwd_bf16x3(int32_t* table_host) {
 }
 
 int sn_pack_weights(const float* const* raw, const int32_t* table, long n_entries, void* blob, int dtype, void* stream) {
-  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3) return SN_E_UNSUPPORTED;
+  if (dtype != SN_DTYPE_F32 && dtype != SN_DTYPE_BF16 && dtype != SN_DTYPE_BF16X3 && dtype != SN_DTYPE_F16) return SN_E_UNSUPPORTED;
   if (!raw || !table || !blob || n_entries <= 0) return SN_E_BADARG;
   RawPtrs rp;
   for (int i = 0; i < snl::N_RAW; ++i) {
@@ -211,6 +224,13 @@ int sn_mlp_forward(const void* blob, int dtype, const float* rays, const float* 
   if (dtype == SN_DTYPE_BF16X3)                  // fp32-level accuracy on the bf16 MFMA: 3-term split (csrc/sn_mlp_fwd_bf16x3.hip)
     return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out,
                                                     nullptr, nullptr, 0, (hipStream_t)stream);
+  if (dtype == SN_DTYPE_F16) {                   // fp16 operands on the bf16 kernels' instruction streams (round 6; inference only)
+    if (!sigma_only && !(flags & SN_FLAG_BF16_COMPILER_SCHEDULED))
+      return (classic ? sn_mlp_forward_bf16_v3_f16_classic_launch : sn_mlp_forward_bf16_v3_f16_launch)(
+          blob, rays, z_vals, n_rays * (long)n_samples, n_samples, out, (hipStream_t)stream);
+    return (classic ? sn_mlp_forward_bf16_f16_classic_launch : sn_mlp_forward_bf16_f16_launch)(
+        blob, rays, z_vals, n_rays * (long)n_samples, n_samples, sigma_only, 0, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
+  }
   if (dtype == SN_DTYPE_BF16 && !sigma_only && !(flags & SN_FLAG_BF16_COMPILER_SCHEDULED))     // the hand-scheduled kernel
     return SN_HEADS(classic, sn_mlp_forward_bf16_v3)(blob, rays, z_vals, n_rays * (long)n_samples, n_samples, out, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16)
@@ -373,6 +393,9 @@ int sn_mlp_forward_embedded(const void* blob, int dtype, const float* x, long n_
   dtype &= ~SN_DTYPE_CLASSIC_HEADS;
   if (dtype == SN_DTYPE_BF16X3)
     return SN_HEADS(classic, sn_mlp_forward_bf16x3)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, (hipStream_t)stream);
+  if (dtype == SN_DTYPE_F16)
+    return (classic ? sn_mlp_forward_bf16_f16_classic_launch : sn_mlp_forward_bf16_f16_launch)(
+        blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
   if (dtype == SN_DTYPE_BF16)
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, x, nullptr, n_rows, ld, sigma_only, 1, out, nullptr, nullptr, 0, 0, (hipStream_t)stream);
   if (dtype != SN_DTYPE_F32) return SN_E_UNSUPPORTED;

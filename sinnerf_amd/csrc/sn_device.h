@@ -13,13 +13,33 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // WidenedSigmoid heads, both reference call sites -- and with -DSN_CLASSIC_HEADS for the constructor's default
 // (models/nerf.py:91-100: ReLU after dir_encoding, Sigmoid after rgb).  The second pass lives in its own kernel namespace and
 // exports <name>_classic_launch; everything but the two head activations (and their derivatives) is the same code.
-#ifdef SN_CLASSIC_HEADS
-#define snk snkc
-constexpr bool SN_NEWACT = false;
-#define SN_LAUNCH_NAME(base) base##_classic_launch
+// The bf16-operand INFERENCE kernels (sn_mlp_fwd_bf16.hip, sn_mlp_fwd_bf16_v3.hip) are compiled once more with -DSN_OPERAND_F16
+// (round 6): the same instruction streams with v_cvt_pk_f16_f32 / v_mfma_f32_32x32x16_f16 -- fp16 operands, 11 significand bits
+// instead of 8 at the same matrix rate (SN_DTYPE_F16; its own kernel namespaces and <name>_f16[_classic]_launch entry points).
+#ifdef SN_OPERAND_F16
+#define SN_CVT_PK "v_cvt_pk_f16_f32"
+#define SN_MFMA_16 "v_mfma_f32_32x32x16_f16"
 #else
-constexpr bool SN_NEWACT = true;
+#define SN_CVT_PK "v_cvt_pk_bf16_f32"
+#define SN_MFMA_16 "v_mfma_f32_32x32x16_bf16"
+#endif
+#ifdef SN_CLASSIC_HEADS
+#ifdef SN_OPERAND_F16
+#define snk snkhc
+#define SN_LAUNCH_NAME(base) base##_f16_classic_launch
+#else
+#define snk snkc
+#define SN_LAUNCH_NAME(base) base##_classic_launch
+#endif
+constexpr bool SN_NEWACT = false;
+#else
+#ifdef SN_OPERAND_F16
+#define snk snkh
+#define SN_LAUNCH_NAME(base) base##_f16_launch
+#else
 #define SN_LAUNCH_NAME(base) base##_launch
+#endif
+constexpr bool SN_NEWACT = true;
 #endif
 
 // ---------------------------------------------------------------------------------------------

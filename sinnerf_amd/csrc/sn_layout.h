@@ -31,7 +31,7 @@ namespace snl {
 // DT_BF16X3 (sn_mlp_fwd_bf16x3.hip): every weight as a (hi, lo) pair of bf16 -- hi = RNE(w), lo = RNE(w - hi) -- for the 3-term split
 // product  W.x ~= Wh.xh + Wl.xh + Wh.xl  on the bf16 MFMA at fp32-level accuracy.  Slabs are K x 128 B like the fp32 ones:
 //   bf16x3: [K/16 k-steps][hi, lo][64 lanes][8] bf16    (two ds_read_b128 feed three MFMAs)
-enum { DT_F32 = 0, DT_BF16 = 1, DT_BF16X3 = 3 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_BF16X3 = 3, DT_F16 = 4 };     // DT_F16 (round 6): the DT_BF16 layout with fp16-rounded weights
 // "x3 state" -- the training state of the bf16x3 kernels (acts / G, slots 0..8; slot 9 and emb stay fp32): a row of 256 features is
 // 1 KB like an fp32 row, but holds every value as its (hi, lo) bf16 pair: per 8 consecutive features 16 B of hi parts, then 16 B of
 // lo parts.  The forward / chain epilogues have the pairs in registers anyway (they are the next layer's B operand); the
@@ -72,7 +72,7 @@ constexpr long slab_elem_offset(int s) {
   return o;
 }
 constexpr long TOTAL_W_ELEMS = slab_elem_offset(N_SLABS);           // 593920
-constexpr int esize(int dt) { return dt == DT_BF16 ? 2 : 4; }        // bytes per weight in the blob (bf16x3: a 2 + 2 byte pair)
+constexpr int esize(int dt) { return (dt == DT_BF16 || dt == DT_F16) ? 2 : 4; }        // bytes per weight in the blob (bf16x3: a 2 + 2 byte pair)
 constexpr long bias_byte_offset(int dt) { return TOTAL_W_ELEMS * esize(dt); }
 constexpr int BIAS_FLOATS = N_SLABS * 32;
 // aux table (fp32) behind the biases:  sigma_w[2][128] | rgb_w[3][2][64] | sigma_b, rgb_b[3] | pad  -> 648 floats

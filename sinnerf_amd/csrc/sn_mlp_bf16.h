@@ -20,7 +20,7 @@ typedef RingT<64, RING_SLOT_BYTES_BF16> RingB;
 
 SN_DEV uint32_t pack2(float a, float b) {        // {bf16(a), bf16(b)}, RNE (asm: hipcc converts the halves separately + v_perm)
   uint32_t d;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  asm(SN_CVT_PK " %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
 SN_DEV uint32_t relu_pk(uint32_t x) {            // ReLU on a packed bf16 pair: v_pk_max_i16 x, 0
@@ -41,7 +41,7 @@ SN_DEV u32x4 pack8(const float* v) {
 // (the packed dwords t0, t1 = the bf16 pairs written to the AGPR file are returned: the bf16-state training variants
 //  store exactly these values)
 SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1) {   // pack, ReLU on the pairs
-  asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+  asm volatile(SN_CVT_PK " %0, %2, %3\n\t" SN_CVT_PK " %1, %4, %5\n\t"
                "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\t"
                "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
                : "=&v"(t0), "=&v"(t1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
@@ -58,7 +58,7 @@ SN_DEV void epi_relu(int reg, float x0, float x1, float x2, float x3) {
 // chain otherwise re-reads for [h > 0].
 SN_DEV void epi_relu_bits(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1, uint32_t& bits) {
   const uint32_t sm = 0x80008000u;              // in an SGPR: v_and_or_b32 takes no literal on gfx9, and no VGPR is spent on it
-  asm volatile("v_cvt_pk_bf16_f32 %0, %3, %4\n\tv_cvt_pk_bf16_f32 %1, %5, %6\n\t"
+  asm volatile(SN_CVT_PK " %0, %3, %4\n\t" SN_CVT_PK " %1, %5, %6\n\t"
                "v_lshrrev_b32 %2, 1, %2\n\tv_and_or_b32 %2, %0, %9, %2\n\t"
                "v_pk_max_i16 %0, %0, 0\n\tv_lshrrev_b32 %2, 1, %2\n\t"
                "v_and_or_b32 %2, %1, %9, %2\n\tv_pk_max_i16 %1, %1, 0\n\t"
@@ -70,17 +70,17 @@ SN_DEV void epi_relu_bits(int reg, float x0, float x1, float x2, float x3, uint3
 SN_DEV void epi_relu_f32_bits(int reg, float x0, float x1, float x2, float x3, float (&v)[4], uint32_t& t0, uint32_t& t1,
                               uint32_t& bits) {
   const uint32_t sm = 0x80008000u;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %7, %8\n\tv_cvt_pk_bf16_f32 %1, %9, %10\n\t"
+  asm volatile(SN_CVT_PK " %0, %7, %8\n\t" SN_CVT_PK " %1, %9, %10\n\t"
                "v_max_f32 %2, 0, %7\n\tv_max_f32 %3, 0, %8\n\tv_max_f32 %4, 0, %9\n\tv_max_f32 %5, 0, %10\n\t"
                "v_lshrrev_b32 %6, 1, %6\n\tv_and_or_b32 %6, %0, %13, %6\n\t"
-               "v_lshrrev_b32 %6, 1, %6\n\tv_cvt_pk_bf16_f32 %0, %2, %3\n\t"
-               "v_and_or_b32 %6, %1, %13, %6\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+               "v_lshrrev_b32 %6, 1, %6\n\t" SN_CVT_PK " %0, %2, %3\n\t"
+               "v_and_or_b32 %6, %1, %13, %6\n\t" SN_CVT_PK " %1, %4, %5\n\t"
                "v_accvgpr_write_b32 a[%11], %0\n\tv_accvgpr_write_b32 a[%12], %1"
                : "=&v"(t0), "=&v"(t1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "+v"(bits)
                : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1), "s"(sm));
 }
 SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3, uint32_t& t0, uint32_t& t1) {   // no activation
-  asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+  asm volatile(SN_CVT_PK " %0, %2, %3\n\t" SN_CVT_PK " %1, %4, %5\n\t"
                "v_accvgpr_write_b32 a[%6], %0\n\tv_accvgpr_write_b32 a[%7], %1"
                : "=&v"(t0), "=&v"(t1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
 }
@@ -90,7 +90,7 @@ SN_DEV void epi_copy(int reg, float x0, float x1, float x2, float x3) {
 }
 SN_DEV void epi_relu_f32(int reg, float x0, float x1, float x2, float x3, float (&v)[4], uint32_t& t0, uint32_t& t1) {   // fp32 ReLU
   asm volatile("v_max_f32 %2, 0, %6\n\tv_max_f32 %3, 0, %7\n\tv_max_f32 %4, 0, %8\n\tv_max_f32 %5, 0, %9\n\t"
-               "v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\t"
+               SN_CVT_PK " %0, %2, %3\n\t" SN_CVT_PK " %1, %4, %5\n\t"
                "v_accvgpr_write_b32 a[%10], %0\n\tv_accvgpr_write_b32 a[%11], %1"
                : "=&v"(t0), "=&v"(t1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
                : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(reg), "n"(reg + 1));
@@ -122,14 +122,14 @@ constexpr int XP16_WAVE_BYTES = 32 * XP16_PITCH;            // 2560
 // previous layer's v_accvgpr_write, and a VALU write -> MFMA read needs 2 wait states the compiler cannot insert for asm.
 template <bool FIRST>
 SN_DEV void mma_a(f32x16& acc, const u32x4& a, int reg) {
-  if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
+  if (FIRST) asm volatile("s_nop 1\n\t" SN_MFMA_16 " %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
+  else asm volatile(SN_MFMA_16 " %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(a), "n"(reg), "n"(reg + 3));
 }
 // ... or B in VGPRs
 template <bool FIRST>
 SN_DEV void mma_v(f32x16& acc, const u32x4& a, const u32x4& b) {
-  if (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  if (FIRST) asm volatile("s_nop 1\n\t" SN_MFMA_16 " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else asm volatile(SN_MFMA_16 " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // MFMA (8 passes) -> VALU read of its result: the wait states the compiler would insert for a builtin MFMA
 SN_DEV void mfma_result_fence() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }

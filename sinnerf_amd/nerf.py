@@ -20,14 +20,17 @@ _DTYPES = {"fp32": _lib.SN_DTYPE_F32, "float32": _lib.SN_DTYPE_F32, torch.float3
            "bf16": _lib.SN_DTYPE_BF16, "bfloat16": _lib.SN_DTYPE_BF16, torch.bfloat16: _lib.SN_DTYPE_BF16,
            # fp32-level accuracy on the bf16 matrix cores (3-term hi/lo split, csrc/sn_mlp_{fwd,bwd}_bf16x3.hip): inference, and
            # under autograd the forward, the backward chain and the weight gradients (training state: (hi, lo) bf16 pairs in fp32-sized buffers)
-           "bf16x3": _lib.SN_DTYPE_BF16X3}
+           "bf16x3": _lib.SN_DTYPE_BF16X3,
+           # fp16 operands / fp32 accumulate at the bf16 rate (v_mfma_f32_32x32x16_f16): INFERENCE only -- 11 significand bits instead of 8,
+           # 8-17x closer to the fp32 render than "bf16" on the trained-weight fixtures; activations beyond +-65504 overflow
+           "fp16": _lib.SN_DTYPE_F16, "float16": _lib.SN_DTYPE_F16, torch.float16: _lib.SN_DTYPE_F16}
 
 
 def dtype_code(dtype):
     try:
         return _DTYPES[dtype]
     except KeyError:
-        raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32', 'bf16' or 'bf16x3')")
+        raise ValueError(f"unsupported compute dtype {dtype!r} (use 'fp32', 'bf16', 'bf16x3' or -- inference only -- 'fp16')")
 
 
 class Embedding(nn.Module):
@@ -174,7 +177,7 @@ class NeRF(nn.Module):
         for t in raws:
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("sinnerf_amd.NeRF: parameters must be contiguous float32 master weights")
-        if self._training_pack(raws):
+        if self._training_pack(raws) and code != _lib.SN_DTYPE_F16:      # (fp16 operands: inference only, no transposed blob)
             return self._pack_both(code, raws, dev, sig)[0]
         blob = hit[0] if (hit is not None and hit[0].device == dev) else \
             torch.empty(_lib.lib.sn_packed_weights_bytes(code), dtype=torch.uint8, device=dev)

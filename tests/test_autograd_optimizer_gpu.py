@@ -1,5 +1,6 @@
-"""GPU: round-2 additions on the host side of the path -- NeRF.forward under autograd, the flat optimiser against
-stale-view / stale-pack failure modes, launch-graph capturability."""
+"""GPU: the host side of the training path -- NeRF.forward under autograd, the flat optimiser against stale-view / stale-pack failure modes,
+the weight-gradient entry against fp64 contractions, the gradient sink, launch-graph capturability (HIP graph == eager).  (Filed by subject in
+round 6; these were tests/test_round2_gpu.py.)"""
 import numpy as np
 import pytest
 

@@ -1,6 +1,6 @@
 """bench.py is its own launcher: `python bench.py --gpus N` with no WORLD_SIZE starts N ranks itself.
 The rendezvous half runs here on CPU with gloo through the SAME launcher function and argument parser; the GPU half is
-covered by tests/test_round3_gpu.py::test_bench_self_launch_two_gloo_ranks_one_gpu."""
+covered by tests/test_training_kernels_system_gpu.py::test_bench_self_launch_two_gloo_ranks_one_gpu."""
 import json
 import os
 import subprocess

@@ -20,7 +20,8 @@ def test_other_layer_configurations_are_refused_at_construction():
         with pytest.raises(NotImplementedError, match="D=8, W=256"):
             sinnerf_amd.NeRF(**kw)
     with pytest.raises(ValueError, match="compute dtype"):
-        sinnerf_amd.NeRF(compute_dtype="fp16")
+        sinnerf_amd.NeRF(compute_dtype="fp8")
+    assert sinnerf_amd.NeRF(compute_dtype="fp16").compute_dtype == "fp16"    # round 6: an INFERENCE arithmetic (tests/test_fp16_gpu.py)
 
 
 def test_no_torch_op_backend_in_the_package():
@@ -135,7 +136,7 @@ def test_bench_line_keeps_every_named_config_and_stays_under_the_driver_tail():
     named configs present."""
     import json
     import bench
-    d = json.load(open(os.path.join(REPO, "profiles", "r05_final_bench_fp32.json")))
+    d = json.load(open(os.path.join(REPO, "profiles", "r06_run1_bench_full_fp32.json")))
     prose = "x" * 400
     res = dict(d)
     res["records"] = {k: dict(v, workload=prose, losses=prose, roofline=dict(v.get("roofline") or {}, kernel=prose, traffic_note=prose))

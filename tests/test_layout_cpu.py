@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/sinnerf_hip.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert L.lib.sn_abi_version() == L.ABI_VERSION == 4
+    assert L.lib.sn_abi_version() == L.ABI_VERSION == 5
     assert L.lib.sn_packed_weights_bytes(0) == 4 * (32 * (8 * 64 + 24 * 256 + 8 * 320 + 32 * 256 + 4 * 288) + 76 * 32 + 648)
     assert L.lib.sn_error_string(-3).decode().startswith("perturb")
 
@@ -254,7 +254,7 @@ def test_training_streams_are_deterministic_and_complete():
 
 def test_bf16_emb_positions_invert_the_layout_slot_maps():
     """SN_DTYPE_EMB_BF16 stores the embedded inputs at their K-slot positions (32 h + e / 16 h + e); sn_dw.hip's emb_xyz_pos / emb_dir_pos
-    (restated here, and in tests/test_round3_gpu.py where the device code is checked) must be the inverse of csrc/sn_layout.h's
+    (restated here, and in tests/test_training_kernels_system_gpu.py where the device code is checked) must be the inverse of csrc/sn_layout.h's
     slot -> column maps the packed weights are built from."""
     from sinnerf_amd import _lib as L
 

@@ -429,7 +429,7 @@ def test_empty_batch_and_unsupported_sizes():
     with pytest.raises(SinnerfHipError):
         _lib.check(rc, "sn_composite_forward")
     # ... while render_rays itself takes such a call (and other layer / embedding configurations) through the general torch-op
-    # path on the device: tests/test_round3_gpu.py::test_general_configurations_*
+    # path on the device: tests/test_training_kernels_system_gpu.py::test_general_configurations_*
 
 
 def test_bf16_hand_scheduled_kernel_equals_compiler_scheduled():

@@ -114,7 +114,7 @@ def test_render_gradients_on_trained_weights(name):
     w = worst["bf16x3"]
     assert max(w["sampled_coarse"], w["sampled_fine"]) <= 1e-2 and max(w["norm_coarse"], w["norm_fine"]) <= 2e-3, w
     # bf16: against the oracle's backward with the SAME operand roundings (forward under bf16_operands(), backward with
-    # operand_round=bf16_round) at the bars tests/test_round3_gpu.py holds the init-weight llff patch to (3e-2 norm-wise, cosine 0.9995
+    # operand_round=bf16_round) at the bars tests/test_training_kernels_system_gpu.py holds the init-weight llff patch to (3e-2 norm-wise, cosine 0.9995
     # on the large tensors), and loosely against the all-fp32 gradients (cosine >= 0.99: mixed precision is validated at convergence
     # length, tests/test_convergence_gpu.py -- one 96-ray batch differs by 5-10 % norm-wise in the first trunk layers, measured)
     models = O.model_params(meta)

@@ -1,5 +1,7 @@
-"""Round-3 GPU tests: training on the BASELINE config shapes, the ADVICE r2 fixes of the system
-surface, and bench.py as its own launcher."""
+"""GPU: the hand-scheduled bf16-state training kernels (bit identity with the compiler-scheduled ones, fuzz, determinism, the bf16 form of
+`emb`), training on the BASELINE config shapes (llff 5292-ray patch, the four-render step), the system surface (optimiser upgrade, FlatAdam state
+dict, refusals) and bench.py as its own launcher with two gloo ranks on one GPU.  (Filed by subject in round 6; these were
+tests/test_round3_gpu.py.)"""
 import json
 import os
 import subprocess

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out
 {
-[ -z "$SKIP_TESTS" ] && python -m pytest tests/test_grads_gpu.py tests/test_bf16_configs_gpu.py tests/test_round2_gpu.py -x -q -m gpu 2>&1 | tail -2
+[ -z "$SKIP_TESTS" ] && python -m pytest tests/test_grads_gpu.py tests/test_bf16_configs_gpu.py tests/test_autograd_optimizer_gpu.py -x -q -m gpu 2>&1 | tail -2
 for rep in 1 2; do for lib in "" "$@"; do echo -n "lib=${lib:-main}  "; SINNERF_HIP_LIB=$lib python tools/bf16_stage_time.py 2>&1 | grep "S="; done; done
 } | tee gpurun_out/ab_bf16_train.log
 cd /tmp

@@ -56,6 +56,8 @@ KNOBS = dict(prefetch=4,        # A-fragment prefetch distance in k-steps (ring 
              abl_sign4=0,       # timing experiment (WRONG results): one dwordx4 sign store per FOUR tiles instead of a dword per tile
              abl_vstore=1, abl_stage=1, abl_sign=1,   # store mode timing ablations (0 = leave out: WRONG results): the global stores, the
                                 # staging round trip (swaps + LDS writes / reads + stores), the sign-word arithmetic
+             f16=0,             # 1 = the SAME stream with fp16 operands (round 6, SN_DTYPE_F16): v_cvt_pk_f16_f32 / v_mfma_f32_32x32x16_f16
+                                # (same issue classes and latencies; v_pk_max_i16 is a ReLU on a packed fp16 pair as on a bf16 pair)
              abl_stw=1, abl_str=1)    # ... the staging ds_write_b128s alone / the staging ds_read_b128s alone (which of the two owns the
                                 # LDS bank conflicts the counters see: VERDICT r3 item 8)
 
@@ -763,6 +765,8 @@ def main():
         k, v = kv.split("=")
         knobs[k] = type(KNOBS[k])(float(v)) if isinstance(KNOBS[k], float) else int(v)
     g = gen(knobs)
+    if knobs.get("f16"):
+        g.out = [l.replace("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32").replace("v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16") for l in g.out]
     n_other = len(g.out) - g.mfma_count
     with open(out_path, "w") as f:
         f.write("// GENERATED by tools/gen_bf16_trunk.py %s -- do not edit.\n" % " ".join(sys.argv[2:]))
