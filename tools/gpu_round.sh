@@ -30,8 +30,8 @@ echo "== pmc train (HBM bytes of the training kernels)"
 timeout 600 $P --pmc FETCH_SIZE -o pmc_train_fetch -- python $R/tools/train_bench.py > $R/gpurun_out/prof_pmc_train_fetch.log 2>&1; echo "exit $?"
 timeout 600 $P --pmc WRITE_SIZE -o pmc_train_write -- python $R/tools/train_bench.py > $R/gpurun_out/prof_pmc_train_write.log 2>&1; echo "exit $?"
 echo "== bf16x3 inference launch: stats, then cycles / MFMA-busy / clock"
-timeout 300 $P --stats -o stats_x3 -- python $R/tools/x3_infer_time.py fp32 bf16 bf16x3 > $R/gpurun_out/x3_infer.log 2>&1; echo "exit $?"; cat $R/gpurun_out/x3_infer.log | tail -3
-timeout 300 $P --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -o pmc_x3 -- python $R/tools/x3_infer_time.py fp32 bf16 bf16x3 > /dev/null 2>&1; echo "exit $?"
+timeout 300 $P --stats -o stats_x3 -- python $R/tools/x3_infer_time.py fp32 bf16 bf16x3 fp16 > $R/gpurun_out/x3_infer.log 2>&1; echo "exit $?"; cat $R/gpurun_out/x3_infer.log | tail -3
+timeout 300 $P --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -o pmc_x3 -- python $R/tools/x3_infer_time.py fp32 bf16 bf16x3 fp16 > /dev/null 2>&1; echo "exit $?"
 cd $R
 python - <<'PY' | tee gpurun_out/x3_infer_pmc.txt
 import csv, glob, collections, statistics
@@ -51,3 +51,7 @@ echo "== pmc train (cycles, MFMA-busy, clock of the training kernels)"
 bash tools/train_pmc.sh > gpurun_out/train_pmc.log 2>&1; echo "exit $?"; tail -12 gpurun_out/train_pmc.txt
 echo "== bf16x3 training stages: generated streams vs compiler-scheduled (time, bit identity)"
 python tools/x3_stage_time.py 20 2>&1 | grep -v amdgpu.ids | tee gpurun_out/x3_stage_time.txt
+echo "== fp32 inference: round-6 kernel vs the LDS-ring kernel (time, bit identity), then PMC passes"
+python tools/f32_infer_ab.py 3 2>&1 | grep -v amdgpu.ids | tee gpurun_out/f32_infer_ab.txt
+bash tools/f32_pmc.sh final > /dev/null 2>&1; echo "exit $?"; grep -A3 "f32g_kernel<false, 0, false>" gpurun_out/f32_pmc_final.txt | head -8
+
