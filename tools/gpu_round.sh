@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 python -c "import bench; print(bench.kernel_sources_sha())" > gpurun_out/kernel_sources_sha.txt 2>/dev/null
 echo "== pytest"; timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -5 gpurun_out/pytest_gpu.log
 echo "== smoke"; timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/smoke.log
-echo "== bench fp32"; timeout 600 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench.log | cut -c1-300
+echo "== bench fp32"; timeout 600 python bench.py --steps 3 --warmup 1 --full-json gpurun_out/bench_full_fp32_main.json > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench.log | cut -c1-300
 echo "== bench bf16"; timeout 600 python bench.py --steps 3 --warmup 1 --dtype bf16 --no-cpu-baseline > gpurun_out/bench_bf16.log 2>&1; echo "exit $?"; tail -1 gpurun_out/bench_bf16.log | cut -c1-200
 echo "== train bench"; timeout 600 python tools/train_bench.py > gpurun_out/train_bench.log 2>&1; echo "train exit $?"; tail -1 gpurun_out/train_bench.log
 cd /tmp
