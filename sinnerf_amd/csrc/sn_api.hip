@@ -19,6 +19,10 @@ int sn_mlp_backward_chain_f32_launch(const void* bblob, const float* acts, const
                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_mlp_backward_chain_f32_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                      long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
+int sn_mlp_backward_chain_f32g_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw, long n_points,
+                                      long slot_rows, float* G, float* g_out, hipStream_t stream);
+int sn_mlp_backward_chain_f32g_classic_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
+                                              long n_points, long slot_rows, float* G, float* g_out, hipStream_t stream);
 int sn_mlp_backward_chain_bf16_launch(const void* bblob, const float* acts, const float* out_raw, const float* g_raw,
                                       long n_points, long slot_rows, float* G, float* g_out, int state_bf16,
                                       hipStream_t stream);
@@ -317,6 +321,8 @@ int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, co
   if (dtype != SN_DTYPE_F32)
     return SN_HEADS(classic, sn_mlp_backward_chain_bf16)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
                                                          dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
+  if (!compiler_scheduled)                       // round 6: the fragments-from-L2 chain (csrc/sn_mlp_bwd_f32g.hip): the same bits
+    return SN_HEADS(classic, sn_mlp_backward_chain_f32g)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out, (hipStream_t)stream);
   return SN_HEADS(classic, sn_mlp_backward_chain_f32)(blob_bwd, acts, out_raw, g_raw, n_points, slot_rows, g_acts, g_out,
                                                       (hipStream_t)stream);
 }

@@ -87,3 +87,41 @@ def test_training_forward_generations_write_the_same_state(n, S, new_act):
         assert torch.isfinite(acts_n[slot, :P, :w]).all(), slot
         assert torch.equal(acts_n[slot, :P, :w], acts_o[slot, :P, :w]), slot
     assert torch.equal(emb_n[:P, :63], emb_o[:P, :63]) and torch.equal(emb_n[:P, 64:91], emb_o[:P, 64:91])
+
+
+@pytest.mark.parametrize("n,S", [(70, 37), (4096, 128), (3, 5)])
+@pytest.mark.parametrize("new_act", [True, False])
+def test_backward_chain_generations_write_the_same_gradients(n, S, new_act):
+    """sn_mlp_backward_chain(SN_DTYPE_F32): the round-6 chain (csrc/sn_mlp_bwd_f32g.hip: fragments from L2, the derivative mask as ONE VALU
+    gap per slab, LDS round trip into the AGPRs, no barrier) against the round-2 LDS-ring chain (SN_DTYPE_COMPILER_SCHEDULED) on the same
+    stored state: all ten slots of G (rows of real points; pad rows stay zero), the head block, g_out -- bit for bit."""
+    import sinnerf_amd
+    from sinnerf_amd import _lib
+    d = dev()
+    m = sinnerf_amd.NeRF(use_new_activation=new_act)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.trained_params("fine").items()})
+    m = m.to(d).train()
+    rays = O.lego_rays(400, 400, seed=0)
+    rays = np.ascontiguousarray(rays[np.random.RandomState(11 + n).choice(rays.shape[0], n, replace=False)])
+    z = np.sort(np.random.RandomState(S).uniform(2, 6, (n, S)).astype(np.float32), -1)
+    rays_t, z_t = torch.from_numpy(rays).to(d), torch.from_numpy(z).to(d)
+    out, acts, emb = _train_forward(m, rays_t, z_t, 0)
+    P = n * S
+    rows = acts.shape[1]
+    acts[:, P:] = 0                                                          # pad rows: whatever the forward left there is not read back
+    g = torch.from_numpy(np.random.RandomState(2).standard_normal((n, S, 4)).astype(np.float32)).to(d)
+    res = []
+    for flag in (0, _lib.SN_DTYPE_COMPILER_SCHEDULED):
+        G = torch.full((10, rows, 256), float("nan"), device=d); G[:, P:] = 0
+        g_o = torch.full((P, 4), float("nan"), device=d)
+        _lib.check(_lib.lib.sn_mlp_backward_chain(_lib.ptr(m.packed_bwd("fp32")), m.kernel_dtype(_lib.SN_DTYPE_F32) | flag, _lib.ptr(acts),
+                                                  _lib.ptr(out), _lib.ptr(g), P, rows, _lib.ptr(G), _lib.ptr(g_o), _lib.stream_ptr()), "chain")
+        torch.cuda.synchronize()
+        res.append((G, g_o))
+    (Gn, gon), (Go, goo) = res
+    assert torch.isfinite(gon).all() and torch.equal(gon, goo)
+    for slot in range(10):
+        w = 128 if slot == 9 else 256
+        assert torch.isfinite(Gn[slot, :P, :w]).all(), slot
+        assert torch.equal(Gn[slot, :P, :w], Go[slot, :P, :w]), slot
+    assert torch.equal(Gn[9, :P, 128:160], Go[9, :P, 128:160])               # the rgb / sigma block of the weight-gradient kernels
