@@ -12,6 +12,10 @@ int sn_mlp_forward_f32g_launch(const void* blob, const float* in0, const float* 
                                int input_mode, float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
 int sn_mlp_forward_f32g_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld, int sigma_only,
                                        int input_mode, float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
+int sn_mlp_forward_f32g_store_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld, int sigma_only,
+                                     int input_mode, float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
+int sn_mlp_forward_f32g_store_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld, int sigma_only,
+                                             int input_mode, float* out, float* acts, float* emb, long slot_rows, hipStream_t stream);
 int sn_mlp_forward_f32_classic_launch(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                               int sigma_only, int input_mode, float* out, float* acts, float* emb,
                               long slot_rows, hipStream_t stream);
@@ -276,7 +280,7 @@ int sn_mlp_forward_train(const void* blob, int dtype, const float* rays, const f
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
                                                   dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
   if (!compiler_scheduled)                       // round 6: the fragments-from-L2 kernel in store mode (csrc/sn_mlp_fwd_f32g.hip): the same state
-    return SN_HEADS(classic, sn_mlp_forward_f32g)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows, (hipStream_t)stream);
+    return SN_HEADS(classic, sn_mlp_forward_f32g_store)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows, (hipStream_t)stream);
   return SN_HEADS(classic, sn_mlp_forward_f32)(blob, rays, z_vals, n_points, n_samples, 0, 0, out, acts, emb, slot_rows,
                                                (hipStream_t)stream);
 }
@@ -296,7 +300,7 @@ int sn_mlp_forward_train_embedded(const void* blob, int dtype, const float* x, l
   if (dtype != SN_DTYPE_F32)
     return SN_HEADS(classic, sn_mlp_forward_bf16)(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows,
                                                   dtype == SN_DTYPE_BF16_STATE, (hipStream_t)stream);
-  return SN_HEADS(classic, sn_mlp_forward_f32g)(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows, (hipStream_t)stream);
+  return SN_HEADS(classic, sn_mlp_forward_f32g_store)(blob, x, nullptr, n_rows, ld, 0, 1, out, acts, emb, slot_rows, (hipStream_t)stream);
 }
 
 int sn_mlp_backward_chain(const void* blob_bwd, int dtype, const float* acts, const float* out_raw, const float* g_raw,

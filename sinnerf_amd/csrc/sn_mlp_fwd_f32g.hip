@@ -326,9 +326,17 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 }  // namespace snk
 
 // ---------------------------------------------------------------------------------------------------
-extern "C" int SN_LAUNCH_NAME(sn_mlp_forward_f32g)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
-                                                   int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
-                                                   hipStream_t stream) {
+// The file is compiled as TWO translation units (csrc/Makefile; compile time: six instantiations of a fully unrolled point tile): the
+// inference kernels (sn_mlp_forward_f32g[_classic]_launch) and, with -DSN_F32G_TU_STORE, the training forward
+// (sn_mlp_forward_f32g_store[_classic]_launch).
+#ifdef SN_F32G_TU_STORE
+#define SN_F32G_ENTRY sn_mlp_forward_f32g_store
+#else
+#define SN_F32G_ENTRY sn_mlp_forward_f32g
+#endif
+extern "C" int SN_LAUNCH_NAME(SN_F32G_ENTRY)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+                                             int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
+                                             hipStream_t stream) {
   using namespace snk;
   if (n_points <= 0) return 0;
   const long tiles = (n_points + 127) / 128;
@@ -344,25 +352,24 @@ extern "C" int SN_LAUNCH_NAME(sn_mlp_forward_f32g)(const void* blob, const float
     SN_ENSURE_DYN_LDS(kfn, lds);                                                                                    \
     hipLaunchKernelGGL(kfn, grid, block, lds, stream, b, in0, in1, n_points, s_or_ld, out, acts, emb, slot_rows);   \
   } while (0)
-#if defined(SN_F32G_AB)                         // timing builds: ONE instantiation (compile time): the frame render's, or the training
-#ifdef SN_F32G_AB_STORE                         // forward's with -DSN_F32G_AB_STORE
+#if defined(SN_F32G_AB)                         // timing builds (tools/build_variant_f32g.sh): ONE instantiation: the frame render's, or
+#ifdef SN_F32G_AB_STORE                         // the training forward's with -DSN_F32G_AB_STORE (which replaces BOTH objects)
   if (!store || input_mode != 0) return -4;
   SN_LAUNCH(false, 0, true);
 #else
   if (store || sigma_only || input_mode != 0) return -4;
   SN_LAUNCH(false, 0, false);
 #endif
+#elif defined(SN_F32G_TU_STORE)
+  if (!store) return -4;
+  if (input_mode == 0) SN_LAUNCH(false, 0, true); else SN_LAUNCH(false, 1, true);
+#elif defined(SN_CLASSIC_HEADS)                 // the sigma-only kernels never reach the heads: sn_api.hip routes them to the main pass
+  if (store || sigma_only) return -4;
+  if (input_mode == 0) SN_LAUNCH(false, 0, false); else SN_LAUNCH(false, 1, false);
 #else
-  if (store) {
-    if (input_mode == 0) SN_LAUNCH(false, 0, true); else SN_LAUNCH(false, 1, true);
-  }
-#ifdef SN_CLASSIC_HEADS                         // the sigma-only kernels never reach the heads: sn_api.hip routes them to the main pass
-  else if (sigma_only) return -4;
-  else if (input_mode == 0) SN_LAUNCH(false, 0, false); else SN_LAUNCH(false, 1, false);
-#else
-  else if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false); }
+  if (store) return -4;
+  if (input_mode == 0) { if (sigma_only) SN_LAUNCH(true, 0, false); else SN_LAUNCH(false, 0, false); }
   else { if (sigma_only) SN_LAUNCH(true, 1, false); else SN_LAUNCH(false, 1, false); }
-#endif
 #endif
 #undef SN_LAUNCH
   return (int)hipGetLastError();

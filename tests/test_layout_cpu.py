@@ -333,3 +333,17 @@ def test_x3_split_tile_swizzle_is_consistent_and_bank_conflict_free():
                     for half in (addrs[:32], addrs[32:]):                  # (b)
                         banks = [(a // 4 + d) % 64 for a in half for d in (0, 1)]
                         assert len(set(banks)) == 64, (W, f0, second, part)
+
+
+def test_relu_as_signed_integer_max_is_exact():
+    """csrc/sn_mlp_pipe.h epi32_relu_lds / lds_relu_word (round 6): the fp32 kernels apply ReLU in LDS as `ds_max_i32(word, 0)` -- no VALU
+    instruction next to the f32-input MFMA.  As signed integers every negative float (and -0.0) is < 0 and every positive float is its own
+    bit pattern, monotone in value: max_i32(bits(x), 0) must be bits(max(x, +0.0)) for every non-NaN x, incl. denormals and infinities."""
+    r = np.random.RandomState(0)
+    x = np.concatenate([r.standard_normal(200000).astype(np.float32) * np.float32(10.0) ** r.randint(-38, 38, 200000).astype(np.float32),
+                        np.array([0.0, -0.0, 1e-45, -1e-45, 1.1754944e-38, -1.1754944e-38, np.inf, -np.inf, 3.4028235e38, -3.4028235e38,
+                                  1.0, -1.0], np.float32)])
+    x = x[np.isfinite(x) | np.isinf(x)]
+    got = np.maximum(x.view(np.int32), np.int32(0)).view(np.float32)
+    want = np.where(x > 0, x, np.float32(0.0)).astype(np.float32)            # max(x, +0.0) with -0.0 -> +0.0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
