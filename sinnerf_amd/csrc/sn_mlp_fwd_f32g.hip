@@ -334,7 +334,8 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #else
 #define SN_F32G_ENTRY sn_mlp_forward_f32g
 #endif
-extern "C" int SN_LAUNCH_NAME(SN_F32G_ENTRY)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
+#define SN_F32G_LAUNCH_NAME(base) SN_LAUNCH_NAME(base)        // (one more level: the argument is expanded before ## pastes it)
+extern "C" int SN_F32G_LAUNCH_NAME(SN_F32G_ENTRY)(const void* blob, const float* in0, const float* in1, long n_points, int s_or_ld,
                                              int sigma_only, int input_mode, float* out, float* acts, float* emb, long slot_rows,
                                              hipStream_t stream) {
   using namespace snk;
