@@ -99,7 +99,12 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     const float x = __fadd_rn(ox, __fmul_rn(dx, zz));
     const float y = __fadd_rn(oy, __fmul_rn(dy, zz));
     const float z = __fadd_rn(oz, __fmul_rn(dz, zz));
+#ifdef SN_F32G_NO_VALU_BLOCKS                    // timing build: the trunk alone (no embedding / sigma head / softplus arithmetic)
+#pragma unroll
+    for (int e = 0; e < 32; ++e) xe[e] = x + (float)e;
+#else
     embed_xyz(x, y, z, h, xe);
+#endif
   } else {
     const float* row = in0 + p * (long)S;        // S = leading dimension here
     int hh = h;
@@ -163,10 +168,19 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
 #pragma unroll
         for (int i = 0; i < 4; ++i) sw[i] = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_SIGW + h * 128 + 16 * t + 4 * i);
       } else if (st == 3) {
+#ifdef SN_F32G_NO_VALU_BLOCKS
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sv[i] = r[i];
+        if (false)
+#endif
 #pragma unroll
         for (int i = 0; i < 16; ++i) sv[i] = relu1(r[i]);
 #pragma unroll
+#ifndef SN_F32G_NO_VALU_BLOCKS
         for (int i = 0; i < 16; ++i) sg = __builtin_fmaf(sw[i / 4][i % 4], sv[i], sg);        // same order as a K-slot sweep
+#else
+        for (int i = 0; i < 1; ++i) sg += sv[0];
+#endif
         asm volatile("" : "+v"(sg));
       } else if (st >= 4 && st < 8) {
         f32x4 x;
@@ -250,7 +264,12 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
   float de[16];
   if (INPUT_MODE == 0) {
     const float* rp = in0 + (p / S) * 8;
+#ifdef SN_F32G_NO_VALU_BLOCKS
+#pragma unroll
+    for (int e = 0; e < 16; ++e) de[e] = rp[3] + (float)e;
+#else
     embed_dir(rp[3], rp[4], rp[5], h, de);
+#endif
   } else {
     const float* row = in0 + p * (long)S;
     int hh = h;
@@ -275,8 +294,16 @@ mlp_fwd_f32g_kernel(const char* __restrict__ blob, const float* __restrict__ in0
     const int q = st / 6;
     float v[4];
 #pragma unroll
+#ifdef SN_F32G_NO_VALU_BLOCKS
+    for (int i = 0; i < 4; ++i) v[i] = r[4 * q + i];
+#else
     for (int i = 0; i < 4; ++i) v[i] = SN_NEWACT ? shifted_softplus_fast(r[4 * q + i]) : relu1(r[4 * q + i]);   // nerf.py:84 / :94
+#endif
 #pragma unroll
+#ifdef SN_F32G_NO_VALU_BLOCKS
+    for (int c = 0; c < 1; ++c) c3[0] += v[0];
+    if (false)
+#endif
     for (int c = 0; c < 3; ++c) {
       const f32x4 w = *reinterpret_cast<const f32x4*>(lds_aux + snl::AUX_RGBW + c * 128 + h * 64 + 16 * t + 4 * q);
       c3[c] = __builtin_fmaf(w[0], v[0], c3[c]);

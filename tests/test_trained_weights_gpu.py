@@ -137,3 +137,36 @@ def test_render_gradients_on_trained_weights(name):
     print(name, "bf16 vs bf16-emulated oracle: worst norm-wise %.2e; worst cosine vs the all-fp32 HIP gradients %.5f" % (worst16, worst_cos32))
     record(f"{name}:bf16:vs_emulated_oracle_norm", worst16)
     record(f"{name}:bf16:worst_cosine_vs_fp32", worst_cos32)
+
+
+def test_full_frame_on_trained_weights_against_the_staged_reference_on_the_same_gpu():
+    """BASELINE configs[1] at FULL size on trained weights: the 160 000-ray 400x400 frame (64+64, eval) of the trained student rendered by the
+    UNMODIFIED reference modules (oracle/_ref, staged by build(); PyTorch-ROCm eager on this GPU, eval.py's chunking) and by every arithmetic
+    of the HIP path.  fp32 and bf16x3: the fp32 bars on all 160 000 rays (the fixtures hold 96-192); fp16 / bf16: PSNR within 0.05 dB
+    (SURVEY section 8d protocol, gt = reference render + fixed pixel noise) and the measured err/bound recorded."""
+    import sinnerf_amd
+    from oracle import stage_ref
+    if not stage_ref.available():
+        pytest.skip("oracle/_ref is not staged on this box (build() stages it where /root/reference exists)")
+    ref_rendering, _ = stage_ref.load()
+    params = [O.trained_params("coarse"), O.trained_params("fine")]
+    ref_models, ref_emb = stage_ref.build_reference_models(params)
+    ref_models = [m.to(dev()).eval() for m in ref_models]
+    rays = torch.from_numpy(O.lego_rays(400, 400, seed=1)).to(dev())          # the student's held-out pose
+    with torch.no_grad():
+        parts = [ref_rendering.render_rays(ref_models, ref_emb, rays[i:i + 32768], 64, False, 0, 0, 64, 1 << 19, True, test_time=False)
+                 for i in range(0, rays.shape[0], 32768)]
+    ref = {k: torch.cat([p[k] for p in parts], 0).cpu().numpy() for k in parts[0]}
+    gt = ref["rgb_fine"] + np.random.RandomState(0).normal(0, 0.02, ref["rgb_fine"].shape).astype(np.float32)
+    for dt in ("fp32", "bf16x3", "fp16", "bf16"):
+        with torch.no_grad():
+            got = to_np(sinnerf_amd.render_rays(trained_models(dt), embeddings(), rays, 64, False, 0, 0, 64, 1 << 19, True))
+        e = err_over_bound(got, ref)
+        d = O.psnr(got["rgb_fine"], gt) - O.psnr(ref["rgb_fine"], gt)
+        print(f"full frame, trained student [{dt}]: err / fp32 bound = {e:.4f}, dPSNR = {d:+.5f} dB")
+        record(f"full_frame_trained:{dt}:err_over_bound", e)
+        record(f"full_frame_trained:{dt}:dpsnr_db", d)
+        assert all(np.isfinite(v).all() for v in got.values())
+        assert abs(d) <= 0.05
+        if dt in ("fp32", "bf16x3"):
+            check_render(got, ref, tag=f"full-frame:{dt}")
