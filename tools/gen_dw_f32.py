@@ -12,7 +12,7 @@ statement laid out by hand:
     (no compiler-allocated AGPR, no scratch);
   * fragments: two sets of 4 + 4 VGPRs (v[F0 : F0+15]); the reads of pair s+1 (4 x ds_read2st64_b32: blocks a and a+2 are 256 B
     apart) are issued behind the first MFMAs of pair s, the counted wait sits in front of pair s+1's first MFMA;
-  * one LDS-DMA piece of the chunk three ahead per pair (m0 + global_load_lds_dwordx4), the bias column sums (4 v_add) too;
+  * one LDS-DMA piece of the chunk three ahead per pair (m0 + global_load_lds_dwordx4), the bias column sums (4 v_add, in ONE gap) too;
   * chunk entry: s_waitcnt vmcnt(16) (this chunk has landed, two younger ones in flight), s_barrier, the reads of pair 0.
 
 Operands of the chunk statement (see the kernel): bs0..3 (+v) column sums; la0 la1 lb0 lb1 (v) LDS read addresses of this
@@ -69,8 +69,10 @@ def gen():
             rs = reads(st ^ 1, s + 1)
             for j in range(4):
                 fill.setdefault(j, []).append(rs[j])
+        # the four bias column sums in ONE gap (round 6): next to the f32-input MFMA a gap with n VALU instructions costs 9.6 + 4 n cycles
+        # (tools/ubench/f32_gap_cost.hip) -- four gaps of one cost 54 cycles per 16 MFMAs, one gap of four 26
         for a in range(4):
-            fill.setdefault(4 + a, []).append("v_add_f32 %%[bs%d], %%[bs%d], v%d" % (a, a, FA(st, a)))
+            fill.setdefault(4, []).append("v_add_f32 %%[bs%d], %%[bs%d], v%d" % (a, a, FA(st, a)))
         g, o, lds = pieces[s]
         fill.setdefault(9, []).append("s_add_u32 m0, %%[md], %d" % lds)
         fill.setdefault(10, []).append("global_load_lds_dwordx4 %%[%s], %%[%s]" % (o, g))       # one MFMA between m0 and its use
