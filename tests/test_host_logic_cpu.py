@@ -136,7 +136,7 @@ def test_bench_line_keeps_every_named_config_and_stays_under_the_driver_tail():
     named configs present."""
     import json
     import bench
-    d = json.load(open(os.path.join(REPO, "profiles", "r06_run5_bench_full_fp32.json")))
+    d = json.load(open(os.path.join(REPO, "profiles", "r06_run6_bench_full_fp32.json")))
     prose = "x" * 400
     res = dict(d)
     res["records"] = {k: dict(v, workload=prose, losses=prose, roofline=dict(v.get("roofline") or {}, kernel=prose, traffic_note=prose))
