@@ -42,9 +42,11 @@ extern "C" {
                         * 8-17x below SN_DTYPE_BF16's (tests/test_trained_weights_gpu.py); activations beyond +-65504 overflow (the
                         * entry points do not check).  Blob layout and size = SN_DTYPE_BF16's. */
 #define SN_DTYPE_CLASSIC_HEADS 0x100
-/* OR-ed into `dtype` of sn_mlp_forward_train / sn_mlp_backward_chain (SN_DTYPE_BF16_STATE): run the compiler-scheduled kernels
- * (csrc/sn_mlp_fwd_bf16.hip, csrc/sn_mlp_bwd_bf16.hip) instead of the hand-scheduled ones (csrc/sn_mlp_fwd_bf16_t.hip, ...).
- * Same arithmetic, same stored state bit for bit; kept for A/B timing and the bit-identity tests. */
+/* OR-ed into `dtype` of sn_mlp_forward_train / sn_mlp_backward_chain: run the PREVIOUS generation of the kernel instead of the shipped one --
+ * SN_DTYPE_BF16_STATE / SN_DTYPE_BF16X3: the compiler-scheduled kernels (csrc/sn_mlp_fwd_bf16.hip, csrc/sn_mlp_bwd_bf16.hip,
+ * csrc/sn_mlp_{fwd,bwd}_bf16x3.hip) instead of the generated instruction streams (csrc/sn_mlp_*_t.hip); SN_DTYPE_F32 (round 6): the
+ * LDS-ring kernels (csrc/sn_mlp_fwd.hip, csrc/sn_mlp_bwd.hip) instead of the fragments-from-L2 ones (csrc/sn_mlp_fwd_f32g.hip,
+ * csrc/sn_mlp_bwd_f32g.hip).  Same arithmetic, same stored state bit for bit; kept for A/B timing and the bit-identity tests. */
 #define SN_DTYPE_COMPILER_SCHEDULED 0x200
 /* OR-ed into `dtype` (SN_DTYPE_BF16_STATE, hand-scheduled kernels) of sn_mlp_forward_train, sn_weight_grads and
  * sn_weight_grads_workspace_bytes -- all three or none: `emb` is a bf16 array (slot_rows, 128) holding the embedded inputs as the
